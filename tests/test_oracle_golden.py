@@ -1,0 +1,217 @@
+"""The CPU oracle against the golden vectors produced by running the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import adaptive_softmax as oas
+from oracle import graph as og
+from oracle import hgt as ohgt
+from oracle import knn as oknn
+from oracle import pq as opq
+
+
+# ---------------------------------------------------------------- PQ codec (pq_wrapper.py)
+@pytest.mark.parametrize("case", ["sq_pre", "sq_pre_nob", "rect_pre", "nopre"])
+def test_pq_codec(golden, case):
+    g = golden("pq")
+    cen = g[f"{case}.cen"]
+    A = g[f"{case}.A"] if f"{case}.A" in g else None
+    b = g[f"{case}.b"] if f"{case}.b" in g else None
+    codes = opq.pq_encode(g[f"{case}.x"], cen, A, b)
+    assert np.array_equal(codes, g[f"{case}.codes"])                      # integer work: bit-exact
+    dec = opq.pq_decode(codes, cen, A, b)
+    np.testing.assert_allclose(dec, g[f"{case}.decode"], atol=1e-6, rtol=1e-6)   # pq_wrapper.py:233-237
+    for metric in ("ip", "l2"):
+        norm2, sdc = opq.pq_tables(cen, metric)
+        np.testing.assert_allclose(norm2, g[f"{case}.norm2"], rtol=1e-6)
+        np.testing.assert_allclose(sdc[:, :8, :8], g[f"{case}.{metric}.sdc_corner"], atol=2e-6)
+        np.testing.assert_allclose(sdc.sum(-1), g[f"{case}.{metric}.sdc_rowsum"], rtol=1e-4, atol=1e-3)
+        sim = opq.compute_sim(codes[:5], codes, sdc)
+        np.testing.assert_allclose(sim, g[f"{case}.{metric}.sim"], rtol=1e-5, atol=1e-4)
+
+
+def full_size_codec():
+    rs = np.random.RandomState(77)
+    M, dsub, d = 128, 8, 1024
+    cen = (rs.randn(M, 256, dsub) * 0.5).astype(np.float32)
+    A = (rs.randn(d, d) / np.sqrt(d)).astype(np.float32)
+    b = (rs.randn(d) * 0.1).astype(np.float32)
+    return cen, A, b
+
+
+def test_pq_full_size(golden):
+    g = golden("pq")
+    cen, A, b = full_size_codec()
+    codes = g["full.codes"]
+    look = opq.pq_lookup(codes, cen)
+    assert float(np.float64(look).sum()) == float(g["full.lookup_checksum"][0])   # pure lookup: exact
+    np.testing.assert_allclose(opq.pq_decode(codes, cen, A, b), g["full.decode"], atol=2e-5, rtol=1e-5)
+
+
+# ---------------------------------------------------------------- kNN prob (knn_model.py)
+@pytest.mark.parametrize("metric_type", ["do_not_recomp_ip", "do_not_recomp_l2", "ip", "l2"])
+@pytest.mark.parametrize("cosine", [False, True])
+@pytest.mark.parametrize("t", [1.0, 0.01])
+def test_knn_prob(golden, metric_type, cosine, t):
+    g = golden("knn")
+    tag = f"{metric_type}.{'cos' if cosine else 'raw'}.t{t}"
+    q = oknn.normalize_queries(torch.from_numpy(g["queries"]), cosine)
+    sims = oknn.sims_from_search(g[tag + ".dists"], g[tag + ".ids"], q, metric_type, g["keys"], cosine)
+    p, recall = oknn.knn_target_prob(sims, g[tag + ".ids"], g["vals"], g["targets"], t)
+    np.testing.assert_allclose(p.numpy(), g[tag + ".p"], rtol=2e-5, atol=1e-7)
+    assert np.array_equal(recall.numpy(), g[tag + ".recall"])
+    masked = sims.clone()
+    masked[torch.from_numpy(g[tag + ".ids"] == -1)] = oknn.MASK_VALUE
+    np.testing.assert_allclose(masked.numpy(), g[tag + ".sims"], rtol=1e-5, atol=1e-5)
+
+
+def test_brute_force_search_matches_reference_stand_in(golden):
+    g = golden("knn")
+    q = oknn.normalize_queries(torch.from_numpy(g["queries"]), True).numpy()
+    d, i = oknn.brute_force_search(q, g["keys"], 8, "ip", cosine=True)
+    ref_i = g["do_not_recomp_ip.cos.t1.0.ids"]
+    keep = ref_i != -1
+    assert np.array_equal(i[keep], ref_i[keep])
+
+
+def test_combine(golden):
+    g = golden("combine")
+    for lm in (0.1, 0.15, 0.2, 0.25):
+        out = oknn.combine_knn_and_vocab_probs(g["p_knn"], g["lm_logp"], lm)
+        np.testing.assert_allclose(out.numpy(), g[f"mix.{lm}"], rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------- graph (token_block_dataset.py)
+def test_build_ntgt_edges_doctest():
+    o2i = {0: 0, 1: 1, 2: 2, 12: 3, 13: 4}
+    assert og.build_ntgt_edges(o2i, 3) == ([0, 0, 1, 0, 1, 2, 3, 3, 4], [0, 1, 1, 2, 2, 2, 3, 4, 4])
+    assert og.build_ntgt_edges(o2i, 0) == ([0, 1, 2, 3, 4], [0, 1, 2, 3, 4])
+    assert og.build_ntgt_edges({}, 1, True) == ([], [])
+
+
+def test_edge_builders(golden):
+    g = golden("graph")
+    o2i = {0: 0, 1: 1, 2: 2, 12: 3, 13: 4}
+    for ctx, bi in [(3, False), (0, False), (1, True), (1, False), (2, True)]:
+        s, t = og.build_ntgt_edges(o2i, ctx, bi)
+        assert np.array_equal(np.array([s, t]), g[f"edges.ctx{ctx}.bi{int(bi)}"])
+    for L_, mc in [(5, 0), (8, 3), (1, 0)]:
+        us, vs = og.auto_regressive_edges(L_, mc)
+        assert np.array_equal(np.stack([us, vs]), g[f"ar.{L_}.{mc}"])
+
+
+GRAPH_TAGS = ["T8k4l0r0", "T8k4l1r1", "T8k4l2r2", "T6k3l2r0", "T6k3l0r2", "T5k2l3r1"]
+
+
+def _lr(tag):
+    return int(tag[tag.index("l") + 1]), int(tag[tag.index("r") + 1])
+
+
+@pytest.mark.parametrize("tag", GRAPH_TAGS)
+def test_build_graph(golden, tag):
+    g = golden("graph")
+    l, r = _lr(tag)
+    nb, codes, vals = g[tag + ".nb"], g["codes"], g["vals"]
+    n_store = codes.shape[0]
+    gr = og.build_graph(nb, np.zeros(nb.shape[0], np.int64), n_store, l, r)
+    assert np.array_equal(np.stack(gr["inter"]), g[tag + ".ntgt_inter_tgt"])
+    assert np.array_equal(np.stack(gr["intra_ntgt"]), g[tag + ".ntgt_intra_ntgt"])
+    assert np.array_equal(np.stack(gr["intra_tgt"]), g[tag + ".tgt_intra_tgt"])
+    assert np.array_equal(codes[gr["ntgt_offsets"]], g[tag + ".ntgt_codes"])
+    assert np.array_equal(vals[gr["ntgt_offsets"]], g[tag + ".ntgt_labels"])
+    # the padded slot layout walks the same nodes in the same order
+    rows, valid = og.slot_layout(nb, n_store, l, r)
+    assert np.array_equal(rows[valid], gr["ntgt_offsets"])
+
+
+# ---------------------------------------------------------------- HGT (hgt.py under the DGL stand-in)
+def hgt_cases(g):
+    keys = sorted({k.split(".tgt_in")[0] for k in g.files if k.endswith(".tgt_in")})
+    return keys
+
+
+def test_hgt_layers(golden):
+    g, gg = golden("hgt"), golden("graph")
+    cases = hgt_cases(g)
+    assert len(cases) >= 8
+    for key in cases:
+        tag, cfg = key.split(".")
+        n_layers, n_heads = int(cfg[1]), int(cfg[3:])
+        l, r = _lr(tag)
+        nb = gg[tag + ".nb"]
+        gr = og.build_graph(nb, np.zeros(nb.shape[0], np.int64), g["codes"].shape[0], l, r)
+        sd = {k[len(key) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(key + ".sd.")}
+        ntgt = opq.pq_decode(g["codes"][gr["ntgt_offsets"]], g["cen"], g["A"], g["b"])
+        feats = {"tgt": torch.from_numpy(g[key + ".tgt_in"]), "ntgt": torch.from_numpy(ntgt)}
+        outs = ohgt.hgt_forward(sd, n_layers, n_heads, feats, gr, return_all_layers=True)
+        for i, h in enumerate(outs):
+            np.testing.assert_allclose(h["tgt"].numpy(), g[key + f".tgt_out{i}"], atol=2e-5, rtol=1e-4)
+            np.testing.assert_allclose(h["ntgt"].numpy(), g[key + f".ntgt_out{i}"], atol=2e-5, rtol=1e-4)
+
+
+# ---------------------------------------------------------------- adaptive softmax
+def asm_weights(g):
+    return {"cutoff": list(g["cutoff"]), "emb": [torch.from_numpy(g[f"emb{i}"]) for i in range(3)],
+            "proj": [None] + [torch.from_numpy(g[f"proj{i}"]) for i in (1, 2)],
+            "class_proj": torch.from_numpy(g["class_proj"])}
+
+
+def test_adaptive_softmax(golden):
+    g = golden("adaptive_softmax")
+    w = asm_weights(g)
+    x = torch.from_numpy(g["x"]).view(-1, g["x"].shape[-1])
+    t = torch.from_numpy(g["target"]).view(-1)
+    np.testing.assert_allclose(oas.target_log_prob(x, t, w).numpy(), g["target_logp"].reshape(-1),
+                               atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(oas.dense_log_prob(x, w).numpy(), g["dense"].reshape(x.shape[0], -1),
+                               atol=2e-6, rtol=1e-5)
+
+
+# ---------------------------------------------------------------- scoring chain (sequence_scorer.py)
+@pytest.mark.parametrize("keytype", ["gcn_feat", "keytype"])
+@pytest.mark.parametrize("lmbda,temp", [(0.25, 1.0), (0.1, 0.01), (0.0, 1.0)])
+def test_scorer_chain(golden, keytype, lmbda, temp):
+    g, ga = golden("scorer"), golden("adaptive_softmax")
+    w = asm_weights(ga)
+    feats, inner, target = torch.from_numpy(g["feats"]), torch.from_numpy(g["inner"]), torch.from_numpy(g["target"])
+    bsz, T, d = feats.shape
+    lm = oas.target_log_prob(feats.view(-1, d), target.view(-1).clamp(min=0), w).view(bsz, T)
+    if lmbda > 0:
+        q = feats.transpose(0, 1) if keytype == "gcn_feat" else inner            # [T,B,d]  sequence_scorer.py:105
+        q = oknn.normalize_queries(q.reshape(-1, d), True)
+        dists, ids = oknn.brute_force_search(q.numpy(), g["keys"], 6, "ip", cosine=True)
+        # reproduce the stand-in's trailing -1 padding on every third row
+        for rrow in range(0, q.shape[0], 3):
+            ids[rrow, -1:] = -1
+            dists[rrow, -1:] = -3.4e38
+        tq = target.transpose(0, 1).reshape(-1)                                 # [T*B] order of the queries
+        tq = target.permute(0, 1).reshape(T * bsz)                              # as written at :117 (bug kept)
+        p, rec = oknn.knn_target_prob(dists, ids, g["vals"], tq, temp)
+        p = p.view(T, bsz).t()
+        rec = rec.view(T, bsz).t()
+        lm = oknn.combine_knn_and_vocab_probs(p, lm, lmbda)
+    for i in range(bsz):
+        s = int(g["start_indices"][i])
+        tag = f"{keytype}.l{lmbda}.t{temp}.{i}"
+        n = len(g[tag + ".tokens"])
+        np.testing.assert_allclose(lm[i, s:s + n].numpy(), g[tag + ".positional_scores"], rtol=2e-5, atol=2e-6)
+        if lmbda > 0:
+            assert np.array_equal(rec[i, s:][target[i, s:] != 1].numpy(), g[tag + ".knn_recall"])
+
+
+# ---------------------------------------------------------------- datastore raw format (data_store.py)
+@pytest.mark.parametrize("name", ["fp16_i16", "fp16_i32", "fp32_i32", "fp16_v2"])
+def test_datastore_format(golden, name):
+    g = golden("datastore")
+    info = json.loads(bytes(g[name + ".info"]).decode())
+    kdt = np.float16 if info["dstore_fp16"] else np.float32
+    vdt = np.int16 if info["dstore_fp16"] and info["vocab_size"] < 2 ** 15 else np.int32   # data_store.py:50
+    keys = np.frombuffer(bytes(g[name + ".keys_raw"]), dtype=kdt).reshape(info["dstore_size"], info["hidden_size"])
+    vals = np.frombuffer(bytes(g[name + ".vals_raw"]), dtype=vdt).reshape(info["dstore_size"], info["val_size"])
+    if info["val_size"] == 1:
+        vals = vals.reshape(-1)
+    assert np.array_equal(keys, g[name + ".keys"]) and keys.dtype == g[name + ".keys"].dtype
+    assert np.array_equal(vals, g[name + ".vals"]) and vals.dtype == g[name + ".vals"].dtype
