@@ -1,0 +1,136 @@
+"""ctypes binding of libgnnlm_hip.so (C ABI: include/gnnlm.h).
+
+The descriptor structs are generated from the header itself, so the header stays the single source
+of truth.  There is NO fallback: if the shared library is missing or is not the gfx950 build,
+importing a kernel entry point raises (the product path must fail loudly without the HIP library).
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+HEADER = os.path.join(ROOT, "include", "gnnlm.h")
+LIB_PATH = os.path.join(_HERE, "lib", "libgnnlm_hip.so")
+
+_SCALARS = {
+    "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+    "double": ctypes.c_double, "size_t": ctypes.c_size_t, "uint8_t": ctypes.c_uint8, "int": ctypes.c_int,
+}
+
+
+def _parse_structs(text):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields = []
+        for stmt in m.group(2).split(";"):
+            stmt = " ".join(stmt.split())
+            if not stmt:
+                continue
+            mm = re.match(r"(const\s+)?(\w+)\s*(.*)", stmt)
+            base, rest = mm.group(2), mm.group(3)
+            for decl in rest.split(","):
+                decl = decl.strip()
+                ptr = decl.startswith("*")
+                decl = decl.lstrip("* ")
+                arr = re.match(r"(\w+)\s*\[(\d+)\]", decl)
+                name = arr.group(1) if arr else decl
+                if ptr:
+                    ctype = ctypes.c_void_p
+                elif base in _SCALARS:
+                    ctype = _SCALARS[base]
+                else:
+                    raise ValueError(f"gnnlm.h: unsupported field type {base!r} in {m.group(3)}")
+                if arr:
+                    ctype = ctype * int(arr.group(2))
+                fields.append((name, ctype))
+        structs[m.group(3)] = type(m.group(3), (ctypes.Structure,), {"_fields_": fields})
+    return structs
+
+
+def _normalise(text):
+    # "const float* A" -> "const float *A" so that the pointer star belongs to the declarator
+    return re.sub(r"(\w)\*\s*(\w)", r"\1 *\2", text)
+
+
+STRUCTS = _parse_structs(_normalise(open(HEADER).read()))
+globals().update(STRUCTS)
+
+
+def exported_symbols():
+    """Every function the header declares (used by the CPU-side ABI test)."""
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(gnnlm_\w+)\s*\(", text)))
+
+
+class GnnlmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it is absent -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GnnlmError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  gnnlm_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.gnnlm_last_error.restype = ctypes.c_char_p
+        L.gnnlm_target_arch.restype = ctypes.c_char_p
+        L.gnnlm_adaptive_workspace_bytes.restype = ctypes.c_size_t
+        L.gnnlm_hgt_workspace_bytes.restype = ctypes.c_size_t
+        L.gnnlm_sizeof.restype = ctypes.c_size_t
+        L.gnnlm_sizeof.argtypes = [ctypes.c_char_p]
+        L.gnnlm_store_codes.restype = ctypes.c_void_p
+        L.gnnlm_store_vals.restype = ctypes.c_void_p
+        vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+        L.gnnlm_causal_softmax.argtypes = [vp, i64, i32, i64, i32, vp]
+        L.gnnlm_layernorm.argtypes = [vp, i64, vp, vp, vp, i64, i64, i32, f32, vp, vp]
+        L.gnnlm_half_to_float.argtypes = [vp, vp, i64, vp]
+        L.gnnlm_row_lse_pick.argtypes = [vp, i64, i64, vp, i32, vp, vp, vp, vp]
+        L.gnnlm_adaptive_workspace_bytes.argtypes = [vp, i64]
+        L.gnnlm_adaptive_target_logp.argtypes = [vp, vp, i64, vp, i64, vp, vp, ctypes.c_size_t, vp]
+        L.gnnlm_masked_sum_f64.argtypes = [vp, vp, i64, vp, vp]
+        L.gnnlm_hgt_workspace_bytes.argtypes = [vp, vp]
+        L.gnnlm_hgt_forward.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
+        for nm in ("gnnlm_gemm_nt", "gnnlm_pq_gather_decode", "gnnlm_star_attn", "gnnlm_chain_attn",
+                   "gnnlm_knn_interp"):
+            getattr(L, nm).argtypes = [vp, vp]
+        if L.gnnlm_target_arch() != b"gfx950" or L.gnnlm_abi_version() != 1:
+            raise GnnlmError("libgnnlm_hip.so is not the gfx950 / ABI-1 build")
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise GnnlmError(f"{what} failed ({rc}): {lib().gnnlm_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  Tensors must be contiguous CUDA tensors."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise GnnlmError("gnnlm_amd kernels need device (HIP) tensors; there is no CPU fallback")
+    if not t.is_contiguous():
+        raise GnnlmError("gnnlm_amd kernels need contiguous tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+def call_desc(name, desc):
+    check(getattr(lib(), name)(ctypes.byref(desc), stream()), name)

@@ -1,0 +1,440 @@
+// C ABI of libgnnlm_hip.so (include/gnnlm.h): thin wrappers over the kernel launchers plus the two
+// host-side orchestrators of the eval hot path -- the HGT forward over the implicit token/neighbour
+// graph and the target-only tied adaptive softmax.  Orchestrators only enqueue kernels on the given
+// stream (no allocation, no synchronisation), so a caller may capture them into a hipGraph.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "kernels.h"
+
+namespace gnnlm {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_last_error = buf;
+    return E_HIP;
+}
+
+namespace {
+
+// bump allocator over a caller-provided workspace; a null base only measures
+struct Carver {
+    char* base;
+    size_t off = 0, cap;
+    Carver(void* b, size_t c) : base(reinterpret_cast<char*>(b)), cap(c) {}
+    template <class T>
+    T* take(int64_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (size_t)std::max<int64_t>(n, 0) * sizeof(T);
+        return p;
+    }
+    bool fits() const { return !base || off <= cap; }
+};
+
+struct HgtBufs {
+    // tgt side
+    float *ht[2], *q, *k, *vt, *scores, *mc, *U, *Z, *ms, *aout, *has_nb;
+    // ntgt side
+    float *hn[2], *nq, *nk, *nv;
+    uint8_t* valid;
+    int64_t Tp;
+};
+
+bool needs_ntgt(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io) { return m.n_layers > 1 || io.out_ntgt != nullptr; }
+
+void carve_hgt(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, Carver& c, HgtBufs& b) {
+    const int64_t Tt = (int64_t)io.n_blocks * io.T, d = m.d, H = m.n_heads;
+    const int64_t dpq = (int64_t)m.M * m.dsub, dmax = std::max<int64_t>(dpq, d);
+    b.Tp = (io.T + 3) & ~3;
+    b.ht[0] = c.take<float>(Tt * d);
+    b.ht[1] = c.take<float>(Tt * d);
+    b.q = c.take<float>(Tt * d);
+    b.k = c.take<float>(Tt * d);
+    b.vt = c.take<float>((int64_t)io.n_blocks * d * b.Tp);
+    b.scores = c.take<float>((int64_t)io.n_blocks * H * io.T * b.Tp);
+    b.mc = c.take<float>(Tt * d);
+    b.U = c.take<float>(Tt * H * dmax);
+    b.Z = c.take<float>(Tt * H * dmax);
+    b.ms = c.take<float>(Tt * d);
+    b.aout = c.take<float>(Tt * d);
+    b.has_nb = c.take<float>(Tt);
+    if (needs_ntgt(m, io)) {
+        const int64_t S = Tt * io.kg * (1 + m.left + m.right);
+        b.hn[0] = c.take<float>(S * dmax);
+        b.hn[1] = c.take<float>(S * dmax);
+        b.nq = c.take<float>(S * dmax);
+        b.nk = c.take<float>(S * dmax);
+        b.nv = c.take<float>(S * dmax);
+        b.valid = c.take<uint8_t>(S);
+    } else {
+        b.hn[0] = b.hn[1] = b.nq = b.nk = b.nv = nullptr;
+        b.valid = nullptr;
+    }
+}
+
+int linear(const float* A, int64_t lda, const float* W, const float* bias, float* C, int64_t M, int N, int K,
+           const float* R, float alpha, hipStream_t s) {
+    GemmParams g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = N;
+    g.bias = bias; g.bias_mode = bias ? 1 : 0;
+    g.R = R; g.ldr = N; g.alpha = alpha;
+    g.M = (int)M; g.N = N; g.K = K;
+    return gemm_nt(g, s);
+}
+
+#define TRY(x)                 \
+    do {                       \
+        int _rc = (x);         \
+        if (_rc != OK) return _rc; \
+    } while (0)
+
+int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, size_t ws_bytes, hipStream_t s) {
+    GNNLM_REQUIRE(m.layers && m.n_layers >= 1, "hgt: no layers");
+    GNNLM_REQUIRE(m.d > 0 && m.n_heads > 0 && m.d % m.n_heads == 0, "hgt: d must be divisible by n_heads");
+    GNNLM_REQUIRE(io.tgt_feats && io.ids && io.out_tgt, "hgt: null io");
+    GNNLM_REQUIRE(io.n_blocks >= 0 && io.T >= 0 && io.kg > 0, "hgt: bad io shape");
+    GNNLM_REQUIRE(m.centroids && m.M > 0 && m.dsub > 0, "hgt: codec missing");
+    GNNLM_REQUIRE(io.fetched_codes || m.codes, "hgt: no code store");
+    const bool ntgt = needs_ntgt(m, io);
+    GNNLM_REQUIRE(!(io.fetched_centres_only && ntgt), "hgt: fetched_centres_only needs n_layers == 1 and no out_ntgt");
+    GNNLM_REQUIRE(!io.fetched_codes || io.fetched_valid || io.fetched_centres_only, "hgt: fetched_codes needs fetched_valid");
+    const int64_t Tt = (int64_t)io.n_blocks * io.T;
+    if (Tt == 0) return OK;
+    const int d = m.d, H = m.n_heads, dk = d / H, T = io.T, kg = io.kg, nb = io.n_blocks;
+    const int n_g = 1 + m.left + m.right;
+    const int dpq = m.M * m.dsub;
+    const int64_t G = Tt * kg, S = G * n_g;
+    GNNLM_REQUIRE(dk % 4 == 0 && d % 4 == 0 && dpq % 4 == 0, "hgt: d_k and the PQ dimension must be multiples of 4");
+    GNNLM_REQUIRE(m.opq_at || dpq == d, "hgt: without OPQ the PQ dimension must equal d");
+
+    Carver c(ws, ws_bytes);
+    HgtBufs b;
+    carve_hgt(m, io, c, b);
+    GNNLM_REQUIRE(ws && c.fits(), "hgt: workspace too small (see gnnlm_hgt_workspace_bytes)");
+    const int64_t Tp = b.Tp;
+
+    const float* hn_cur = nullptr;
+    const uint8_t* valid = nullptr;
+    if (ntgt) {
+        // layer-0 ntgt states: PQ lookup of every slot, then the OPQ rotation (pq_wrapper.py:189-202)
+        GatherParams g{};
+        g.codes = io.fetched_codes ? io.fetched_codes : m.codes;
+        g.direct = io.fetched_codes ? 1 : 0;
+        g.in_valid = io.fetched_valid;
+        g.vals = nullptr; g.vals_itemsize = 4;
+        g.n_store = m.n_store; g.row0 = m.row0; g.n_local = m.n_local;
+        g.M = m.M; g.dsub = m.dsub; g.centroids = m.centroids;
+        g.ids = io.ids; g.n_groups = G; g.left = m.left; g.right = m.right;
+        g.out_valid = b.valid;
+        if (m.opq_at) {
+            g.out_x = b.nq; g.ld_x = dpq;
+            TRY(gather_decode(g, s));
+            TRY(linear(b.nq, dpq, m.opq_at, m.opq_nba, b.hn[0], S, d, dpq, nullptr, 1.f, s));
+        } else {
+            g.out_x = b.hn[0]; g.ld_x = d;
+            TRY(gather_decode(g, s));
+        }
+        hn_cur = b.hn[0];
+        valid = b.valid;
+        if (io.out_valid) GNNLM_HIP(hipMemcpyAsync(io.out_valid, b.valid, (size_t)S, hipMemcpyDeviceToDevice, s));
+    }
+    // V^T buffer: its padding columns (t >= T) are read by the P.V GEMM against zero probabilities
+    GNNLM_HIP(hipMemsetAsync(b.vt, 0, sizeof(float) * (size_t)nb * d * Tp, s));
+
+    const float* ht_in = io.tgt_feats;
+    for (int l = 0; l < m.n_layers; ++l) {
+        const gnnlm_hgt_layer_t& w = m.layers[l];
+        const bool last = l == m.n_layers - 1;
+        const int din = w.din;
+        GNNLM_REQUIRE(w.wq_t && w.wk_t && w.wv_t && w.wa_t && w.ln_g_t && w.ln_b_t && w.wku && w.wvz_t,
+                      "hgt: layer has null tgt weights");
+        GNNLM_REQUIRE(din == (l == 0 ? dpq : d), "hgt: layer.din must be M*dsub for layer 0 and d afterwards");
+
+        // ---- tgt projections (hgt.py:315-322 with the 'intra' relation folded into K and V)
+        TRY(linear(ht_in, d, w.wq_t, w.bq_t, b.q, Tt, d, d, nullptr, 1.f, s));
+        TRY(linear(ht_in, d, w.wk_t, w.bk_t, b.k, Tt, d, d, nullptr, 1.f, s));
+        {   // V'^T[blk][n][t] = sum_k Wv'[n,k] h[blk*T + t, k] + bv'[n]
+            GemmParams g{};
+            g.A = w.wv_t; g.lda = d; g.W = ht_in; g.ldw = d; g.C = b.vt; g.ldc = Tp;
+            g.bias = w.bv_t; g.bias_mode = 2;
+            g.M = d; g.N = T; g.K = d; g.batch1 = nb;
+            g.sW1 = (int64_t)T * d; g.sC1 = (int64_t)d * Tp;
+            TRY(gemm_nt(g, s));
+        }
+        {   // causal scores S[blk,h] = Q_h K'_h^T   (scale folded into K')
+            GemmParams g{};
+            g.A = b.q; g.lda = d; g.W = b.k; g.ldw = d; g.C = b.scores; g.ldc = Tp;
+            g.M = T; g.N = T; g.K = dk; g.batch1 = nb; g.batch2 = H;
+            g.sA1 = (int64_t)T * d; g.sA2 = dk; g.sW1 = (int64_t)T * d; g.sW2 = dk;
+            g.sC1 = (int64_t)H * T * Tp; g.sC2 = (int64_t)T * Tp;
+            TRY(gemm_nt(g, s));
+        }
+        TRY(causal_softmax(b.scores, (int64_t)nb * H, T, Tp, m.max_intra_context, s));
+        {   // m_causal[blk, :, h] = P[blk,h] V'_h
+            GemmParams g{};
+            g.A = b.scores; g.lda = Tp; g.W = b.vt; g.ldw = Tp; g.C = b.mc; g.ldc = d;
+            g.M = T; g.N = dk; g.K = (int)Tp; g.batch1 = nb; g.batch2 = H;
+            g.sA1 = (int64_t)H * T * Tp; g.sA2 = (int64_t)T * Tp;
+            g.sW1 = (int64_t)d * Tp; g.sW2 = (int64_t)dk * Tp;
+            g.sC1 = (int64_t)T * d; g.sC2 = dk;
+            TRY(gemm_nt(g, s));
+        }
+        {   // absorbed star queries U[i,h,:] = Wku_h q[i,h,:]
+            GemmParams g{};
+            g.A = b.q; g.lda = d; g.W = w.wku; g.ldw = dk; g.C = b.U; g.ldc = (int64_t)H * din;
+            g.M = (int)Tt; g.N = din; g.K = dk; g.batch1 = H;
+            g.sA1 = dk; g.sW1 = (int64_t)din * dk; g.sC1 = din;
+            TRY(gemm_nt(g, s));
+        }
+        {
+            StarAttnParams a{};
+            a.U = b.U; a.ids = io.ids; a.T = (int)Tt; a.H = H; a.D = din; a.kg = kg;
+            a.Z = b.Z; a.has_nb = b.has_nb;
+            if (l == 0) {
+                a.codes = io.fetched_codes ? io.fetched_codes : m.codes;
+                a.codes_direct = io.fetched_codes ? (io.fetched_centres_only ? 1 : n_g) : 0;
+                a.row0 = m.row0; a.n_local = m.n_local; a.M = m.M; a.dsub = m.dsub; a.centroids = m.centroids;
+            } else {
+                a.X = hn_cur; a.ldx = d; a.x_group_stride = n_g;
+            }
+            TRY(star_attn(a, s));
+        }
+        {   // 2*agg = Z Wvz + has_nb * bvz + m_causal
+            GemmParams g{};
+            g.A = b.Z; g.lda = (int64_t)H * din; g.W = w.wvz_t; g.ldw = din; g.C = b.ms; g.ldc = d;
+            g.bias = w.bvz; g.bias_mode = 1; g.gate = b.has_nb; g.R = b.mc; g.ldr = d;
+            g.M = (int)Tt; g.N = dk; g.K = din; g.batch1 = H;
+            g.sA1 = din; g.sW1 = (int64_t)dk * din; g.sC1 = dk; g.sB1 = dk; g.sR1 = dk;
+            TRY(gemm_nt(g, s));
+        }
+        // a_linear on the cross-type mean (0.5 folded into alpha) + residual, then LayerNorm (hgt.py:397-405)
+        TRY(linear(b.ms, d, w.wa_t, w.ba_t, b.aout, Tt, d, d, ht_in, 0.5f, s));
+        float* ht_out = last ? io.out_tgt : b.ht[l & 1];
+        TRY(layernorm(b.aout, d, w.ln_g_t, w.ln_b_t, ht_out, d, Tt, d, m.ln_eps, nullptr, s));
+
+        // ---- ntgt update (only when a later layer -- or the caller -- consumes it)
+        if (ntgt && (!last || io.out_ntgt)) {
+            GNNLM_REQUIRE(w.wq_n && w.wk_n && w.wv_n && w.wa_n && w.ln_g_n && w.ln_b_n, "hgt: layer has null ntgt weights");
+            TRY(linear(hn_cur, d, w.wq_n, w.bq_n, b.nq, S, d, d, nullptr, 1.f, s));
+            TRY(linear(hn_cur, d, w.wk_n, w.bk_n, b.nk, S, d, d, nullptr, 1.f, s));
+            TRY(linear(hn_cur, d, w.wv_n, w.bv_n, b.nv, S, d, d, nullptr, 1.f, s));
+            ChainAttnParams ca{};
+            ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
+            ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
+            ca.out = b.nq; ca.ldo = d;      // in place over Q: a (group, head) task loads before it stores
+            TRY(chain_attn(ca, s));
+            TRY(linear(b.nq, d, w.wa_n, w.ba_n, b.nk, S, d, d, hn_cur, 1.f, s));
+            float* hn_out = (last && io.out_ntgt) ? io.out_ntgt : (hn_cur == b.hn[0] ? b.hn[1] : b.hn[0]);
+            TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, S, d, m.ln_eps, valid, s));
+            hn_cur = hn_out;
+        }
+        ht_in = ht_out;
+    }
+    return OK;
+}
+
+struct AsmBufs {
+    float *head_logits, *head_lse, *head_picked, *xi, *tail_logits, *tail_lse, *tail_picked;
+    int32_t *head_pick, *band_rows, *band_pick, *band_count;
+};
+
+void carve_asm(const gnnlm_adaptive_softmax_t& w, int64_t n, Carver& c, AsmBufs& b) {
+    const int nt = w.n_bands - 1;
+    const int64_t head_n = w.cutoff[0] + nt;
+    int64_t max_size = 0, max_dim = 0;
+    for (int i = 1; i < w.n_bands; ++i) {
+        max_size = std::max<int64_t>(max_size, w.cutoff[i] - w.cutoff[i - 1]);
+        max_dim = std::max<int64_t>(max_dim, w.dim[i]);
+    }
+    b.head_logits = c.take<float>(n * head_n);
+    b.head_lse = c.take<float>(n);
+    b.head_picked = c.take<float>(n);
+    b.head_pick = c.take<int32_t>(n);
+    b.band_rows = c.take<int32_t>(std::max(nt, 1) * n);
+    b.band_pick = c.take<int32_t>(std::max(nt, 1) * n);
+    b.band_count = c.take<int32_t>(8);
+    b.xi = c.take<float>(n * max_dim);
+    b.tail_logits = c.take<float>(n * max_size);
+    b.tail_lse = c.take<float>(n);
+    b.tail_picked = c.take<float>(n);
+}
+
+int adaptive_impl(const gnnlm_adaptive_softmax_t& w, const float* x, int64_t ldx, const int64_t* target, int64_t n,
+                  float* lm_logp, void* ws, size_t ws_bytes, hipStream_t s) {
+    GNNLM_REQUIRE(w.n_bands >= 1 && w.n_bands <= 8 && w.head_w && w.d > 0 && w.d % 4 == 0, "adaptive: bad weights");
+    GNNLM_REQUIRE(x && target && lm_logp, "adaptive: null io");
+    if (n == 0) return OK;
+    GNNLM_REQUIRE(n < (1ll << 31), "adaptive: too many rows");
+    Carver c(ws, ws_bytes);
+    AsmBufs b;
+    carve_asm(w, n, c, b);
+    GNNLM_REQUIRE(ws && c.fits(), "adaptive: workspace too small (see gnnlm_adaptive_workspace_bytes)");
+    const int nt = w.n_bands - 1;
+    const int head_n = w.cutoff[0] + nt;
+
+    BandSplitParams bs;
+    bs.target = target; bs.n = n; bs.n_bands = w.n_bands;
+    for (int i = 0; i < w.n_bands; ++i) bs.cutoff[i] = w.cutoff[i];
+    bs.head_pick = b.head_pick; bs.band_rows = b.band_rows; bs.band_pick = b.band_pick; bs.band_count = b.band_count;
+    TRY(band_split(bs, s));
+
+    {   // head: [E_0 ; class_proj] (adaptive_softmax.py:24-47,184-188)
+        GemmParams g{};
+        g.A = x; g.lda = ldx; g.W = w.head_w; g.ldw = w.d; g.C = b.head_logits; g.ldc = head_n;
+        g.M = (int)n; g.N = head_n; g.K = w.d;
+        TRY(gemm_nt(g, s));
+    }
+    TRY(row_lse_pick(b.head_logits, head_n, n, nullptr, head_n, b.head_pick, b.head_lse, b.head_picked, s));
+    TRY(head_logp(b.head_picked, b.head_lse, lm_logp, n, s));
+
+    for (int i = 1; i < w.n_bands; ++i) {   // tails (adaptive_softmax.py:91-115,199-203), target rows only
+        GNNLM_REQUIRE(w.proj_t[i] && w.emb[i] && w.dim[i] > 0 && w.dim[i] % 4 == 0, "adaptive: bad tail band");
+        const int size = w.cutoff[i] - w.cutoff[i - 1];
+        const int32_t* rows = b.band_rows + (int64_t)(i - 1) * n;
+        const int32_t* pick = b.band_pick + (int64_t)(i - 1) * n;
+        const int32_t* cnt = b.band_count + (i - 1);
+        GemmParams g{};
+        g.A = x; g.lda = ldx; g.a_rows = rows; g.W = w.proj_t[i]; g.ldw = w.d; g.C = b.xi; g.ldc = w.dim[i];
+        g.M = (int)n; g.N = w.dim[i]; g.K = w.d; g.m_dev = cnt;
+        TRY(gemm_nt(g, s));
+        GemmParams t{};
+        t.A = b.xi; t.lda = w.dim[i]; t.W = w.emb[i]; t.ldw = w.dim[i]; t.C = b.tail_logits; t.ldc = size;
+        t.M = (int)n; t.N = size; t.K = w.dim[i]; t.m_dev = cnt;
+        TRY(gemm_nt(t, s));
+        TRY(row_lse_pick(b.tail_logits, size, n, cnt, size, pick, b.tail_lse, b.tail_picked, s));
+        TRY(tail_combine(b.tail_picked, b.tail_lse, rows, cnt, n, lm_logp, s));
+    }
+    return OK;
+}
+
+}  // namespace
+}  // namespace gnnlm
+
+using namespace gnnlm;
+
+struct gnnlm_store {
+    int64_t n_store, row0, n_local;
+    int32_t M, vals_itemsize, device;
+    uint8_t* codes;
+    void* vals;
+};
+
+extern "C" {
+
+const char* gnnlm_last_error(void) { return g_last_error.c_str(); }
+int gnnlm_abi_version(void) { return GNNLM_ABI_VERSION; }
+const char* gnnlm_target_arch(void) { return "gfx950"; }
+size_t gnnlm_sizeof(const char* name) {
+    if (!name) return 0;
+#define GNNLM_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
+    GNNLM_SZ(gnnlm_gemm_t) GNNLM_SZ(gnnlm_gather_t) GNNLM_SZ(gnnlm_star_attn_t) GNNLM_SZ(gnnlm_chain_attn_t)
+    GNNLM_SZ(gnnlm_adaptive_softmax_t) GNNLM_SZ(gnnlm_knn_interp_t) GNNLM_SZ(gnnlm_hgt_layer_t)
+    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t)
+#undef GNNLM_SZ
+    return 0;
+}
+
+#define GNNLM_DESC(d)                                       \
+    if (!(d)) {                                             \
+        set_error("invalid argument: null descriptor");     \
+        return E_INVALID;                                   \
+    }
+
+int gnnlm_gemm_nt(const gnnlm_gemm_t* d, void* stream) { GNNLM_DESC(d); return gemm_nt(*d, (hipStream_t)stream); }
+int gnnlm_pq_gather_decode(const gnnlm_gather_t* d, void* stream) { GNNLM_DESC(d); return gather_decode(*d, (hipStream_t)stream); }
+int gnnlm_star_attn(const gnnlm_star_attn_t* d, void* stream) { GNNLM_DESC(d); return star_attn(*d, (hipStream_t)stream); }
+int gnnlm_chain_attn(const gnnlm_chain_attn_t* d, void* stream) { GNNLM_DESC(d); return chain_attn(*d, (hipStream_t)stream); }
+int gnnlm_causal_softmax(float* S, int64_t n_mats, int32_t T, int64_t ld, int32_t max_ctx, void* stream) {
+    return causal_softmax(S, n_mats, T, ld, max_ctx, (hipStream_t)stream);
+}
+int gnnlm_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo,
+                    int64_t rows, int32_t d, float eps, const uint8_t* valid, void* stream) {
+    return layernorm(x, ldx, gamma, beta, out, ldo, rows, d, eps, valid, (hipStream_t)stream);
+}
+int gnnlm_half_to_float(const void* src, float* dst, int64_t n, void* stream) {
+    return half_to_float(src, dst, n, (hipStream_t)stream);
+}
+int gnnlm_row_lse_pick(const float* logits, int64_t ld, int64_t rows, const int32_t* m_dev, int32_t n,
+                       const int32_t* pick, float* lse, float* picked, void* stream) {
+    return row_lse_pick(logits, ld, rows, m_dev, n, pick, lse, picked, (hipStream_t)stream);
+}
+size_t gnnlm_adaptive_workspace_bytes(const gnnlm_adaptive_softmax_t* w, int64_t n) {
+    if (!w) return 0;
+    Carver c(nullptr, 0);
+    AsmBufs b;
+    carve_asm(*w, n, c, b);
+    return c.off + 256;
+}
+int gnnlm_adaptive_target_logp(const gnnlm_adaptive_softmax_t* w, const float* x, int64_t ldx, const int64_t* target,
+                               int64_t n, float* lm_logp, void* workspace, size_t workspace_bytes, void* stream) {
+    GNNLM_DESC(w);
+    return adaptive_impl(*w, x, ldx, target, n, lm_logp, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int gnnlm_knn_interp(const gnnlm_knn_interp_t* d, void* stream) { GNNLM_DESC(d); return knn_interp(*d, (hipStream_t)stream); }
+int gnnlm_masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, void* stream) {
+    return masked_sum_f64(x, mask, n, out, (hipStream_t)stream);
+}
+
+size_t gnnlm_hgt_workspace_bytes(const gnnlm_hgt_t* m, const gnnlm_hgt_io_t* io) {
+    if (!m || !io) return 0;
+    Carver c(nullptr, 0);
+    HgtBufs b;
+    carve_hgt(*m, *io, c, b);
+    return c.off + 256;
+}
+int gnnlm_hgt_forward(const gnnlm_hgt_t* m, const gnnlm_hgt_io_t* io, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    GNNLM_DESC(m);
+    GNNLM_DESC(io);
+    return hgt_forward_impl(*m, *io, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int gnnlm_store_create(int64_t n_store, int64_t row0, int64_t n_local, int32_t M, int32_t vals_itemsize,
+                       int32_t device, gnnlm_store_t** out) {
+    GNNLM_REQUIRE(out && n_store > 0 && row0 >= 0 && n_local > 0 && row0 + n_local <= n_store && M > 0,
+                  "store_create: bad shape");
+    GNNLM_REQUIRE(vals_itemsize == 2 || vals_itemsize == 4, "store_create: vals must be int16 or int32");
+    GNNLM_HIP(hipSetDevice(device));
+    gnnlm_store* s = new gnnlm_store{n_store, row0, n_local, M, vals_itemsize, device, nullptr, nullptr};
+    hipError_t e = hipMalloc((void**)&s->codes, (size_t)n_local * M);
+    if (e == hipSuccess) e = hipMalloc(&s->vals, (size_t)n_local * vals_itemsize);
+    if (e != hipSuccess) {
+        if (s->codes) (void)hipFree(s->codes);
+        delete s;
+        set_error(std::string("store_create: hipMalloc failed: ") + hipGetErrorString(e));
+        return E_NOMEM;
+    }
+    *out = s;
+    return OK;
+}
+int gnnlm_store_upload_codes(gnnlm_store_t* s, const uint8_t* host, int64_t first, int64_t n, void* stream) {
+    GNNLM_REQUIRE(s && host && first >= 0 && n >= 0 && first + n <= s->n_local, "store_upload_codes: bad range");
+    GNNLM_HIP(hipMemcpyAsync(s->codes + first * s->M, host, (size_t)n * s->M, hipMemcpyHostToDevice, (hipStream_t)stream));
+    GNNLM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return OK;
+}
+int gnnlm_store_upload_vals(gnnlm_store_t* s, const void* host, int64_t first, int64_t n, void* stream) {
+    GNNLM_REQUIRE(s && host && first >= 0 && n >= 0 && first + n <= s->n_local, "store_upload_vals: bad range");
+    GNNLM_HIP(hipMemcpyAsync((char*)s->vals + first * s->vals_itemsize, host, (size_t)n * s->vals_itemsize,
+                             hipMemcpyHostToDevice, (hipStream_t)stream));
+    GNNLM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return OK;
+}
+const uint8_t* gnnlm_store_codes(const gnnlm_store_t* s) { return s ? s->codes : nullptr; }
+const void* gnnlm_store_vals(const gnnlm_store_t* s) { return s ? s->vals : nullptr; }
+int gnnlm_store_destroy(gnnlm_store_t* s) {
+    if (!s) return OK;
+    if (s->codes) (void)hipFree(s->codes);
+    if (s->vals) (void)hipFree(s->vals);
+    delete s;
+    return OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,356 @@
+// HGT attention kernels (reference: HGTLayer.forward, fairseq/models/hgt.py:341-386).
+//
+// The three edge types of the token/neighbour graph (fairseq/models/transformer.py:913-918) each get
+// the kernel their shape asks for -- the graph is implicit, no edge list is ever built:
+//   ('ntgt','inter','tgt')   star_attn   : every token attends over its kg neighbour centres.  The
+//        per-neighbour K/V projections are absorbed into the query side (exact algebra):
+//          score = q.(x W_k' ) = x.(W_k' q) = x.u,   sum_j a_j (x_j W_v') = (sum_j a_j x_j) W_v'
+//        so the kernel only needs the raw neighbour rows x_j -- PQ codes decoded on the fly from the
+//        HBM-resident store (layer 1, fused gather + decode) or the previous layer's ntgt states.
+//   ('ntgt','intra','ntgt')  chain_attn  : each group of 1+l+r context nodes is a path graph with
+//        self loops (token_block_dataset.py:395-398): <= 3 incoming edges per node, one wave per
+//        (group, head), operands live in registers.
+//   ('tgt','intra','tgt')    causal_softmax : dense causal attention over the block; the two
+//        contractions run on the GEMM kernel, this is the masked row softmax in between.
+#include "kernels.h"
+
+namespace gnnlm {
+namespace {
+
+constexpr int HB = 8;   // heads processed per pass of star_attn
+
+// Sum 8 per-lane partials over the 64 lanes with a transposing butterfly: 10 shuffles instead of 48.
+// On return lane 8*h holds the total of v[h].
+__device__ __forceinline__ float reduce8(const float (&v)[HB], int lane) {
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    float w[4], y[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float send = b5 ? v[t] : v[t + 4];
+        const float keep = b5 ? v[t + 4] : v[t];
+        w[t] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float send = b4 ? w[t] : w[t + 2];
+        const float keep = b4 ? w[t + 2] : w[t];
+        y[t] = keep + __shfl_xor(send, 16, 64);
+    }
+    float r;
+    {
+        const float send = b3 ? y[0] : y[1];
+        const float keep = b3 ? y[1] : y[0];
+        r = keep + __shfl_xor(send, 8, 64);
+    }
+    r += __shfl_xor(r, 4, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 1, 64);
+    return r;
+}
+
+// One workgroup (4 waves) per token.  QPL = float4 chunks of the feature row held per lane.
+template <int QPL>
+__global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sc = smem;                               // [HB][kg] scores, then alphas
+    float* zred = smem + HB * p.kg;                 // [HB][D]  cross-wave reduction of Z
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x;
+    const int D = p.D, kg = p.kg, nq = D / 4;
+    const int64_t* ids = p.ids + (int64_t)i * kg;
+    const int q_per_m = p.codes ? p.dsub / 4 : 1;
+
+    auto load_x = [&](int j, float4 (&x)[QPL]) -> bool {
+        const int64_t id = ids[j];
+        if (id < 0) return false;
+        if (p.codes) {
+            const int64_t lrow = p.codes_direct ? ((int64_t)i * kg + j) * p.codes_direct : id - p.row0;
+            const uint8_t* crow = p.codes + lrow * p.M;
+#pragma unroll
+            for (int t = 0; t < QPL; ++t) {
+                const int q = lane + 64 * t;
+                x[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < nq) {
+                    const int m = q / q_per_m;
+                    const int within = (q - m * q_per_m) * 4;
+                    x[t] = *reinterpret_cast<const float4*>(
+                        p.centroids + ((int64_t)(m * 256 + crow[m])) * p.dsub + within);
+                }
+            }
+        } else {
+            const float* xr = p.X + ((int64_t)i * kg + j) * p.x_group_stride * p.ldx;
+#pragma unroll
+            for (int t = 0; t < QPL; ++t) {
+                const int q = lane + 64 * t;
+                x[t] = q < nq ? *reinterpret_cast<const float4*>(xr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        return true;
+    };
+
+    int n_valid_total = 0;
+    for (int h0 = 0; h0 < p.H; h0 += HB) {
+        // ---- pass 1: scores s[h][j] = x_j . U[i,h,:]
+        {
+            float4 u[HB][QPL];
+#pragma unroll
+            for (int h = 0; h < HB; ++h)
+#pragma unroll
+                for (int t = 0; t < QPL; ++t) {
+                    const int q = lane + 64 * t;
+                    u[h][t] = (h0 + h < p.H && q < nq)
+                                  ? *reinterpret_cast<const float4*>(p.U + ((int64_t)i * p.H + h0 + h) * D + 4 * q)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            for (int j = wave; j < kg; j += 4) {
+                float4 x[QPL];
+                const bool ok = load_x(j, x);       // wave-uniform
+                float part[HB];
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int t = 0; t < QPL; ++t) {
+                        a = fmaf(x[t].x, u[h][t].x, a);
+                        a = fmaf(x[t].y, u[h][t].y, a);
+                        a = fmaf(x[t].z, u[h][t].z, a);
+                        a = fmaf(x[t].w, u[h][t].w, a);
+                    }
+                    part[h] = a;
+                }
+                const float tot = reduce8(part, lane);
+                if ((lane & 7) == 0) sc[(lane >> 3) * kg + j] = ok ? tot : -INFINITY;
+            }
+        }
+        __syncthreads();
+        // ---- softmax over j per head (wave w: heads w, w+4)
+        for (int h = wave; h < HB; h += 4) {
+            float mx = -INFINITY;
+            for (int j = lane; j < kg; j += 64) mx = fmaxf(mx, sc[h * kg + j]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            int cnt = 0;
+            for (int j = lane; j < kg; j += 64) {
+                const float s = sc[h * kg + j];
+                const bool ok = s != -INFINITY;
+                const float e = ok ? expf(s - mx) : 0.f;
+                cnt += ok;
+                sum += e;
+                sc[h * kg + j] = e;
+            }
+            sum = wave_sum(sum);
+            const float inv = sum > 0.f ? 1.f / sum : 0.f;
+            for (int j = lane; j < kg; j += 64) sc[h * kg + j] *= inv;
+            if (h == 0 && h0 == 0) {
+                cnt = (int)wave_sum((float)cnt);
+                if (lane == 0 && p.has_nb) p.has_nb[i] = cnt > 0 ? 1.f : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: Z[h,:] = sum_j alpha[h][j] x_j
+        {
+            float4 z[HB][QPL];
+#pragma unroll
+            for (int h = 0; h < HB; ++h)
+#pragma unroll
+                for (int t = 0; t < QPL; ++t) z[h][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = wave; j < kg; j += 4) {
+                float4 x[QPL];
+                if (!load_x(j, x)) continue;
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    const float a = sc[h * kg + j];
+#pragma unroll
+                    for (int t = 0; t < QPL; ++t) {
+                        z[h][t].x = fmaf(a, x[t].x, z[h][t].x);
+                        z[h][t].y = fmaf(a, x[t].y, z[h][t].y);
+                        z[h][t].z = fmaf(a, x[t].z, z[h][t].z);
+                        z[h][t].w = fmaf(a, x[t].w, z[h][t].w);
+                    }
+                }
+            }
+            // deterministic cross-wave reduction: waves add in order 0,1,2,3
+            for (int w = 0; w < 4; ++w) {
+                if (wave == w) {
+#pragma unroll
+                    for (int h = 0; h < HB; ++h)
+#pragma unroll
+                        for (int t = 0; t < QPL; ++t) {
+                            const int q = lane + 64 * t;
+                            if (q < nq) {
+                                float4* dst = reinterpret_cast<float4*>(zred + h * D + 4 * q);
+                                if (w == 0) {
+                                    *dst = z[h][t];
+                                } else {
+                                    float4 c = *dst;
+                                    c.x += z[h][t].x; c.y += z[h][t].y; c.z += z[h][t].z; c.w += z[h][t].w;
+                                    *dst = c;
+                                }
+                            }
+                        }
+                }
+                __syncthreads();
+            }
+            for (int e = tid; e < HB * nq; e += 256) {
+                const int h = e / nq, q = e - h * nq;
+                if (h0 + h < p.H)
+                    *reinterpret_cast<float4*>(p.Z + ((int64_t)i * p.H + h0 + h) * D + 4 * q) =
+                        *reinterpret_cast<const float4*>(zred + h * D + 4 * q);
+            }
+        }
+        __syncthreads();
+    }
+    (void)n_valid_total;
+}
+
+constexpr int MAX_NG = 8;
+constexpr int MAX_EPT = 4;
+
+// One wave per (group, head).  Position order along the path: o-l .. o-1, o, o+1 .. o+r.
+__global__ __launch_bounds__(256) void chain_attn_kernel(ChainAttnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= p.n_groups * p.H) return;
+    const int64_t g = task / p.H;
+    const int h = (int)(task - g * p.H);
+    const int n_g = 1 + p.left + p.right;
+    const int dk = p.dk;
+    const float scale = p.scale ? p.scale[h] : 1.f;
+
+    float q[MAX_NG][MAX_EPT], k[MAX_NG][MAX_EPT], v[MAX_NG][MAX_EPT];
+    bool ok[MAX_NG];
+    int64_t slot_of[MAX_NG];
+#pragma unroll
+    for (int pos = 0; pos < MAX_NG; ++pos) {
+        ok[pos] = false;
+        slot_of[pos] = 0;
+        if (pos < n_g) {
+            const int c = pos < p.left ? pos + 1 : (pos == p.left ? 0 : pos);
+            const int64_t s = g * n_g + c;
+            slot_of[pos] = s;
+            ok[pos] = p.valid[s] != 0;
+#pragma unroll
+            for (int t = 0; t < MAX_EPT; ++t) {
+                const int e = lane + 64 * t;
+                const bool in = ok[pos] && e < dk;
+                const int64_t off = s * p.ld + h * dk + (in ? e : 0);
+                q[pos][t] = in ? p.Q[off] : 0.f;
+                k[pos][t] = in ? p.K[off] : 0.f;
+                v[pos][t] = in ? p.V[off] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int pos = 0; pos < MAX_NG; ++pos) {
+        if (pos >= n_g) break;
+        float sc[3];
+        bool has[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int u = pos + d - 1;
+            has[d] = false;
+            sc[d] = -INFINITY;
+            if (u >= 0 && u < MAX_NG) {
+                if (u < n_g && ok[u] && ok[pos]) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int t = 0; t < MAX_EPT; ++t) a = fmaf(q[pos][t], k[u][t], a);
+                    a = wave_sum(a);
+                    sc[d] = a * scale;
+                    has[d] = true;
+                }
+            }
+        }
+        const float mx = fmaxf(sc[0], fmaxf(sc[1], sc[2]));
+        float e[3], den = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            e[d] = has[d] ? expf(sc[d] - mx) : 0.f;
+            den += e[d];
+        }
+        const float inv = den > 0.f ? 1.f / den : 0.f;
+#pragma unroll
+        for (int t = 0; t < MAX_EPT; ++t) {
+            const int el = lane + 64 * t;
+            if (el < dk) {
+                float o = 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int u = pos + d - 1;
+                    if (u >= 0 && u < MAX_NG) o = fmaf(e[d] * inv, v[u][t], o);
+                }
+                p.out[slot_of[pos] * p.ldo + h * dk + el] = o;
+            }
+        }
+    }
+}
+
+// One wave per score row.  Row w of matrix m: keep u <= w (and w-u < max_ctx), softmax, zero the rest
+// (including the padding columns up to ld, which the following P.V GEMM reads).
+__global__ __launch_bounds__(256) void causal_softmax_kernel(float* S, int64_t n_rows, int T, int64_t ld, int max_ctx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int w = (int)(row % T);
+    float* r = S + row * ld;          // matrices are stored with T rows each, contiguous
+    const int lo = max_ctx > 0 ? max(0, w - max_ctx + 1) : 0;
+    float mx = -INFINITY;
+    for (int u = lo + lane; u <= w; u += 64) mx = fmaxf(mx, r[u]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int u = lo + lane; u <= w; u += 64) sum += expf(r[u] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int u = lane; u < (int)ld; u += 64) r[u] = (u >= lo && u <= w) ? expf(r[u] - mx) * inv : 0.f;
+}
+
+}  // namespace
+
+int star_attn(const StarAttnParams& p, hipStream_t stream) {
+    GNNLM_REQUIRE(p.U && p.ids && p.Z, "star_attn: null operand");
+    GNNLM_REQUIRE(p.T >= 0 && p.H > 0 && p.kg > 0 && p.D > 0 && p.D % 4 == 0 && p.D <= 1024,
+                  "star_attn: need D % 4 == 0 and D <= 1024");
+    GNNLM_REQUIRE((p.codes != nullptr) != (p.X != nullptr), "star_attn: exactly one of codes / X");
+    if (p.codes) {
+        GNNLM_REQUIRE(p.centroids && p.M > 0 && p.dsub % 4 == 0 && p.M * p.dsub == p.D,
+                      "star_attn: PQ source needs centroids and M*dsub == D, dsub % 4 == 0");
+    } else {
+        GNNLM_REQUIRE(p.ldx % 4 == 0 && (uintptr_t)p.X % 16 == 0, "star_attn: X alignment");
+    }
+    if (p.T == 0) return OK;
+    const size_t shmem = (size_t)(HB * p.kg + HB * p.D) * sizeof(float);
+    GNNLM_REQUIRE(shmem <= 160 * 1024, "star_attn: kg too large for LDS");
+    const int nq = p.D / 4;
+    dim3 grid(p.T), block(256);
+    if (nq <= 64) {
+        hipLaunchKernelGGL(star_attn_kernel<1>, grid, block, shmem, stream, p);
+    } else if (nq <= 128) {
+        hipLaunchKernelGGL(star_attn_kernel<2>, grid, block, shmem, stream, p);
+    } else {
+        hipLaunchKernelGGL(star_attn_kernel<4>, grid, block, shmem, stream, p);
+    }
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int chain_attn(const ChainAttnParams& p, hipStream_t stream) {
+    GNNLM_REQUIRE(p.Q && p.K && p.V && p.valid && p.out, "chain_attn: null operand");
+    GNNLM_REQUIRE(1 + p.left + p.right <= MAX_NG, "chain_attn: 1+left+right must be <= 8");
+    GNNLM_REQUIRE(p.dk > 0 && p.dk <= 64 * MAX_EPT && p.H > 0, "chain_attn: d_k must be <= 256");
+    const int64_t tasks = p.n_groups * p.H;
+    if (tasks == 0) return OK;
+    hipLaunchKernelGGL(chain_attn_kernel, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, stream, p);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int causal_softmax(float* S, int64_t n_mats, int T, int64_t ld, int max_ctx, hipStream_t stream) {
+    GNNLM_REQUIRE(S && T > 0 && ld >= T, "causal_softmax: bad arguments");
+    const int64_t rows = n_mats * T;
+    if (rows == 0) return OK;
+    hipLaunchKernelGGL(causal_softmax_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, S, rows, T, ld, max_ctx);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // namespace gnnlm

@@ -1,0 +1,91 @@
+// PQ datastore row gather + decode, HBM-resident.
+//
+// Replaces, per token block, the host-side row gathers of the reference
+//   quant_neighbor_feats[offset] / neighbor_tokens[offset]   fairseq/data/token_block_dataset.py:370-371,391-393
+// (a PlasmaArray / np.memmap per-row Python append + np.stack, :407-410) and the table lookup half of
+//   TorchPQCodec.decode                                       knn/pq_wrapper.py:169-196
+// The neighbour-context expansion of new_build_graph (:378-394) is done in-kernel from the centre row:
+// slot c of a group is row  o (c = 0),  o-left .. o-1 (c = 1..left),  o+1 .. o+right (c = left+1..).
+//
+// HBM-bound: one wave per slot reads the 128-B code row (one cache line) and writes D*4 bytes of
+// decoded features, 16 B per lane per store instruction (fully coalesced 1-KiB wave stores).  The
+// 1-MiB centroid table is read through L2 (it is shared by every wave on the chip and stays resident).
+#include "kernels.h"
+
+namespace gnnlm {
+namespace {
+
+__global__ __launch_bounds__(256) void gather_decode_kernel(GatherParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int n_g = 1 + p.left + p.right;
+    const int64_t n_slots = p.n_groups * n_g;
+    const int D = p.M * p.dsub;
+    const int nq = D / 4;                       // float4 per decoded row
+    const int q_per_m = p.dsub / 4;
+
+    for (int64_t s = wave; s < n_slots; s += nwaves) {
+        const int64_t g = s / n_g;
+        const int c = (int)(s - g * n_g);
+        bool local;
+        int64_t lrow;
+        if (p.direct) {
+            lrow = s;
+            local = p.in_valid[s] != 0;
+        } else {
+            const int64_t centre = p.ids[g];
+            const int delta = c == 0 ? 0 : (c <= p.left ? c - 1 - p.left : c - p.left);
+            const int64_t row = centre + delta;
+            const bool valid = centre >= 0 && row >= 0 && row < p.n_store;
+            lrow = row - p.row0;
+            local = valid && lrow >= 0 && lrow < p.n_local;   // sharded store: caller routes ids
+        }
+        if (lane == 0) {
+            if (p.out_valid) p.out_valid[s] = local ? 1 : 0;
+            if (p.out_labels) {
+                int32_t lab = -1;
+                if (local && p.vals)
+                    lab = p.vals_itemsize == 2 ? (int32_t) reinterpret_cast<const int16_t*>(p.vals)[lrow]
+                                               : reinterpret_cast<const int32_t*>(p.vals)[lrow];
+                p.out_labels[s] = lab;
+            }
+        }
+        const uint8_t* crow = p.codes + (local ? lrow : 0) * p.M;
+        if (p.out_codes) {
+            for (int m = lane; m < p.M; m += 64) p.out_codes[s * p.M + m] = local ? crow[m] : 0;
+        }
+        if (p.out_x) {
+            float4* out = reinterpret_cast<float4*>(p.out_x + s * p.ld_x);
+            for (int q = lane; q < nq; q += 64) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (local) {
+                    const int m = q / q_per_m;
+                    const int within = (q - m * q_per_m) * 4;
+                    const int code = crow[m];
+                    v = *reinterpret_cast<const float4*>(p.centroids + ((int64_t)(m * 256 + code)) * p.dsub + within);
+                }
+                out[q] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int gather_decode(const GatherParams& p, hipStream_t stream) {
+    GNNLM_REQUIRE(p.codes && (p.direct ? p.in_valid != nullptr : p.ids != nullptr), "gather_decode: null codes/ids");
+    GNNLM_REQUIRE(p.M > 0 && p.dsub > 0 && p.dsub % 4 == 0, "gather_decode: dsub must be a multiple of 4");
+    GNNLM_REQUIRE(p.left >= 0 && p.right >= 0 && p.n_groups >= 0, "gather_decode: bad shape");
+    GNNLM_REQUIRE(!p.out_x || (p.centroids && p.ld_x % 4 == 0 && (uintptr_t)p.out_x % 16 == 0),
+                  "gather_decode: out_x needs centroids, 16-byte alignment and ld % 4 == 0");
+    GNNLM_REQUIRE(p.vals_itemsize == 2 || p.vals_itemsize == 4, "gather_decode: vals must be int16 or int32");
+    const int64_t n_slots = p.n_groups * (1 + p.left + p.right);
+    if (n_slots == 0) return OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(n_slots, 4), 256 * 16);
+    hipLaunchKernelGGL(gather_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // namespace gnnlm

@@ -1,0 +1,60 @@
+// Internal launcher declarations (C++).  The public C ABI is include/gnnlm.h.
+#pragma once
+#include "common.h"
+#include "../../include/gnnlm.h"
+
+namespace gnnlm {
+
+// Descriptor structs are the public C structs of include/gnnlm.h.
+typedef gnnlm_gemm_t GemmParams;
+typedef gnnlm_gather_t GatherParams;
+typedef gnnlm_star_attn_t StarAttnParams;
+typedef gnnlm_chain_attn_t ChainAttnParams;
+typedef gnnlm_knn_interp_t KnnInterpParams;
+
+int gemm_nt(const GemmParams& p, hipStream_t stream);
+int gather_decode(const GatherParams& p, hipStream_t stream);
+int star_attn(const StarAttnParams& p, hipStream_t stream);
+int chain_attn(const ChainAttnParams& p, hipStream_t stream);
+
+// rows of S[b, h, w, :T] -> causal softmax (u <= w, and w-u < max_ctx if max_ctx > 0), in place
+int causal_softmax(float* S, int64_t n_mats, int T, int64_t ld, int max_ctx, hipStream_t stream);
+
+// out[r,:] = LayerNorm(x[r,:]) * gamma + beta ; optional row validity (invalid rows -> 0)
+int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,
+              int64_t ldo, int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream);
+
+// out = 0.5 * (a + b)
+int mean2(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
+
+// fp16 -> fp32 row convert
+int half_to_float(const void* src, float* dst, int64_t n, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// adaptive softmax / kNN interpolation
+// ---------------------------------------------------------------------------------------------
+// lse[r] = logsumexp(logits[r, :n]); picked[r] = logits[r, pick[r]] (pick may be null)
+int row_lse_pick(const float* logits, int64_t ld, int64_t rows, const int32_t* m_dev, int n,
+                 const int32_t* pick, float* lse, float* picked, hipStream_t stream);
+
+struct BandSplitParams {
+    const int64_t* target = nullptr; int64_t n = 0;
+    int n_bands = 0; int32_t cutoff[8] = {0};      // cutoff[0..n_bands-1], band b = [cutoff[b-1], cutoff[b])
+    int32_t* head_pick = nullptr;          // [n] index into the head logits (target or cutoff0+band-1)
+    int32_t* band_rows = nullptr;          // [n_bands-1, n] compacted row lists of the tail bands
+    int32_t* band_pick = nullptr;          // [n_bands-1, n] target - cutoff[band-1] for the compacted rows
+    int32_t* band_count = nullptr;         // [n_bands-1]
+};
+int band_split(const BandSplitParams& p, hipStream_t stream);
+
+// lm_logp[rows[r]] = head_lsm[rows[r]] + (tail_picked[r] - tail_lse[r])   (rows null: identity)
+int head_logp(const float* picked, const float* lse, float* out, int64_t n, hipStream_t stream);
+int tail_combine(const float* tail_picked, const float* tail_lse, const int32_t* rows,
+                 const int32_t* count_dev, int64_t n_max, float* lm_logp, hipStream_t stream);
+
+int knn_interp(const KnnInterpParams& p, hipStream_t stream);
+
+// sum of x[start[b] : ] per ... simple masked sum in double: out[0] += sum(x[i] * (mask?mask[i]:1))
+int masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, hipStream_t stream);
+
+}  // namespace gnnlm

@@ -1,0 +1,273 @@
+// Row-wise kernels of the eval hot path: LayerNorm epilogue of HGTLayer (fairseq/models/hgt.py:397-407),
+// the log-softmax reductions of the tied adaptive softmax (fairseq/modules/adaptive_softmax.py:184-203)
+// and the kNN-LM distance-softmax interpolation (knn/knn_model.py:192-217,
+// fairseq/sequence_scorer.py:55-68,110,121).  All HBM/latency-bound; f32 arithmetic like the reference.
+#include <hip/hip_fp16.h>
+#include "kernels.h"
+
+namespace gnnlm {
+namespace {
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t ldx, const float* gamma,
+                                                        const float* beta, float* out, int64_t ldo,
+                                                        int64_t rows, int d, float eps, const uint8_t* valid) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float* orow = out + row * ldo;
+    if (valid && !valid[row]) {
+        for (int e = lane; e < d; e += 64) orow[e] = 0.f;
+        return;
+    }
+    float s = 0.f;
+    for (int e = lane; e < d; e += 64) s += xr[e];
+    const float mean = wave_sum(s) / d;
+    float v = 0.f;
+    for (int e = lane; e < d; e += 64) {
+        const float c = xr[e] - mean;
+        v = fmaf(c, c, v);
+    }
+    const float rstd = rsqrtf(wave_sum(v) / d + eps);
+    for (int e = lane; e < d; e += 64) orow[e] = (xr[e] - mean) * rstd * gamma[e] + beta[e];
+}
+
+__global__ void mean2_kernel(const float* a, const float* b, float* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 0.5f * (a[i] + b[i]);
+}
+
+__global__ void half_to_float_kernel(const __half* src, float* dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = __half2float(src[i]);
+}
+
+// one workgroup per row: lse = logsumexp(row[:n]), picked = row[pick]
+__global__ __launch_bounds__(256) void row_lse_pick_kernel(const float* logits, int64_t ld, int64_t rows,
+                                                           const int32_t* m_dev, int n, const int32_t* pick,
+                                                           float* lse, float* picked) {
+    __shared__ float red_m[4], red_s[4];
+    const int64_t row = blockIdx.x;
+    if (m_dev && row >= *m_dev) return;
+    const float* r = logits + row * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -INFINITY, s = 0.f;
+    for (int e = tid; e < n; e += 256) {
+        const float v = r[e];
+        if (v > m) {
+            s = s * expf(m - v) + 1.f;
+            m = v;
+        } else {
+            s += expf(v - m);
+        }
+    }
+    // combine (m, s) pairs across the wave, then across the 4 waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        const float mm = fmaxf(m, m2);
+        s = (m == -INFINITY ? 0.f : s * expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - mm));
+        m = mm;
+    }
+    if (lane == 0) { red_m[wave] = m; red_s[wave] = s; }
+    __syncthreads();
+    if (tid == 0) {
+        float mm = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+        float ss = 0.f;
+        for (int w = 0; w < 4; ++w) ss += red_m[w] == -INFINITY ? 0.f : red_s[w] * expf(red_m[w] - mm);
+        lse[row] = mm + logf(ss);
+        if (picked) picked[row] = pick ? r[pick[row]] : 0.f;
+    }
+}
+
+// single wave: stable compaction of the rows whose target falls into each tail band
+__global__ __launch_bounds__(64) void band_split_kernel(BandSplitParams p) {
+    const int lane = threadIdx.x;
+    int count[8] = {0};
+    for (int64_t base = 0; base < p.n; base += 64) {
+        const int64_t r = base + lane;
+        const bool in = r < p.n;
+        const int64_t t = in ? p.target[r] : 0;
+        int band = 0;
+#pragma unroll
+        for (int b = 1; b < 8; ++b)
+            if (b < p.n_bands && t >= p.cutoff[b - 1]) band = b;
+        if (in) p.head_pick[r] = band == 0 ? (int32_t)t : p.cutoff[0] + band - 1;
+#pragma unroll
+        for (int b = 1; b < 8; ++b) {
+            if (b >= p.n_bands) break;
+            const bool mine = in && band == b;
+            const unsigned long long mask = __ballot(mine);
+            const int before = __popcll(mask & ((1ull << lane) - 1ull));
+            if (mine) {
+                const int64_t dst = (int64_t)(b - 1) * p.n + count[b] + before;
+                p.band_rows[dst] = (int32_t)r;
+                p.band_pick[dst] = (int32_t)(t - p.cutoff[b - 1]);
+            }
+            count[b] += __popcll(mask);
+        }
+    }
+    if (lane == 0)
+        for (int b = 1; b < p.n_bands; ++b) p.band_count[b - 1] = count[b];
+}
+
+__global__ void head_logp_kernel(const float* picked, const float* lse, float* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = picked[i] - lse[i];
+}
+
+__global__ void tail_combine_kernel(const float* tail_picked, const float* tail_lse, const int32_t* rows,
+                                    const int32_t* count_dev, int64_t n_max, float* lm_logp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = count_dev ? min((int64_t)*count_dev, n_max) : n_max;
+    if (i < n) {
+        const int64_t r = rows ? rows[i] : i;
+        lm_logp[r] += tail_picked[i] - tail_lse[i];
+    }
+}
+
+// one wave per token
+__global__ __launch_bounds__(256) void knn_interp_kernel(KnnInterpParams p, float log_1ml, float log_l) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.n) return;
+    const float* sims = p.sims + i * p.k;
+    const int64_t* ids = p.ids + i * p.k;
+    const int64_t tgt = p.targets[i];
+    float mx = -INFINITY;
+    for (int j = lane; j < p.k; j += 64) {
+        const float s = (ids[j] == -1 ? -1e10f : sims[j]) / p.temperature;      // knn_model.py:193,196
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float den = 0.f, num = 0.f;
+    int rec = 0;
+    for (int j = lane; j < p.k; j += 64) {
+        const int64_t id = ids[j];
+        const float s = (id == -1 ? -1e10f : sims[j]) / p.temperature;
+        const float e = expf(s - mx);
+        int64_t val;
+        if (p.knn_vals) {
+            val = p.knn_vals[i * p.k + j];
+        } else {
+            // numpy indexing semantics of vals[knns] (knn_model.py:198): -1 wraps to the last row
+            const int64_t row = (id < 0 ? id + p.n_store : id) - p.row0;
+            val = p.vals_itemsize == 2 ? (int64_t) reinterpret_cast<const int16_t*>(p.vals)[row]
+                                       : (int64_t) reinterpret_cast<const int32_t*>(p.vals)[row];
+        }
+        const bool hit = val == tgt;                                             // :211
+        den += e;
+        num += hit ? e : 0.f;
+        rec += hit;
+    }
+    den = wave_sum(den);
+    num = wave_sum(num);
+    rec = (int)wave_sum((float)rec);
+    if (lane == 0) {
+        const float pk = num / den;
+        if (p.out_pknn) p.out_pknn[i] = pk;
+        if (p.out_recall) p.out_recall[i] = rec;
+        // sequence_scorer.py:55-68 with knn_probs = log(p + 1e-10) (:121)
+        const float a = p.lm_logp[i] + log_1ml;
+        const float b = logf(pk + 1e-10f) + log_l;
+        const float m = fmaxf(a, b);
+        p.out_logp[i] = m + logf(expf(a - m) + expf(b - m));
+    }
+}
+
+__global__ __launch_bounds__(256) void masked_sum_f64_kernel(const float* x, const uint8_t* mask, int64_t n, double* out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += (!mask || mask[i]) ? (double)x[i] : 0.0;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += red[0];
+}
+
+}  // namespace
+
+int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo,
+              int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream) {
+    GNNLM_REQUIRE(x && gamma && beta && out && d > 0, "layernorm: bad arguments");
+    if (rows == 0) return OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, x, ldx, gamma, beta,
+                       out, ldo, rows, d, eps, valid);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int mean2(const float* a, const float* b, float* out, int64_t n, hipStream_t stream) {
+    if (n == 0) return OK;
+    hipLaunchKernelGGL(mean2_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, a, b, out, n);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int half_to_float(const void* src, float* dst, int64_t n, hipStream_t stream) {
+    GNNLM_REQUIRE(src && dst, "half_to_float: null");
+    if (n == 0) return OK;
+    hipLaunchKernelGGL(half_to_float_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const __half*>(src), dst, n);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int row_lse_pick(const float* logits, int64_t ld, int64_t rows, const int32_t* m_dev, int n, const int32_t* pick,
+                 float* lse, float* picked, hipStream_t stream) {
+    GNNLM_REQUIRE(logits && lse && n > 0, "row_lse_pick: bad arguments");
+    if (rows == 0) return OK;
+    hipLaunchKernelGGL(row_lse_pick_kernel, dim3((unsigned)rows), dim3(256), 0, stream, logits, ld, rows, m_dev, n,
+                       pick, lse, picked);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int band_split(const BandSplitParams& p, hipStream_t stream) {
+    GNNLM_REQUIRE(p.target && p.head_pick && p.n_bands >= 1 && p.n_bands <= 8, "band_split: bad arguments");
+    GNNLM_REQUIRE(p.n_bands == 1 || (p.band_rows && p.band_pick && p.band_count), "band_split: null band outputs");
+    hipLaunchKernelGGL(band_split_kernel, dim3(1), dim3(64), 0, stream, p);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int head_logp(const float* picked, const float* lse, float* out, int64_t n, hipStream_t stream) {
+    if (n == 0) return OK;
+    hipLaunchKernelGGL(head_logp_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, picked, lse, out, n);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int tail_combine(const float* tail_picked, const float* tail_lse, const int32_t* rows, const int32_t* count_dev,
+                 int64_t n_max, float* lm_logp, hipStream_t stream) {
+    if (n_max == 0) return OK;
+    hipLaunchKernelGGL(tail_combine_kernel, dim3((unsigned)cdiv(n_max, 256)), dim3(256), 0, stream, tail_picked,
+                       tail_lse, rows, count_dev, n_max, lm_logp);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int knn_interp(const KnnInterpParams& p, hipStream_t stream) {
+    GNNLM_REQUIRE(p.lm_logp && p.sims && p.ids && p.targets && p.out_logp, "knn_interp: null operand");
+    GNNLM_REQUIRE(p.knn_vals || p.vals, "knn_interp: need vals or pre-fetched knn_vals");
+    GNNLM_REQUIRE(p.k > 0 && p.temperature > 0.f && p.lmbda > 0.0 && p.lmbda < 1.0, "knn_interp: need k>0, t>0, 0<lmbda<1");
+    GNNLM_REQUIRE(p.vals_itemsize == 2 || p.vals_itemsize == 4, "knn_interp: vals must be int16 or int32");
+    if (p.n == 0) return OK;
+    // coefficients are float32 roundings of the float64 logs, as in coeffs[0] = np.log(1 - coeff)
+    const float log_1ml = (float)log(1.0 - p.lmbda), log_l = (float)log(p.lmbda);
+    hipLaunchKernelGGL(knn_interp_kernel, dim3((unsigned)cdiv(p.n, 4)), dim3(256), 0, stream, p, log_1ml, log_l);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, hipStream_t stream) {
+    GNNLM_REQUIRE(x && out, "masked_sum_f64: null");
+    hipLaunchKernelGGL(masked_sum_f64_kernel, dim3(1), dim3(256), 0, stream, x, mask, n, out);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // namespace gnnlm

@@ -1,0 +1,248 @@
+"""HGT over the implicit token/neighbour graph -- host-side mirror of ``fairseq/models/hgt.py``.
+
+``HGT`` / ``HGTLayer`` keep the reference's constructor signature and parameter names
+(``gcs.{i}.{k,q,v,a}_linears.{t}.{weight,bias}``, ``norms``, ``relation_pri/att/msg``, ``skip``;
+hgt.py:55-79, :460-492) so a reference checkpoint loads with ``load_state_dict``.  ``forward`` takes a
+:class:`NeighborGraph` instead of a DGL heterograph: the graph of the reference
+(token_block_dataset.py:338-412) is fully determined by the neighbour-id matrix and the context
+sizes, so it is never materialised.
+
+Before the first forward the weights are *prepared* once (float64 on the host, rounded to float32):
+  * relation matrices and ``relation_pri / sqrt(d_k)`` are folded into the K / V projections
+    (``k' = (h W_k^T + b_k) R``  ==  ``h (W_k^T R) + b_k R``; hgt.py:347-348,355);
+  * on the star edges the neighbour-side K / V projections (and, in layer 0, the OPQ rotation of
+    ``TorchPQCodec.decode``, pq_wrapper.py:198-202) are absorbed into the query side, see csrc/attn.hip;
+all exact algebra -- only the floating-point association changes.
+"""
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+NTYPE2IDX = {"tgt": 0, "ntgt": 1}
+ETYPE2IDX = {"intra": 0, "inter": 1}
+
+
+@dataclass
+class CodeStore:
+    """PQ code table (and labels) resident in HBM: rows [row0, row0 + n_local) of an n_store-row store."""
+    codes: torch.Tensor                  # uint8 [n_local, M]
+    centroids: torch.Tensor              # f32 [M, 256, dsub]
+    n_store: int
+    row0: int = 0
+    vals: Optional[torch.Tensor] = None  # int16/int32 [n_local]
+    A: Optional[torch.Tensor] = None     # f32 [M*dsub, d]  OPQ matrix (decode: (x - b) @ A)
+    b: Optional[torch.Tensor] = None     # f32 [M*dsub]
+
+
+@dataclass
+class NeighborGraph:
+    """What replaces the DGL graph: ``ids[b*T + i, j]`` = datastore row of neighbour j of token i."""
+    ids: torch.Tensor                    # int64 [n_blocks*T, kg], -1 = none
+    n_blocks: int
+    T: int
+    left: int
+    right: int
+    store: CodeStore
+    tgt_h: Optional[torch.Tensor] = None            # f32 [n_blocks*T, d]  (graph.nodes['tgt'].data['h'])
+    fetched_codes: Optional[torch.Tensor] = None    # sharded store: codes of every slot, already fetched
+    fetched_valid: Optional[torch.Tensor] = None
+    fetched_centres_only: bool = False
+    max_intra_context: int = 0
+
+    @property
+    def kg(self):
+        return self.ids.shape[1]
+
+
+class HGTLayer(nn.Module):
+    """Parameter container with the reference's names/shapes (hgt.py:27-79).  The math runs in
+    :meth:`HGT.forward` through the C ABI."""
+
+    def __init__(self, in_dim, out_dim, ntype2idx, etype2idx, n_heads, dropout=0.2, use_norm=True,
+                 two_stream=False, attn_drop=0.2):
+        super().__init__()
+        assert out_dim % n_heads == 0
+        self.in_dim, self.out_dim, self.n_heads = in_dim, out_dim, n_heads
+        self.d_k = out_dim // n_heads
+        self.num_types, self.num_relations = len(ntype2idx), len(etype2idx)
+        self.use_norm, self.two_stream = use_norm, two_stream
+        mk = lambda i, o: nn.ModuleList([nn.Linear(i, o) for _ in range(self.num_types)])
+        self.k_linears, self.q_linears, self.v_linears = mk(in_dim, out_dim), mk(in_dim, out_dim), mk(in_dim, out_dim)
+        self.a_linears = mk(out_dim, out_dim)
+        self.norms = nn.ModuleList([nn.LayerNorm(out_dim) for _ in range(self.num_types)] if use_norm else [])
+        self.relation_pri = nn.Parameter(torch.ones(self.num_relations, n_heads))
+        self.relation_att = nn.Parameter(torch.empty(self.num_relations, n_heads, self.d_k, self.d_k))
+        self.relation_msg = nn.Parameter(torch.empty(self.num_relations, n_heads, self.d_k, self.d_k))
+        self.skip = nn.Parameter(torch.ones(self.num_types))
+        nn.init.xavier_uniform_(self.relation_att)
+        nn.init.xavier_uniform_(self.relation_msg)
+
+
+def prepare_hgt_weights(sd: Dict[str, torch.Tensor], n_layers: int, n_heads: int, store: CodeStore,
+                        device, prefix: str = ""):
+    """Fold / absorb the reference weights (state-dict names of hgt.py) into the layout of
+    ``gnnlm_hgt_layer_t``.  Returns (list of dicts of device tensors, dict of codec tensors)."""
+    f64 = lambda t: t.detach().to("cpu", torch.float64)
+    dev32 = lambda t: t.to(torch.float32).contiguous().to(device)
+    d = sd[prefix + "gcs.0.q_linears.0.weight"].shape[0]
+    H, dk = n_heads, d // n_heads
+    A = f64(store.A) if store.A is not None else None                     # [dpq, d]
+    bq = f64(store.b) if (store.b is not None and store.b.numel() > 0) else None
+    layers = []
+    for i in range(n_layers):
+        p = f"{prefix}gcs.{i}."
+        pri, att, msg = f64(sd[p + "relation_pri"]), f64(sd[p + "relation_att"]), f64(sd[p + "relation_msg"])
+        out = {}
+
+        def fold(nm, t, rel, scale):
+            """W'[hblock,:] = (R_h^T s_h) W[hblock,:],  b'[hblock] = b[hblock] R_h s_h."""
+            W, b = f64(sd[p + f"{nm}_linears.{t}.weight"]), f64(sd[p + f"{nm}_linears.{t}.bias"])
+            Wn, bn = torch.empty_like(W), torch.empty_like(b)
+            for h in range(H):
+                R = rel[h] * scale[h]
+                Wn[h * dk:(h + 1) * dk] = R.t() @ W[h * dk:(h + 1) * dk]
+                bn[h * dk:(h + 1) * dk] = b[h * dk:(h + 1) * dk] @ R
+            return Wn, bn
+
+        ones = torch.ones(H, dtype=torch.float64)
+        for t, tag in ((0, "t"), (1, "n")):
+            out[f"wq_{tag}"] = f64(sd[p + f"q_linears.{t}.weight"])
+            out[f"bq_{tag}"] = f64(sd[p + f"q_linears.{t}.bias"])
+            out[f"wk_{tag}"], out[f"bk_{tag}"] = fold("k", t, att[0], pri[0] / math.sqrt(dk))
+            out[f"wv_{tag}"], out[f"bv_{tag}"] = fold("v", t, msg[0], ones)
+            out[f"wa_{tag}"] = f64(sd[p + f"a_linears.{t}.weight"])
+            out[f"ba_{tag}"] = f64(sd[p + f"a_linears.{t}.bias"])
+            out[f"ln_g_{tag}"] = f64(sd[p + f"norms.{t}.weight"])
+            out[f"ln_b_{tag}"] = f64(sd[p + f"norms.{t}.bias"])
+        # star edges ('ntgt','inter','tgt'): source type ntgt (1), relation inter (1)
+        Wk, Wv, bv = f64(sd[p + "k_linears.1.weight"]), f64(sd[p + "v_linears.1.weight"]), f64(sd[p + "v_linears.1.bias"])
+        pre = A if (i == 0 and A is not None) else None
+        din = pre.shape[0] if pre is not None else d
+        wku = torch.empty(H, din, dk, dtype=torch.float64)
+        wvz_t = torch.empty(H, dk, din, dtype=torch.float64)
+        bvz = torch.empty(d, dtype=torch.float64)
+        for h in range(H):
+            Ks = Wk[h * dk:(h + 1) * dk].t() @ att[1][h] * (pri[1][h] / math.sqrt(dk))      # [d, dk]
+            Vs = Wv[h * dk:(h + 1) * dk].t() @ msg[1][h]                                      # [d, dk]
+            bvh = bv[h * dk:(h + 1) * dk] @ msg[1][h]
+            if pre is not None:
+                if bq is not None:
+                    bvh = bvh - (bq @ pre) @ Vs
+                Ks, Vs = pre @ Ks, pre @ Vs
+            wku[h], wvz_t[h], bvz[h * dk:(h + 1) * dk] = Ks, Vs.t(), bvh
+        out["wku"], out["wvz_t"], out["bvz"] = wku, wvz_t, bvz
+        layers.append(({k: dev32(v) for k, v in out.items()}, din))
+    codec = {"centroids": store.centroids.to(device, torch.float32).contiguous()}
+    if A is not None:
+        codec["opq_at"] = dev32(A.t())
+        if bq is not None:
+            codec["opq_nba"] = dev32(-(bq @ A))
+    return layers, codec
+
+
+class HGT(nn.Module):
+    """Drop-in for ``HGT`` of fairseq/models/hgt.py:459-513 (eval forward, non-incremental)."""
+
+    def __init__(self, ntype2idx=None, etype2idx=None, in_dim=1024, hidden_dim=1024, out_dim=1024, n_layers=3,
+                 n_heads=8, use_norm=True, dropout=0.0, two_stream=False, attn_drop=0.0):
+        super().__init__()
+        ntype2idx = ntype2idx or NTYPE2IDX
+        etype2idx = etype2idx or ETYPE2IDX
+        if dict(ntype2idx) != NTYPE2IDX or dict(etype2idx) != ETYPE2IDX:
+            raise NotImplementedError("only the node/edge types of TokenGraphTransformerDecoder "
+                                      "(transformer.py:913-920) are supported")
+        if not (in_dim == hidden_dim == out_dim):
+            raise NotImplementedError("in_dim == hidden_dim == out_dim required (the GNN-LM recipes; "
+                                      "hgt.py:505-513 adapters are not built)")
+        if two_stream or not use_norm:
+            raise NotImplementedError("two_stream=True / use_norm=False are not on the eval path (transformer.py:931)")
+        self.ntype2idx, self.etype2idx = ntype2idx, etype2idx
+        self.in_dim = self.hidden_dim = self.out_dim = hidden_dim
+        self.n_layers, self.n_heads = n_layers, n_heads
+        self.gcs = nn.ModuleList([HGTLayer(hidden_dim, hidden_dim, ntype2idx, etype2idx, n_heads,
+                                           use_norm=use_norm, dropout=dropout, attn_drop=attn_drop)
+                                  for _ in range(n_layers)])
+        self.adapt_ws = nn.ModuleList()
+        self._prepared = None
+
+    def _load_from_state_dict(self, *a, **k):
+        self._prepared = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def prepare(self, store: CodeStore, device):
+        """Fold the weights for ``store``'s codec and build the C descriptors (cached)."""
+        key = (id(store), str(device))
+        if self._prepared is not None and self._prepared["key"] == key:
+            return self._prepared
+        layers, codec = prepare_hgt_weights(self.state_dict(), self.n_layers, self.n_heads, store, device)
+        arr = (_lib.gnnlm_hgt_layer_t * self.n_layers)()
+        for i, (w, din) in enumerate(layers):
+            for name, t in w.items():
+                setattr(arr[i], name, t.data_ptr())
+            arr[i].din = din
+        m = _lib.gnnlm_hgt_t()
+        m.d, m.n_heads, m.n_layers = self.hidden_dim, self.n_heads, self.n_layers
+        m.ln_eps = self.gcs[0].norms[0].eps
+        M, _, dsub = store.centroids.shape
+        m.M, m.dsub = M, dsub
+        m.centroids = codec["centroids"].data_ptr()
+        if "opq_at" in codec:
+            m.opq_at = codec["opq_at"].data_ptr()
+        if "opq_nba" in codec:
+            m.opq_nba = codec["opq_nba"].data_ptr()
+        m.codes = store.codes.data_ptr()
+        if store.vals is not None:
+            m.vals, m.vals_itemsize = store.vals.data_ptr(), store.vals.element_size()
+        m.n_store, m.row0, m.n_local = store.n_store, store.row0, store.codes.shape[0]
+        m.layers = ctypes.cast(arr, ctypes.c_void_p)
+        self._prepared = {"key": key, "model": m, "layers_arr": arr, "tensors": (layers, codec), "ws": None}
+        return self._prepared
+
+    def forward(self, G: NeighborGraph, features: Dict[str, torch.Tensor] = None, etypes=None,
+                incremental_state=None, return_ntgt: bool = False):
+        """Returns ``{'tgt': [n_blocks*T, d]}`` (+ ``'ntgt'`` [n_valid_slots, d] in reference node
+        order when ``return_ntgt``; the eval path never consumes it, transformer.py:1053)."""
+        if incremental_state is not None:
+            raise NotImplementedError("incremental decoding (HGTLayer.infer) is out of scope (generation only)")
+        tgt = (features or {}).get("tgt", G.tgt_h)
+        if tgt is None:
+            raise ValueError("tgt features missing: pass features={'tgt': ...} or G.tgt_h")
+        if not tgt.is_cuda:
+            raise _lib.GnnlmError("HGT.forward needs device tensors; gnnlm_amd has no CPU fallback")
+        tgt = tgt.to(torch.float32).contiguous()
+        prep = self.prepare(G.store, tgt.device)
+        m = prep["model"]
+        m.left, m.right, m.max_intra_context = G.left, G.right, G.max_intra_context
+        io = _lib.gnnlm_hgt_io_t()
+        io.n_blocks, io.T, io.kg = G.n_blocks, G.T, G.kg
+        ids = G.ids.contiguous()
+        io.tgt_feats, io.ids = tgt.data_ptr(), ids.data_ptr()
+        if G.fetched_codes is not None:
+            io.fetched_codes = G.fetched_codes.data_ptr()
+            if G.fetched_valid is not None:
+                io.fetched_valid = G.fetched_valid.data_ptr()
+            io.fetched_centres_only = int(G.fetched_centres_only)
+        out_tgt = torch.empty_like(tgt)
+        io.out_tgt = out_tgt.data_ptr()
+        n_g = 1 + G.left + G.right
+        S = ids.shape[0] * G.kg * n_g
+        if return_ntgt:
+            out_ntgt = torch.empty(S, self.hidden_dim, device=tgt.device, dtype=torch.float32)
+            out_valid = torch.empty(S, device=tgt.device, dtype=torch.uint8)
+            io.out_ntgt, io.out_valid = out_ntgt.data_ptr(), out_valid.data_ptr()
+        L = _lib.lib()
+        need = L.gnnlm_hgt_workspace_bytes(ctypes.byref(m), ctypes.byref(io))
+        if prep["ws"] is None or prep["ws"].numel() < need or prep["ws"].device != tgt.device:
+            prep["ws"] = torch.empty(need, device=tgt.device, dtype=torch.uint8)
+        _lib.check(L.gnnlm_hgt_forward(ctypes.byref(m), ctypes.byref(io), _lib.ptr(prep["ws"]), prep["ws"].numel(),
+                                       _lib.stream()), "gnnlm_hgt_forward")
+        out = {"tgt": out_tgt}
+        if return_ntgt:
+            out["ntgt"] = out_ntgt[out_valid.bool()]
+        return out

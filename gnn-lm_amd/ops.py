@@ -1,0 +1,192 @@
+"""torch-tensor wrappers over the kernel-level C ABI (include/gnnlm.h).
+
+torch is plumbing here (device memory + the current HIP stream); every function below launches a
+hand-written gfx950 kernel through libgnnlm_hip.so and raises if that library is missing.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call, call_desc, ptr, stream
+
+
+def _dev(*ts):
+    """Refuse host tensors explicitly: the product path has no CPU fallback."""
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.is_contiguous() or (t.is_cuda and t.dim() == 2 and t.stride(1) == 1)):
+            raise _lib.GnnlmError("gnnlm_amd kernels need contiguous device (HIP) tensors; there is no CPU fallback")
+
+
+def _f32(t):
+    assert t.dtype == torch.float32, f"expected float32, got {t.dtype}"
+    return t
+
+
+def gemm_nt(A, W, bias=None, residual=None, alpha=1.0, out=None, bias_mode=1, gate=None,
+            a_rows=None, m_dev=None):
+    """C = alpha * A @ W.T (+ gate*bias) (+ residual).  A [M,K] (row stride may exceed K), W [N,K]."""
+    _f32(A), _f32(W)
+    _dev(A, W, bias, residual, gate, a_rows, m_dev, out)
+    M, K = A.shape
+    N = W.shape[0]
+    if a_rows is not None:
+        M = a_rows.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    g = _lib.gnnlm_gemm_t()
+    g.A, g.lda = A.data_ptr(), A.stride(0)
+    g.W, g.ldw = W.data_ptr(), W.stride(0)
+    g.C, g.ldc = out.data_ptr(), out.stride(0)
+    if a_rows is not None:
+        g.a_rows = a_rows.data_ptr()
+    if bias is not None:
+        g.bias, g.bias_mode = bias.data_ptr(), bias_mode
+    if gate is not None:
+        g.gate = gate.data_ptr()
+    if residual is not None:
+        g.R, g.ldr = residual.data_ptr(), residual.stride(0)
+    if m_dev is not None:
+        g.m_dev = m_dev.data_ptr()
+    g.alpha = alpha
+    g.M, g.N, g.K = M, N, K
+    call_desc("gnnlm_gemm_nt", g)
+    return out
+
+
+def pq_gather_decode(codes, centroids, ids, left=0, right=0, n_store=None, row0=0, vals=None,
+                     want_x=True, want_codes=False, want_labels=False, want_valid=True):
+    """Gather + decode the slots of each centre row in ``ids`` (flattened).  Returns a dict."""
+    _dev(codes, centroids, ids, vals)
+    M, ksub, dsub = centroids.shape
+    assert ksub == 256 and codes.dtype == torch.uint8 and ids.dtype == torch.int64
+    n_g = 1 + left + right
+    G = ids.numel()
+    S = G * n_g
+    dev = codes.device
+    d = _lib.gnnlm_gather_t()
+    d.codes = codes.data_ptr()
+    d.n_local = codes.shape[0]
+    d.n_store = n_store if n_store is not None else codes.shape[0]
+    d.row0 = row0
+    d.M, d.dsub = M, dsub
+    d.centroids = centroids.data_ptr()
+    d.ids, d.n_groups = ids.data_ptr(), G
+    d.left, d.right = left, right
+    d.vals_itemsize = 4
+    out = {}
+    if vals is not None:
+        d.vals, d.vals_itemsize = vals.data_ptr(), vals.element_size()
+    if want_x:
+        out["x"] = torch.empty(S, M * dsub, device=dev, dtype=torch.float32)
+        d.out_x, d.ld_x = out["x"].data_ptr(), M * dsub
+    if want_codes:
+        out["codes"] = torch.empty(S, M, device=dev, dtype=torch.uint8)
+        d.out_codes = out["codes"].data_ptr()
+    if want_labels:
+        out["labels"] = torch.empty(S, device=dev, dtype=torch.int32)
+        d.out_labels = out["labels"].data_ptr()
+    if want_valid:
+        out["valid"] = torch.empty(S, device=dev, dtype=torch.uint8)
+        d.out_valid = out["valid"].data_ptr()
+    call_desc("gnnlm_pq_gather_decode", d)
+    return out
+
+
+def star_attn(U, ids, codes=None, centroids=None, row0=0, X=None, x_group_stride=1, codes_direct=0):
+    _dev(U, ids, codes, centroids, X)
+    T, H, D = U.shape
+    kg = ids.shape[1]
+    Z = torch.empty_like(U)
+    has_nb = torch.empty(T, device=U.device, dtype=torch.float32)
+    a = _lib.gnnlm_star_attn_t()
+    a.U, a.ids = U.data_ptr(), ids.data_ptr()
+    a.T, a.H, a.D, a.kg = T, H, D, kg
+    if codes is not None:
+        a.codes, a.row0, a.n_local = codes.data_ptr(), row0, codes.shape[0]
+        a.M, a.dsub = centroids.shape[0], centroids.shape[2]
+        a.centroids = centroids.data_ptr()
+        a.codes_direct = codes_direct
+    else:
+        a.X, a.ldx, a.x_group_stride = X.data_ptr(), X.stride(0), x_group_stride
+    a.Z, a.has_nb = Z.data_ptr(), has_nb.data_ptr()
+    call_desc("gnnlm_star_attn", a)
+    return Z, has_nb
+
+
+def chain_attn(Q, K, V, valid, left, right, H, scale=None):
+    _dev(Q, K, V, valid, scale)
+    S, d = Q.shape
+    n_g = 1 + left + right
+    out = torch.empty_like(Q)
+    c = _lib.gnnlm_chain_attn_t()
+    c.Q, c.K, c.V, c.ld = Q.data_ptr(), K.data_ptr(), V.data_ptr(), Q.stride(0)
+    c.valid = valid.data_ptr()
+    c.n_groups, c.left, c.right, c.H, c.dk = S // n_g, left, right, H, d // H
+    if scale is not None:
+        c.scale = scale.data_ptr()
+    c.out, c.ldo = out.data_ptr(), out.stride(0)
+    call_desc("gnnlm_chain_attn", c)
+    return out
+
+
+def causal_softmax_(S, T, max_ctx=0):
+    """In place over S [n_mats, T, ld]."""
+    n_mats, T_, ld = S.shape
+    assert T_ == T
+    call("gnnlm_causal_softmax", ptr(S), n_mats, T, ld, max_ctx, stream())
+    return S
+
+
+def layernorm(x, gamma, beta, eps=1e-5, valid=None):
+    rows, d = x.shape
+    out = torch.empty_like(x)
+    call("gnnlm_layernorm", ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(out), out.stride(0), rows, d, eps,
+         ptr(valid), stream())
+    return out
+
+
+def half_to_float(x):
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    call("gnnlm_half_to_float", ptr(x), ptr(out), x.numel(), stream())
+    return out
+
+
+def row_lse_pick(logits, pick=None):
+    rows, n = logits.shape
+    lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    picked = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    call("gnnlm_row_lse_pick", ptr(logits), logits.stride(0), rows, None, n, ptr(pick), ptr(lse), ptr(picked), stream())
+    return lse, picked
+
+
+def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_store=None, row0=0, knn_vals=None):
+    _dev(lm_logp, sims, ids, targets, vals, knn_vals)
+    n, k = sims.shape
+    dev = sims.device
+    out = torch.empty(n, device=dev, dtype=torch.float32)
+    pk = torch.empty(n, device=dev, dtype=torch.float32)
+    rec = torch.empty(n, device=dev, dtype=torch.int64)
+    d = _lib.gnnlm_knn_interp_t()
+    d.lm_logp, d.sims, d.ids, d.targets = lm_logp.data_ptr(), sims.data_ptr(), ids.data_ptr(), targets.data_ptr()
+    d.vals_itemsize = 4
+    if vals is not None:
+        d.vals, d.vals_itemsize = vals.data_ptr(), vals.element_size()
+        d.n_local = vals.shape[0]
+        d.n_store = n_store if n_store is not None else vals.shape[0]
+        d.row0 = row0
+    if knn_vals is not None:
+        assert knn_vals.dtype == torch.int32
+        d.knn_vals = knn_vals.data_ptr()
+    d.n, d.k = n, k
+    d.temperature, d.lmbda = temperature, lmbda
+    d.out_logp, d.out_pknn, d.out_recall = out.data_ptr(), pk.data_ptr(), rec.data_ptr()
+    call_desc("gnnlm_knn_interp", d)
+    return out, pk, rec
+
+
+def masked_sum_f64(x, mask=None, acc=None):
+    if acc is None:
+        acc = torch.zeros(1, device=x.device, dtype=torch.float64)
+    call("gnnlm_masked_sum_f64", ptr(x), ptr(mask), x.numel(), ptr(acc), stream())
+    return acc

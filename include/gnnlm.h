@@ -1,0 +1,251 @@
+/* gnnlm.h -- C ABI of libgnnlm_hip.so: the MI355X (gfx950) implementation of the GNN+kNN eval hot
+ * path of ShannonAI/GNN-LM (`fairseq-eval-lm --graph --use-precompute-feat --knnlm`).
+ *
+ * The reference has NO native / FFI boundary on this path (everything is Python over torch, DGL and
+ * faiss: SURVEY.md section 8b), so each entry point below names the reference Python function it
+ * replaces (paths relative to the reference tree).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative errno-style code (GNNLM_E_*);
+ *     gnnlm_last_error() returns a thread-local message for the last failure
+ *   - all `const float*` / `void*` operands are DEVICE pointers unless the name says `host`
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls only enqueue work
+ *   - the caller owns every buffer; descriptors are plain structs, zero-initialise them and fill
+ *     what you need (0 / NULL always means "not used / default")
+ *   - matrices are row-major; "ld" is the row stride in ELEMENTS
+ *   - no call allocates or synchronises except gnnlm_store_* (explicitly documented)
+ */
+#ifndef GNNLM_H
+#define GNNLM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNLM_ABI_VERSION 1
+#define GNNLM_OK 0
+#define GNNLM_E_INVALID (-22)
+#define GNNLM_E_NOMEM (-12)
+#define GNNLM_E_HIP (-5)
+
+const char* gnnlm_last_error(void);
+int gnnlm_abi_version(void);
+/* name of the code object's target ("gfx950") -- lets a loader check it got the MI355X build */
+const char* gnnlm_target_arch(void);
+/* sizeof() of a descriptor struct by its typedef name ("gnnlm_gemm_t", ...), 0 if unknown: lets a
+ * foreign-language binding verify its struct mirror */
+size_t gnnlm_sizeof(const char* struct_name);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense contraction:  C[M,N] = alpha * A[M,K] . W[N,K]^T (+ gate[row] * bias) (+ R)
+ * f32 operands, f32 MFMA accumulate (v_mfma_f32_32x32x2_f32: exact fmaf chain).
+ * Replaces: nn.Linear of HGTLayer (fairseq/models/hgt.py:315-322,401), the relation einsum (:347-348),
+ *           fn.v_dot_u / u_mul_e+sum on the dense tgt-tgt edges (:354,383-385),
+ *           `x @ A` of TorchPQCodec.decode (knn/pq_wrapper.py:202),
+ *           the head/tail matmuls of AdaptiveSoftmax (fairseq/modules/adaptive_softmax.py:184-203).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gnnlm_gemm {
+    const float* A;  int64_t lda;
+    const int32_t* a_rows;     /* optional gather: logical row r reads A row a_rows[r] (<0: zero row) */
+    const float* W;  int64_t ldw;
+    float* C;        int64_t ldc;
+    const int32_t* c_rows;     /* optional scatter: logical row r is stored to C (and read from R) row c_rows[r] */
+    const float* bias;         /* bias_mode 1: per column [N]; 2: per row [M] */
+    int32_t bias_mode;
+    const float* gate;         /* optional [M]: per-row multiplier of the bias */
+    const float* R;  int64_t ldr;
+    float alpha;               /* 0 is read as 1 */
+    int32_t M, N, K;           /* K % 4 == 0 */
+    const int32_t* m_dev;      /* optional device-side row count (<= M): tiles beyond it exit */
+    int32_t batch1, batch2;    /* 0 is read as 1; batch index (b1, b2) */
+    int64_t sA1, sA2, sW1, sW2, sC1, sC2, sB1, sB2, sR1, sR2;   /* batch strides in elements */
+    int32_t precision;         /* 0: f32 MFMA */
+} gnnlm_gemm_t;
+int gnnlm_gemm_nt(const gnnlm_gemm_t* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PQ datastore row gather + decode (HBM-resident store).
+ * Replaces: quant_neighbor_feats[offset] / neighbor_tokens[offset] row gathers and the context
+ *           expansion of GraphTokenBlockDataset.new_build_graph
+ *           (fairseq/data/token_block_dataset.py:354-394,407-410; PlasmaArray.__getitem__
+ *           fairseq/data/new_plasma_utils.py:115-116; MmapDataset.__getitem__ fairseq/data/mmap_dataset.py:57-58)
+ *           and the lookup half of TorchPQCodec.decode (knn/pq_wrapper.py:169-196).
+ * Slot order inside a group: centre o, then o-left..o-1, then o+1..o+right (reference node order).
+ * A slot is valid iff ids[g] != -1 and 0 <= row < n_store (the bound of :384) and the
+ * row lies in the shard [row0, row0+n_local).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gnnlm_gather {
+    const uint8_t* codes;      /* [n_local, M] */
+    const void* vals;          /* [n_local] int16 / int32 (optional) */
+    int32_t vals_itemsize;     /* 2 or 4 */
+    int64_t n_store, row0, n_local;
+    int32_t M, dsub;           /* dsub % 4 == 0; ksub is fixed to 256 (8-bit codes, pq_wrapper.py:33) */
+    const float* centroids;    /* [M, 256, dsub] */
+    const int64_t* ids;        /* [n_groups] */
+    int64_t n_groups;
+    int32_t left, right;
+    float* out_x;  int64_t ld_x;   /* optional [n_groups*(1+left+right), M*dsub], zero rows for invalid slots */
+    uint8_t* out_codes;        /* optional [n_slots, M] */
+    int32_t* out_labels;       /* optional [n_slots], -1 for invalid */
+    uint8_t* out_valid;        /* optional [n_slots] */
+    int32_t direct;            /* 1: `codes` is an already-fetched [n_slots, M] buffer (slot s = row s), */
+    const uint8_t* in_valid;   /*    validity comes from in_valid[n_slots]; ids is ignored */
+} gnnlm_gather_t;
+int gnnlm_pq_gather_decode(const gnnlm_gather_t* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ('ntgt','inter','tgt') attention with the neighbour-side projections absorbed into the query:
+ *   s[i,h,j] = x_j . U[i,h,:]  (valid j only),  alpha = softmax_j,  Z[i,h,:] = sum_j alpha x_j
+ * x_j is decoded on the fly from PQ codes (codes != NULL) or read from dense rows (X != NULL).
+ * Replaces: apply_edges(v_dot_u) + edge_softmax + u_mul_e/sum on the star edges
+ *           (fairseq/models/hgt.py:354-356,383-385) fused with the gather/decode above.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gnnlm_star_attn {
+    const float* U;            /* [T, H, D] */
+    const int64_t* ids;        /* [T, kg], -1 = no neighbour */
+    int32_t T, H, D, kg;
+    const uint8_t* codes;  int64_t row0, n_local;  int32_t M, dsub;
+    int32_t codes_direct;      /* s > 0: `codes` is an already-fetched buffer, row of (i,j) = (i*kg+j)*s (sharded store) */
+    const float* centroids;
+    const float* X;  int64_t ldx;  int64_t x_group_stride;   /* dense row of (i,j) = X + (i*kg+j)*x_group_stride*ldx */
+    float* Z;                  /* [T, H, D] */
+    float* has_nb;             /* optional [T]: 1.0 if >= 1 valid neighbour */
+} gnnlm_star_attn_t;
+int gnnlm_star_attn(const gnnlm_star_attn_t* desc, void* stream);
+
+/* ('ntgt','intra','ntgt'): path graph with self loops over each group's slots
+ * (build_ntgt_edges(context=1, bidirect=True), fairseq/data/token_block_dataset.py:395-398,545-584;
+ *  attention math fairseq/models/hgt.py:354-356,383-385). */
+typedef struct gnnlm_chain_attn {
+    const float* Q;  const float* K;  const float* V;  int64_t ld;   /* [n_slots, d] */
+    const uint8_t* valid;      /* [n_slots] */
+    int64_t n_groups;  int32_t left, right, H, dk;
+    const float* scale;        /* optional [H]; NULL = 1 (relation_pri/sqrt(dk) folded into K) */
+    float* out;  int64_t ldo;
+} gnnlm_chain_attn_t;
+int gnnlm_chain_attn(const gnnlm_chain_attn_t* desc, void* stream);
+
+/* masked row softmax of the dense ('tgt','intra','tgt') scores (auto_regressive_edges,
+ * fairseq/data/token_block_dataset.py:586-594; edge_softmax fairseq/models/hgt.py:356).
+ * S holds n_mats matrices of T rows, row stride ld; columns >= T are zeroed. */
+int gnnlm_causal_softmax(float* S, int64_t n_mats, int32_t T, int64_t ld, int32_t max_ctx, void* stream);
+
+/* LayerNorm epilogue of HGTLayer (fairseq/models/hgt.py:404-405).  valid (optional): rows with 0 -> zeros */
+int gnnlm_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,
+                    int64_t ldo, int64_t rows, int32_t d, float eps, const uint8_t* valid, void* stream);
+
+/* fp16 -> fp32 (precompute_feats[offsets].astype(np.float32), token_block_dataset.py:328) */
+int gnnlm_half_to_float(const void* src, float* dst, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tied adaptive softmax, target log-probability only
+ * (AdaptiveSoftmax.get_log_prob with target, fairseq/modules/adaptive_softmax.py:170-206, +
+ *  gather_target_probs fairseq/sequence_scorer.py:48-53,89).
+ * ---------------------------------------------------------------------------------------------- */
+int gnnlm_row_lse_pick(const float* logits, int64_t ld, int64_t rows, const int32_t* m_dev, int32_t n,
+                       const int32_t* pick, float* lse, float* picked, void* stream);
+
+typedef struct gnnlm_adaptive_softmax {
+    int32_t d, n_bands;
+    int32_t cutoff[8];         /* cutoff[0..n_bands-1]; cutoff[n_bands-1] = vocab size */
+    const float* head_w;       /* [cutoff[0] + n_bands - 1, d]: rows of E_0 followed by class_proj */
+    const float* proj_t[8];    /* band b>=1: [dim_b, d] (embeddings.b.1.weight TRANSPOSED) */
+    const float* emb[8];       /* band b>=1: [cutoff[b]-cutoff[b-1], dim_b] */
+    int32_t dim[8];
+} gnnlm_adaptive_softmax_t;
+size_t gnnlm_adaptive_workspace_bytes(const gnnlm_adaptive_softmax_t* w, int64_t n);
+/* lm_logp[r] = log p(target[r] | x[r]) */
+int gnnlm_adaptive_target_logp(const gnnlm_adaptive_softmax_t* w, const float* x, int64_t ldx,
+                               const int64_t* target, int64_t n, float* lm_logp,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * kNN-LM distance-softmax + interpolation
+ * (KNNModel.get_knn_prob knn/knn_model.py:192-217; SequenceScorer fairseq/sequence_scorer.py:55-68,110,121).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gnnlm_knn_interp {
+    const float* lm_logp;      /* [n] */
+    const float* sims;         /* [n, k] similarities after sim_func (knn_model.py:137-177) */
+    const int64_t* ids;        /* [n, k], -1 = padding (masked with -1e10, :193) */
+    const void* vals;  int32_t vals_itemsize;  int64_t n_store, row0, n_local;
+    const int32_t* knn_vals;   /* optional [n, k]: vals[ids] already fetched (sharded store) */
+    const int64_t* targets;    /* [n] */
+    int64_t n;  int32_t k;
+    float temperature;
+    double lmbda;
+    float* out_logp;           /* [n] */
+    float* out_pknn;           /* optional [n] */
+    int64_t* out_recall;       /* optional [n] */
+} gnnlm_knn_interp_t;
+int gnnlm_knn_interp(const gnnlm_knn_interp_t* desc, void* stream);
+
+/* out[0] += sum_i x[i] * (mask ? mask[i] != 0 : 1), accumulated in f64 (score_sum of
+ * fairseq_cli/eval_lm.py:273; the reference accumulates in f32 on the CPU) */
+int gnnlm_masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HGT forward over the implicit token/neighbour graph
+ * (TokenGraphTransformerDecoder.extract_graph_features fairseq/models/transformer.py:1011-1053,
+ *  HGT.forward fairseq/models/hgt.py:494-513, HGTLayer.forward :299-420).
+ * Weights are PREPARED (folded) tensors, see gnnlm_amd/hgt.py::prepare_hgt_weights and DESIGN.md.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gnnlm_hgt_layer {
+    /* node type tgt */
+    const float *wq_t, *bq_t, *wk_t, *bk_t, *wv_t, *bv_t, *wa_t, *ba_t, *ln_g_t, *ln_b_t;
+    /* star edge, absorbed: wku [H, din, dk], wvz_t [H, dk, din], bvz [d] */
+    const float *wku, *wvz_t, *bvz;
+    int32_t din;
+    /* node type ntgt (NULL in the last layer unless ntgt outputs are requested) */
+    const float *wq_n, *bq_n, *wk_n, *bk_n, *wv_n, *bv_n, *wa_n, *ba_n, *ln_g_n, *ln_b_n;
+} gnnlm_hgt_layer_t;
+
+typedef struct gnnlm_hgt {
+    int32_t d, n_heads, n_layers, left, right, max_intra_context;
+    float ln_eps;
+    int32_t M, dsub;
+    const float* centroids;    /* [M, 256, dsub] */
+    const float* opq_at;       /* [d, M*dsub] = A^T, NULL if the codec has no pre-transform */
+    const float* opq_nba;      /* [d] = -(b . A), NULL if no b */
+    const uint8_t* codes;  const void* vals;  int32_t vals_itemsize;
+    int64_t n_store, row0, n_local;
+    const gnnlm_hgt_layer_t* layers;   /* HOST array [n_layers] */
+} gnnlm_hgt_t;
+
+typedef struct gnnlm_hgt_io {
+    int32_t n_blocks, T, kg;   /* n_blocks independent blocks of T tokens (causal attention stays inside a block) */
+    const float* tgt_feats;    /* [n_blocks*T, d] f32 */
+    const int64_t* ids;        /* [n_blocks*T, kg] neighbour rows, -1 = none */
+    const uint8_t* fetched_codes;   /* optional [n_blocks*T*kg*(1+l+r), M]: slots already fetched (sharded store) */
+    const uint8_t* fetched_valid;   /* with fetched_codes: [n_slots] */
+    int32_t fetched_centres_only;   /* 1: fetched_* hold only the centre slot of each group ([n_blocks*T*kg, M]);
+                                       legal only when no ntgt update is needed (n_layers == 1, out_ntgt == NULL) */
+    float* out_tgt;            /* [n_blocks*T, d] */
+    float* out_ntgt;           /* optional [n_slots, d]: last layer's ntgt states (API parity / tests) */
+    uint8_t* out_valid;        /* optional [n_slots] */
+} gnnlm_hgt_io_t;
+size_t gnnlm_hgt_workspace_bytes(const gnnlm_hgt_t* model, const gnnlm_hgt_io_t* io);
+int gnnlm_hgt_forward(const gnnlm_hgt_t* model, const gnnlm_hgt_io_t* io, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Owning HBM store for non-torch callers (DataStore / PlasmaArray residency,
+ * knn/data_store.py:29-64, fairseq/tasks/language_modeling.py:274-276).  These DO allocate and the
+ * uploads synchronise the given stream before returning.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gnnlm_store gnnlm_store_t;
+int gnnlm_store_create(int64_t n_store, int64_t row0, int64_t n_local, int32_t M, int32_t vals_itemsize,
+                       int32_t device, gnnlm_store_t** out);
+int gnnlm_store_upload_codes(gnnlm_store_t* s, const uint8_t* host_codes, int64_t first_local_row, int64_t n_rows, void* stream);
+int gnnlm_store_upload_vals(gnnlm_store_t* s, const void* host_vals, int64_t first_local_row, int64_t n_rows, void* stream);
+const uint8_t* gnnlm_store_codes(const gnnlm_store_t* s);
+const void* gnnlm_store_vals(const gnnlm_store_t* s);
+int gnnlm_store_destroy(gnnlm_store_t* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNLM_H */

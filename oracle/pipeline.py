@@ -66,3 +66,18 @@ def eval_block(blk, model, lmbda, temperature, dtype=torch.float32):
     else:
         out["logp"] = lm_logp
     return out
+
+
+def run_problem(prob, lmbda, temperature, dtype=torch.float32):
+    """Evaluate a ``gnnlm_amd.synthetic.make_problem`` problem with the oracle, block by block."""
+    blk = prob["block"]
+    model = {"sd": {k: v for k, v in prob["sd"].items()}, "n_layers": prob["n_layers"], "n_heads": prob["n_heads"],
+             "centroids": prob["cen"], "A": prob["A"], "b": prob["b"], "codes": prob["codes"], "vals": prob["vals"],
+             "n_store": prob["n_store"], "left": prob["left"], "right": prob["right"], "asm": prob["asm"]}
+    T, outs = blk["T"], []
+    for i in range(blk["n_blocks"]):
+        sl = slice(i * T, (i + 1) * T)
+        one = {"neighbor_idxs": blk["ids"][sl], "tgt_feats": blk["tgt_feats"][sl], "targets": blk["targets"][sl],
+               "knn_sims": blk["knn_sims"][sl], "knn_ids": blk["knn_ids"][sl]}
+        outs.append(eval_block(one, model, lmbda, temperature, dtype))
+    return {k: torch.cat([o[k] for o in outs]).numpy() for k in outs[0]}

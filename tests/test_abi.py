@@ -1,0 +1,53 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/gnnlm.h
+declares, and the generated ctypes mirrors have the sizes the C compiler sees.  No compute calls."""
+import ctypes
+import os
+
+import pytest
+
+from gnnlm_amd import _lib
+
+
+def test_library_loads_and_is_gfx950():
+    L = _lib.lib()
+    assert L.gnnlm_target_arch() == b"gfx950"
+    assert L.gnnlm_abi_version() == 1
+
+
+def test_every_declared_symbol_is_exported():
+    L = _lib.lib()
+    syms = _lib.exported_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), s
+
+
+def test_struct_mirrors_match_c_sizes():
+    L = _lib.lib()
+    assert len(_lib.STRUCTS) >= 9
+    for name, st in _lib.STRUCTS.items():
+        assert L.gnnlm_sizeof(name.encode()) == ctypes.sizeof(st), name
+    assert L.gnnlm_sizeof(b"nope") == 0
+
+
+def test_code_object_targets_gfx950_only():
+    data = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    for other in (b"gfx942", b"gfx90a", b"sm_90"):
+        assert other not in data
+
+
+def test_host_tensors_are_refused():
+    import torch
+    from gnnlm_amd import ops
+    with pytest.raises(_lib.GnnlmError):
+        ops.gemm_nt(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_product_package_does_not_import_oracle():
+    root = os.path.join(_lib.ROOT, "gnn-lm_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
