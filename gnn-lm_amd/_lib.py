@@ -79,6 +79,10 @@ def lib():
             raise GnnlmError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  gnnlm_amd has no CPU fallback.")
+        # torch first: its wheel bundles a HIP runtime with the same SONAME as /opt/rocm's
+        # (libamdhip64.so.7); whichever is loaded first serves the whole process, and device memory
+        # handed over from torch must belong to the runtime the kernels are launched on.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.gnnlm_last_error.restype = ctypes.c_char_p
         L.gnnlm_target_arch.restype = ctypes.c_char_p

@@ -25,8 +25,10 @@ class AdaptiveSoftmax:
         self.cutoff = [int(c) for c in cutoff]
         self.d = emb[0].shape[1]
         self.head_w = f(torch.cat([emb[0].float(), class_proj.float()], 0))      # adaptive_softmax.py:24-47
-        self.emb = [None] + [f(e) for e in emb[1:]]
-        self.proj_t = [None] + [f(p.t()) for p in proj[1:]]                      # TiedLinear(transpose=True), :99-101
+        # tail dims are padded with zero columns to a multiple of 4 (the GEMM's K granularity): exact
+        pad = lambda t: torch.nn.functional.pad(t.float(), (0, (-t.shape[1]) % 4))
+        self.emb = [None] + [f(pad(e)) for e in emb[1:]]
+        self.proj_t = [None] + [f(pad(p).t()) for p in proj[1:]]                 # TiedLinear(transpose=True), :99-101
         w = _lib.gnnlm_adaptive_softmax_t()
         w.d, w.n_bands = self.d, len(cutoff)
         for i, c in enumerate(self.cutoff):

@@ -277,7 +277,9 @@ __global__ __launch_bounds__(256) void chain_attn_kernel(ChainAttnParams p) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     const int u = pos + d - 1;
-                    if (u >= 0 && u < MAX_NG) o = fmaf(e[d] * inv, v[u][t], o);
+                    if (u >= 0 && u < MAX_NG) {
+                        if (has[d]) o = fmaf(e[d] * inv, v[u][t], o);
+                    }
                 }
                 p.out[slot_of[pos] * p.ldo + h * dk + el] = o;
             }
