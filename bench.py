@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Benchmark of the GNN+kNN eval hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path (gather -> HGT -> adaptive softmax -> kNN interpolation -> score
+sum) over one batch of `--blocks` independent 256-token blocks of synthetic input with the real
+WikiText-103 shapes (BASELINE.json configs[1]): 103,227,021-key PQ store (128-B codes, OPQ 1024x1024)
+and label table resident in HBM, d=1024, 8 heads, k_g=128 graph neighbours with context 2+2, kNN
+k=1024 (search results given), vocabulary 267,744 with the tied adaptive softmax.
+Inputs are resident in HBM when the timed region starts.  N > 1: every rank scores its own blocks
+(weak scaling); the store is range-sharded and rows are fetched with an RCCL all-to-all
+(--store replicated skips the exchange).
+
+Prints ONE JSON line (rank 0).  `roofline` describes the kernel with the largest share of the step,
+timed with HIP events on its launch stream inside the timed region; `kernels` lists every kernel of
+the step from a profiled warm-up step; `cpu_baseline` is the CPU oracle (the reference algorithm as
+written, torch-CPU fp32) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK = {"mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}           # MI355X_MICROARCH.md chip table
+KERNEL_BOUND = {"gemm_nt_f32_kernel": "mfma"}                    # everything else on this path: hbm
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=8, help="256-token blocks per step per GPU")
+    ap.add_argument("--layers", type=int, default=1, help="HGT layers (configs[1]: 1; the shipped recipe: 3)")
+    ap.add_argument("--n-store", type=int, default=103227021)
+    ap.add_argument("--gcn-k", type=int, default=128)
+    ap.add_argument("--k", type=int, default=1024)
+    ap.add_argument("--tokens-per-sample", type=int, default=256)
+    ap.add_argument("--lmbda", type=float, default=0.25)
+    ap.add_argument("--temperature", type=float, default=0.01)
+    ap.add_argument("--store", choices=["sharded", "replicated"], default="sharded")
+    ap.add_argument("--pool", type=int, default=4, help="distinct input batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=48)
+    ap.add_argument("--small", action="store_true", help="tiny shapes (plumbing check only)")
+    return ap.parse_args()
+
+
+def zipf_dev(n, vocab, gen, dev):
+    u = torch.rand(n, generator=gen, device=dev, dtype=torch.float64)
+    return torch.clamp((torch.exp(u * np.log(vocab + 1.0)) - 1.0).to(torch.int64), max=vocab - 1)
+
+
+def build(args, dev, rank, world):
+    from gnnlm_amd.adaptive_softmax import AdaptiveSoftmax
+    from gnnlm_amd.dist import Shard
+    from gnnlm_amd.engine import GnnLmEngine
+    from gnnlm_amd.hgt import HGT, CodeStore
+    from gnnlm_amd.synthetic import make_asm_weights, make_codec
+    if args.small:
+        d, H, M, dsub, vocab, cutoff = 128, 8, 16, 8, 5000, [500, 2000]
+    else:
+        d, H, M, dsub, vocab, cutoff = 1024, 8, 128, 8, 267744, [20000, 60000]
+    rs = np.random.RandomState(1234)
+    cen, A, b = make_codec(rs, M, dsub, d, opq=True)
+    sharded = world > 1 and args.store == "sharded"
+    shard = Shard(args.n_store, world if sharded else 1, rank if sharded else 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + shard.row0)
+    n_local = shard.n_local
+    codes = torch.empty(n_local, M, dtype=torch.uint8, device=dev)
+    step = 1 << 22
+    for s in range(0, n_local, step):                                     # uint8 i.i.d. uniform
+        e = min(n_local, s + step)
+        codes[s:e] = torch.randint(0, 256, (e - s, M), generator=gen, device=dev, dtype=torch.uint8)
+    vals = zipf_dev(n_local, vocab, gen, dev).to(torch.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    store = CodeStore(codes=codes, centroids=t(cen), n_store=args.n_store, row0=shard.row0, vals=vals, A=t(A), b=t(b))
+    torch.manual_seed(1234)
+    hgt = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=args.layers, n_heads=H)
+    w = make_asm_weights(rs, vocab, d, cutoff)
+    asm = AdaptiveSoftmax(w["cutoff"], w["emb"], w["proj"], w["class_proj"], dev)
+    eng = GnnLmEngine(hgt, asm, store, 2, 2)
+    cpu_model = {"sd": hgt.state_dict(), "asm": w, "cen": cen, "A": A, "b": b, "d": d, "H": H, "M": M, "vocab": vocab}
+    return eng, shard, sharded, cpu_model, (d, vocab)
+
+
+def make_batches(args, dev, rank, d, vocab):
+    from gnnlm_amd.engine import BlockBatch
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99 + rank)
+    T, B, kg, k, N = args.tokens_per_sample, args.blocks, args.gcn_k, args.k, args.n_store
+    n = T * B
+    out = []
+    for _ in range(args.pool):
+        ids = torch.randint(0, N, (n, kg), generator=gen, device=dev, dtype=torch.int64)
+        ids[torch.rand(n, kg, generator=gen, device=dev) < 0.001] = -1
+        ids[torch.arange(B, device=dev) * T + 3] = -1
+        feats = torch.randn(n, d, generator=gen, device=dev).half()
+        knn_ids = torch.randint(0, N, (n, k), generator=gen, device=dev, dtype=torch.int64)
+        knn_ids[::7, -2:] = -1
+        sims = torch.sort(torch.rand(n, k, generator=gen, device=dev) * 0.7 + 0.2, dim=1, descending=True).values
+        targets = zipf_dev(n, vocab, gen, dev)
+        out.append(BlockBatch(ids=ids, tgt_feats=feats, targets=targets, n_blocks=B, T=T,
+                              knn_sims=sims.contiguous(), knn_ids=knn_ids))
+    return out
+
+
+def cpu_baseline(args, cpu_model):
+    """The reference algorithm as written (oracle = test infrastructure, here the timed CPU baseline):
+    per-row graph expansion, PQ decode, un-elided HGT, adaptive softmax, kNN prob, interpolation."""
+    from gnnlm_amd.synthetic import make_block, zipf_tokens
+    from oracle import pipeline
+    rs = np.random.RandomState(7)
+    n_host = min(args.n_store, 2_000_000)
+    M = cpu_model["M"]
+    codes = rs.randint(0, 256, size=(n_host, M)).astype(np.uint8)
+    vals = zipf_tokens(rs, cpu_model["vocab"], n_host).astype(np.int32)
+    Tc = args.cpu_tokens
+    blk = make_block(rs, n_host, vals, cpu_model["vocab"], cpu_model["d"], Tc, args.gcn_k, args.k)
+    prob = {"block": blk, "sd": cpu_model["sd"], "n_layers": args.layers, "n_heads": cpu_model["H"],
+            "cen": cpu_model["cen"], "A": cpu_model["A"], "b": cpu_model["b"], "codes": codes, "vals": vals,
+            "n_store": n_host, "left": 2, "right": 2, "asm": cpu_model["asm"]}
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    pipeline.run_problem(prob, args.lmbda, args.temperature)
+    dt = time.perf_counter() - t0
+    return {"value": Tc / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"1 block of {Tc} tokens, k_g={args.gcn_k}, l=r=2, L={args.layers}, kNN k={args.k}, d={cpu_model['d']}, "
+                      f"{n_host}-row host table, torch-CPU fp32, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gnnlm_amd import _lib, ops
+    from gnnlm_amd.dist import ShardedFetcher
+    eng, shard, sharded, cpu_model, (d, vocab) = build(args, dev, rank, world)
+    batches = make_batches(args, dev, rank, d, vocab)
+    fetcher = ShardedFetcher(eng.store, shard) if sharded else None
+    centres_only = args.layers == 1
+    acc = torch.zeros(1, device=dev, dtype=torch.float64)
+
+    def step(i):
+        b = batches[i % len(batches)]
+        if fetcher is not None:                                   # RCCL all-to-all row fetch
+            b.fetched_codes, b.fetched_valid = fetcher.fetch_codes(b.ids, 2, 2, centres_only)
+            b.fetched_centres_only = centres_only
+            b.knn_vals = fetcher.fetch_knn_vals(b.knn_ids)
+        out = eng.score(b, args.lmbda, args.temperature)
+        ops.masked_sum_f64(out["logp"], None, acc)                # score_sum (eval_lm.py:273)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up; the first warm-up step after initialisation is profiled kernel by kernel
+    step(0)
+    barrier()
+    _lib.profile_begin()
+    step(1)
+    torch.cuda.synchronize()
+    kern = _lib.profile_end()
+    for i in range(max(0, args.warmup - 2)):
+        step(i + 2)
+    dominant = max(kern, key=lambda k_: kern[k_]["total_ms"])
+    names = [_lib.lib().gnnlm_kernel_name(i).decode() for i in range(9)]
+    # ---- timed region: exactly K steps, the dominant kernel bracketed by HIP events on its stream
+    acc.zero_()
+    barrier()
+    _lib.profile_begin(1 << names.index(dominant))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_end()[dominant]
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+        dist.all_reduce(acc)
+    tokens = args.steps * args.blocks * args.tokens_per_sample * world
+    score_sum = acc.item()
+
+    def roof(name, e):
+        bound = KERNEL_BOUND.get(name, "hbm")
+        sec = e["total_ms"] / 1e3
+        if bound == "mfma":
+            a, p, unit = e["flops"] / sec / 1e12, PEAK["mfma_f32_tflops"], "TFLOP/s"
+        else:
+            a, p, unit = e["bytes"] / sec / 1e9, PEAK["hbm_gbs"], "GB/s"
+        return {"kernel": name, "bound": bound, "achieved": round(a, 2), "peak": p, "unit": unit,
+                "frac": round(a / p, 4), "launches": e["launches"], "avg_us": round(e["total_ms"] * 1e3 / e["launches"], 2)}
+
+    if rank == 0:
+        r = roof(dominant, prof)
+        r["traffic"] = None
+        r["launches_per_step"] = prof["launches"] / args.steps
+        res = {
+            "metric": "eval tokens/sec on WikiText-103 (k=1024, GNN+KNN); test ppl match",
+            "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: WikiText-103 full PQ datastore in HBM, k_g=128, "
+                                   "context 2+2, HGT 1 layer, kNN k=1024 (search results given), 256-token blocks",
+                       "n_store": args.n_store, "blocks_per_step_per_gpu": args.blocks, "tokens_per_block": args.tokens_per_sample,
+                       "gcn_k": args.gcn_k, "knn_k": args.k, "hgt_layers": args.layers, "d": d, "vocab": vocab,
+                       "lmbda": args.lmbda, "temperature": args.temperature,
+                       "store": ("range-sharded + RCCL all-to-all" if sharded else "replicated" if world > 1 else "single GPU"),
+                       "synthetic_ppl": round(float(2 ** (-score_sum / tokens / np.log(2))), 4)},
+            "roofline": r,
+            "kernels": [roof(k_, v) for k_, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"])],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args, cpu_model)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

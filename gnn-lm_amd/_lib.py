@@ -90,6 +90,10 @@ def lib():
         L.gnnlm_hgt_workspace_bytes.restype = ctypes.c_size_t
         L.gnnlm_sizeof.restype = ctypes.c_size_t
         L.gnnlm_sizeof.argtypes = [ctypes.c_char_p]
+        L.gnnlm_kernel_name.restype = ctypes.c_char_p
+        L.gnnlm_kernel_name.argtypes = [ctypes.c_int32]
+        L.gnnlm_profile_begin.argtypes = [ctypes.c_uint32]
+        L.gnnlm_profile_end.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         L.gnnlm_store_codes.restype = ctypes.c_void_p
         L.gnnlm_store_vals.restype = ctypes.c_void_p
         vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
@@ -134,6 +138,25 @@ def stream():
 
 def call(name, *args):
     check(getattr(lib(), name)(*args), name)
+
+
+def profile_begin(mask=0xFFFFFFFF):
+    check(lib().gnnlm_profile_begin(mask), "gnnlm_profile_begin")
+
+
+def profile_end():
+    """-> {kernel name: dict(launches, total_ms, flops, bytes)} for the kernels that were launched."""
+    L = lib()
+    arr = (STRUCTS["gnnlm_profile_entry_t"] * 16)()
+    n = ctypes.c_int32(0)
+    check(L.gnnlm_profile_end(arr, 16, ctypes.byref(n)), "gnnlm_profile_end")
+    out = {}
+    for i in range(n.value):
+        e = arr[i]
+        if e.launches:
+            out[L.gnnlm_kernel_name(e.kernel_id).decode()] = {"launches": e.launches, "total_ms": e.total_ms,
+                                                              "flops": e.flops, "bytes": e.bytes}
+    return out
 
 
 def call_desc(name, desc):

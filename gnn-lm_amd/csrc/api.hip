@@ -21,6 +21,43 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return E_HIP;
 }
 
+// ---------------------------------------------------------------------------------------------
+// profiler: (start, stop) event pairs per launch, resolved at gnnlm_profile_end
+// ---------------------------------------------------------------------------------------------
+unsigned g_prof_mask = 0;
+namespace {
+struct ProfRec { int kid; hipEvent_t a, b; double flops, bytes; int32_t* host_scale; double den; };
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_event_pool;
+std::vector<int32_t*> g_pinned_pool;
+hipEvent_t g_pending_start[K_COUNT];
+hipEvent_t take_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+int32_t* take_pinned() {
+    if (!g_pinned_pool.empty()) { int32_t* p = g_pinned_pool.back(); g_pinned_pool.pop_back(); return p; }
+    int32_t* p = nullptr;
+    (void)hipHostMalloc((void**)&p, sizeof(int32_t), hipHostMallocDefault);
+    return p;
+}
+}  // namespace
+void prof_start(int kid, hipStream_t s) {
+    g_pending_start[kid] = take_event();
+    (void)hipEventRecord(g_pending_start[kid], s);
+}
+void prof_stop(int kid, hipStream_t s, double flops, double bytes, const int32_t* scale_dev, double den) {
+    ProfRec r{kid, g_pending_start[kid], take_event(), flops, bytes, nullptr, den};
+    (void)hipEventRecord(r.b, s);
+    if (scale_dev) {
+        r.host_scale = take_pinned();
+        (void)hipMemcpyAsync(r.host_scale, scale_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    }
+    g_prof_recs.push_back(r);
+}
+
 namespace {
 
 // bump allocator over a caller-provided workspace; a null base only measures
@@ -336,7 +373,7 @@ size_t gnnlm_sizeof(const char* name) {
 #define GNNLM_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
     GNNLM_SZ(gnnlm_gemm_t) GNNLM_SZ(gnnlm_gather_t) GNNLM_SZ(gnnlm_star_attn_t) GNNLM_SZ(gnnlm_chain_attn_t)
     GNNLM_SZ(gnnlm_adaptive_softmax_t) GNNLM_SZ(gnnlm_knn_interp_t) GNNLM_SZ(gnnlm_hgt_layer_t)
-    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t)
+    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t)
 #undef GNNLM_SZ
     return 0;
 }
@@ -394,6 +431,42 @@ int gnnlm_hgt_forward(const gnnlm_hgt_t* m, const gnnlm_hgt_io_t* io, void* work
     GNNLM_DESC(m);
     GNNLM_DESC(io);
     return hgt_forward_impl(*m, *io, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static const char* kKernelNames[K_COUNT] = {"gemm_nt_f32_kernel", "gather_decode_kernel", "star_attn_kernel",
+                                            "chain_attn_kernel", "causal_softmax_kernel", "layernorm_kernel",
+                                            "row_lse_pick_kernel", "knn_interp_kernel", "misc"};
+const char* gnnlm_kernel_name(int32_t kernel_id) {
+    return kernel_id >= 0 && kernel_id < K_COUNT ? kKernelNames[kernel_id] : nullptr;
+}
+int gnnlm_profile_begin(uint32_t kernel_mask) {
+    GNNLM_REQUIRE(g_prof_recs.empty(), "profile_begin: a profile is already open");
+    g_prof_mask = kernel_mask;
+    return OK;
+}
+int gnnlm_profile_end(gnnlm_profile_entry_t* out, int32_t n_max, int32_t* n_out) {
+    GNNLM_REQUIRE(out && n_out && n_max >= K_COUNT, "profile_end: need room for every kernel id");
+    g_prof_mask = 0;
+    for (int k = 0; k < K_COUNT; ++k) out[k] = gnnlm_profile_entry_t{k, 0, 0.0, 0.0, 0.0};
+    for (auto& r : g_prof_recs) {
+        GNNLM_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        GNNLM_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        double scale = 1.0;
+        if (r.host_scale) {
+            scale = std::min(1.0, (double)*r.host_scale / r.den);
+            g_pinned_pool.push_back(r.host_scale);
+        }
+        out[r.kid].launches += 1;
+        out[r.kid].total_ms += ms;
+        out[r.kid].flops += r.flops * scale;
+        out[r.kid].bytes += r.bytes * scale;
+        g_event_pool.push_back(r.a);
+        g_event_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    *n_out = K_COUNT;
+    return OK;
 }
 
 int gnnlm_store_create(int64_t n_store, int64_t row0, int64_t n_local, int32_t M, int32_t vals_itemsize,

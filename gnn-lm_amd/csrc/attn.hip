@@ -323,6 +323,9 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
     const size_t shmem = (size_t)(HB * p.kg + HB * p.D) * sizeof(float);
     GNNLM_REQUIRE(shmem <= 160 * 1024, "star_attn: kg too large for LDS");
     const int nq = p.D / 4;
+    const double rows = (double)p.T * p.kg;
+    ProfScope prof(K_STAR, stream, 4.0 * rows * p.H * p.D,
+                   rows * (8.0 + (p.codes ? (double)p.M : 4.0 * p.D)) + 8.0 * p.T * p.H * p.D);
     dim3 grid(p.T), block(256);
     if (nq <= 64) {
         hipLaunchKernelGGL(star_attn_kernel<1>, grid, block, shmem, stream, p);
@@ -341,6 +344,8 @@ int chain_attn(const ChainAttnParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(p.dk > 0 && p.dk <= 64 * MAX_EPT && p.H > 0, "chain_attn: d_k must be <= 256");
     const int64_t tasks = p.n_groups * p.H;
     if (tasks == 0) return OK;
+    const double slots = (double)p.n_groups * (1 + p.left + p.right);
+    ProfScope prof(K_CHAIN, stream, slots * p.H * p.dk * 12.0, slots * (16.0 * p.H * p.dk + 1.0));
     hipLaunchKernelGGL(chain_attn_kernel, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, stream, p);
     GNNLM_LAUNCH_CHECK();
     return OK;
@@ -350,6 +355,7 @@ int causal_softmax(float* S, int64_t n_mats, int T, int64_t ld, int max_ctx, hip
     GNNLM_REQUIRE(S && T > 0 && ld >= T, "causal_softmax: bad arguments");
     const int64_t rows = n_mats * T;
     if (rows == 0) return OK;
+    ProfScope prof(K_CAUSAL, stream, 0.0, 8.0 * rows * ld);
     hipLaunchKernelGGL(causal_softmax_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, S, rows, T, ld, max_ctx);
     GNNLM_LAUNCH_CHECK();
     return OK;

@@ -29,6 +29,23 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define GNNLM_LAUNCH_CHECK() GNNLM_HIP(hipGetLastError())
 
+// Opt-in per-kernel timing with HIP events on the launch stream (bench.py's live roofline).
+enum KernelId { K_GEMM = 0, K_GATHER = 1, K_STAR = 2, K_CHAIN = 3, K_CAUSAL = 4, K_LAYERNORM = 5, K_LSE = 6,
+                K_KNN = 7, K_MISC = 8, K_COUNT = 9 };
+extern unsigned g_prof_mask;
+void prof_start(int kid, hipStream_t s);
+// flops / bytes: algorithmic work of the launch; if scale_dev != null the work is multiplied by
+// (*scale_dev / scale_den) read back stream-ordered (device-side row counts)
+void prof_stop(int kid, hipStream_t s, double flops, double bytes, const int32_t* scale_dev, double scale_den);
+struct ProfScope {
+    int kid; hipStream_t s; double flops, bytes; const int32_t* sd; double den; bool on;
+    ProfScope(int kid_, hipStream_t s_, double flops_, double bytes_, const int32_t* sd_ = nullptr, double den_ = 1.0)
+        : kid(kid_), s(s_), flops(flops_), bytes(bytes_), sd(sd_), den(den_), on((g_prof_mask >> kid_) & 1u) {
+        if (on) prof_start(kid, s);
+    }
+    ~ProfScope() { if (on) prof_stop(kid, s, flops, bytes, sd, den); }
+};
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // MI355X: 8 XCDs, block b is placed on XCD b % 8 (speed only, never correctness).

@@ -83,6 +83,9 @@ int gather_decode(const GatherParams& p, hipStream_t stream) {
     const int64_t n_slots = p.n_groups * (1 + p.left + p.right);
     if (n_slots == 0) return OK;
     const int64_t blocks = std::min<int64_t>(cdiv(n_slots, 4), 256 * 16);
+    const double row_bytes = (double)p.M + (p.out_x ? 4.0 * p.M * p.dsub : 0.0) + (p.out_codes ? p.M : 0.0) +
+                             (p.out_labels ? 4.0 + p.vals_itemsize : 0.0) + (p.out_valid ? 1.0 : 0.0);
+    ProfScope prof(K_GATHER, stream, 0.0, row_bytes * n_slots + 8.0 * p.n_groups);
     hipLaunchKernelGGL(gather_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
     GNNLM_LAUNCH_CHECK();
     return OK;

@@ -177,6 +177,9 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     const int64_t tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
     GNNLM_REQUIRE(tiles < (1ll << 31) && (int64_t)p.batch1 * p.batch2 < 65536, "gemm: grid too large");
     dim3 grid((unsigned)tiles, (unsigned)(p.batch1 * p.batch2));
+    const double work = 2.0 * p.M * (double)p.N * p.K * p.batch1 * p.batch2;
+    ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N) * p.batch1 * p.batch2,
+                   p.m_dev, (double)p.M);
     hipLaunchKernelGGL(gemm_nt_f32_kernel, grid, dim3(256), 0, stream, p);
     GNNLM_LAUNCH_CHECK();
     return OK;

@@ -194,6 +194,7 @@ int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta
               int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream) {
     GNNLM_REQUIRE(x && gamma && beta && out && d > 0, "layernorm: bad arguments");
     if (rows == 0) return OK;
+    ProfScope prof(K_LAYERNORM, stream, 0.0, 8.0 * rows * d);
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, x, ldx, gamma, beta,
                        out, ldo, rows, d, eps, valid);
     GNNLM_LAUNCH_CHECK();
@@ -220,6 +221,7 @@ int row_lse_pick(const float* logits, int64_t ld, int64_t rows, const int32_t* m
                  float* lse, float* picked, hipStream_t stream) {
     GNNLM_REQUIRE(logits && lse && n > 0, "row_lse_pick: bad arguments");
     if (rows == 0) return OK;
+    ProfScope prof(K_LSE, stream, 0.0, 4.0 * rows * n, m_dev, (double)rows);
     hipLaunchKernelGGL(row_lse_pick_kernel, dim3((unsigned)rows), dim3(256), 0, stream, logits, ld, rows, m_dev, n,
                        pick, lse, picked);
     GNNLM_LAUNCH_CHECK();
@@ -257,6 +259,7 @@ int knn_interp(const KnnInterpParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(p.vals_itemsize == 2 || p.vals_itemsize == 4, "knn_interp: vals must be int16 or int32");
     if (p.n == 0) return OK;
     // coefficients are float32 roundings of the float64 logs, as in coeffs[0] = np.log(1 - coeff)
+    ProfScope prof(K_KNN, stream, 0.0, (double)p.n * p.k * (12.0 + (p.knn_vals ? 4.0 : p.vals_itemsize)) + 16.0 * p.n);
     const float log_1ml = (float)log(1.0 - p.lmbda), log_l = (float)log(p.lmbda);
     hipLaunchKernelGGL(knn_interp_kernel, dim3((unsigned)cdiv(p.n, 4)), dim3(256), 0, stream, p, log_1ml, log_l);
     GNNLM_LAUNCH_CHECK();

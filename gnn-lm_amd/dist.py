@@ -1,0 +1,115 @@
+"""Range-sharded datastore over the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference has no multi-GPU eval path; this is the design BASELINE.json's
+north_star asks for.  Token blocks are data parallel (independent, no collective); the only exchange
+is the row fetch from the range-sharded PQ code table / label table:
+
+    rank g owns rows [g*per, (g+1)*per)   with per = ceil(n_store / world)
+
+Per step: bucket the requested rows by owner -> all_to_all of the counts -> all_to_all of the row
+ids (8 B/row) -> every owner gathers its rows with the HIP gather kernel -> all_to_all of the
+payload back (M = 128 B/row of codes, 4 B/row of labels) -> un-permute.  xGMI is point-to-point
+(7 links x ~153 GB/s per GPU): an all-to-all drives all 7 links at once, unlike a ring, so one fused
+exchange per table per step is the right shape.  Row validity needs no communication: a row is valid
+iff 0 <= row < n_store, which the requester knows.
+
+The function is backend-agnostic (RCCL on the GPUs; the CPU tests run it over gloo with a numpy
+gather injected for the owner-side lookup).
+"""
+from dataclasses import dataclass
+from typing import Callable
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class Shard:
+    n_store: int
+    world: int
+    rank: int
+
+    @property
+    def per(self):
+        return -(-self.n_store // self.world)
+
+    @property
+    def row0(self):
+        return min(self.rank * self.per, self.n_store)
+
+    @property
+    def n_local(self):
+        return max(0, min((self.rank + 1) * self.per, self.n_store) - self.row0)
+
+    def owner(self, rows: torch.Tensor) -> torch.Tensor:
+        """Owning rank of each global row; out-of-range rows (incl. -1) are kept local."""
+        ok = (rows >= 0) & (rows < self.n_store)
+        own = torch.div(rows.clamp(min=0), self.per, rounding_mode="floor").clamp(max=self.world - 1)
+        return torch.where(ok, own, torch.full_like(own, self.rank))
+
+
+def exchange_fetch(rows: torch.Tensor, shard: Shard, local_gather: Callable[[torch.Tensor], torch.Tensor],
+                   group=None) -> torch.Tensor:
+    """Fetch ``payload[row]`` for every global row in ``rows`` (int64 [S]) from its owning rank.
+
+    ``local_gather(global_rows) -> [n, C]`` is evaluated on the owner for the rows it receives (all of
+    them inside its shard, or out of range, for which it must return zeros).  Returns [S, C] in the
+    order of ``rows``.  Two host syncs per call (the variable split sizes)."""
+    S = rows.numel()
+    rows = rows.reshape(-1)
+    owner = shard.owner(rows)
+    order = torch.sort(owner, stable=True).indices
+    send_rows = rows[order].contiguous()
+    counts = torch.bincount(owner, minlength=shard.world).to(torch.int64)
+    recv_counts = torch.empty_like(counts)
+    dist.all_to_all_single(recv_counts, counts, group=group)
+    in_splits, out_splits = counts.tolist(), recv_counts.tolist()
+    recv_rows = torch.empty(sum(out_splits), dtype=rows.dtype, device=rows.device)
+    dist.all_to_all_single(recv_rows, send_rows, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    payload = local_gather(recv_rows).contiguous()
+    assert payload.shape[0] == recv_rows.numel()
+    back = torch.empty((S,) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
+    dist.all_to_all_single(back, payload, output_split_sizes=in_splits, input_split_sizes=out_splits, group=group)
+    out = torch.empty_like(back)
+    out[order] = back
+    return out
+
+
+def slot_rows(ids: torch.Tensor, left: int, right: int, n_store: int) -> torch.Tensor:
+    """Global row of every slot of every group (centre, o-left..o-1, o+1..o+right); -1 if invalid
+    (token_block_dataset.py:358,380-385)."""
+    delta = torch.tensor([0] + list(range(-left, 0)) + list(range(1, right + 1)), dtype=torch.int64, device=ids.device)
+    rows = ids.reshape(-1, 1) + delta
+    ok = (ids.reshape(-1, 1) >= 0) & (rows >= 0) & (rows < n_store)
+    return torch.where(ok, rows, torch.full_like(rows, -1)).reshape(-1)
+
+
+class ShardedFetcher:
+    """Product-side exchange: the owner-side lookup is the HIP gather kernel."""
+
+    def __init__(self, store, shard: Shard, group=None):
+        from . import ops
+        self.ops, self.store, self.shard, self.group = ops, store, shard, group
+        assert store.row0 == shard.row0 and store.codes.shape[0] == shard.n_local
+
+    def _gather_codes(self, rows):
+        st = self.store
+        return self.ops.pq_gather_decode(st.codes, st.centroids, rows, 0, 0, n_store=st.n_store, row0=st.row0,
+                                         want_x=False, want_codes=True, want_valid=False)["codes"]
+
+    def _gather_vals(self, rows):
+        st = self.store
+        return self.ops.pq_gather_decode(st.codes, st.centroids, rows, 0, 0, n_store=st.n_store, row0=st.row0,
+                                         vals=st.vals, want_x=False, want_labels=True, want_valid=False)["labels"]
+
+    def fetch_codes(self, ids, left, right, centres_only):
+        """-> (fetched_codes uint8 [S, M], fetched_valid uint8 [S]) for the slots of ``ids`` [n, kg]."""
+        rows = ids.reshape(-1) if centres_only else slot_rows(ids, left, right, self.store.n_store)
+        rows = torch.where((rows >= 0) & (rows < self.store.n_store), rows, torch.full_like(rows, -1))
+        codes = exchange_fetch(rows, self.shard, self._gather_codes, self.group)
+        return codes, (rows >= 0).to(torch.uint8)
+
+    def fetch_knn_vals(self, knn_ids):
+        """vals[knn_ids] with numpy's negative-index wrap for the -1 padding (knn_model.py:198)."""
+        rows = torch.where(knn_ids < 0, knn_ids + self.store.n_store, knn_ids).reshape(-1)
+        return exchange_fetch(rows, self.shard, self._gather_vals, self.group).reshape(knn_ids.shape)

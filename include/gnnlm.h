@@ -232,6 +232,20 @@ int gnnlm_hgt_forward(const gnnlm_hgt_t* model, const gnnlm_hgt_io_t* io, void* 
                       size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Opt-in live timing (bench.py's roofline): while a profile is open every launch of the selected
+ * kernels is bracketed by HIP events on its own stream.  Not thread-safe; one profile at a time.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gnnlm_profile_entry {
+    int32_t kernel_id;
+    int64_t launches;
+    double total_ms;           /* sum of event-measured launch durations */
+    double flops, bytes;       /* algorithmic work of those launches */
+} gnnlm_profile_entry_t;
+const char* gnnlm_kernel_name(int32_t kernel_id);
+int gnnlm_profile_begin(uint32_t kernel_mask);      /* bit i selects kernel id i */
+int gnnlm_profile_end(gnnlm_profile_entry_t* out, int32_t n_max, int32_t* n_out);   /* synchronises the events */
+
+/* ------------------------------------------------------------------------------------------------
  * Owning HBM store for non-torch callers (DataStore / PlasmaArray residency,
  * knn/data_store.py:29-64, fairseq/tasks/language_modeling.py:274-276).  These DO allocate and the
  * uploads synchronise the given stream before returning.

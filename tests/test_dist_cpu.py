@@ -1,0 +1,105 @@
+"""The sharded-store exchange (gnnlm_amd/dist.py) over gloo with world_size 2 and 3 on the CPU.
+The owner-side lookup is injected (numpy indexing of the rank's shard, i.e. the oracle's gather);
+on the GPUs the same function runs over RCCL with the HIP gather kernel."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gnnlm_amd.dist import Shard, exchange_fetch, slot_rows
+from oracle import graph as og
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_store, M, seed, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(seed)
+        codes = rs.randint(0, 256, size=(n_store, M)).astype(np.uint8)      # same table on every rank
+        vals = rs.randint(0, 1000, size=n_store).astype(np.int32)
+        shard = Shard(n_store, world, rank)
+        lo, hi = shard.row0, shard.row0 + shard.n_local
+        my_codes, my_vals = codes[lo:hi], vals[lo:hi]
+
+        def gather_codes(rows):
+            r = rows.numpy()
+            ok = (r >= lo) & (r < hi)
+            assert ok.all() or ((r[~ok] < 0) | (r[~ok] >= n_store)).all(), "received a row this rank does not own"
+            out = np.zeros((len(r), M), np.uint8)
+            out[ok] = my_codes[r[ok] - lo]
+            return torch.from_numpy(out)
+
+        def gather_vals(rows):
+            r = rows.numpy()
+            ok = (r >= lo) & (r < hi)
+            out = np.full(len(r), -1, np.int32)
+            out[ok] = my_vals[r[ok] - lo]
+            return torch.from_numpy(out)
+
+        rs2 = np.random.RandomState(100 + rank)                              # different requests per rank
+        ids = rs2.randint(0, n_store, size=(7, 5)).astype(np.int64)
+        ids[0, 0], ids[1, 1], ids[2, 2], ids[3, :] = -1, 0, n_store - 1, -1
+        for left, right in [(0, 0), (2, 2), (1, 0)]:
+            rows = slot_rows(torch.from_numpy(ids), left, right, n_store)
+            ref_rows, ref_valid = og.slot_layout(ids, n_store, left, right)
+            assert np.array_equal(rows.numpy(), ref_rows.reshape(-1))
+            got = exchange_fetch(rows, shard, gather_codes).numpy()
+            v = ref_valid.reshape(-1)
+            assert np.array_equal(got[v], codes[ref_rows.reshape(-1)[v]]) and not got[~v].any()
+        knn = rs2.randint(0, n_store, size=(6, 9)).astype(np.int64)
+        knn[0, -2:] = -1
+        rows = torch.from_numpy(np.where(knn < 0, knn + n_store, knn).reshape(-1))
+        got = exchange_fetch(rows, shard, gather_vals).numpy().reshape(knn.shape)
+        assert np.array_equal(got, vals[knn])                                # numpy wrap of -1 included
+        # ragged / empty requests
+        empty = exchange_fetch(torch.zeros(0, dtype=torch.int64), shard, gather_vals)
+        assert empty.numel() == 0
+        # final reduction of (score_sum, count) as the eval driver does it
+        t = torch.tensor([float(rank + 1), 10.0 * (rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        assert t.tolist() == [sum(range(1, world + 1)), 10.0 * sum(range(1, world + 1))]
+        q.put((rank, "ok"))
+    except Exception as e:                                                   # pragma: no cover
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_store", [(2, 1001), (3, 50)])
+def test_exchange_fetch_gloo(world, n_store):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_store, 8, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_shard_geometry():
+    for n, w in [(10, 3), (103227021, 8), (5, 8)]:
+        tot = 0
+        for r in range(w):
+            s = Shard(n, w, r)
+            assert s.row0 == min(r * s.per, n)
+            tot += s.n_local
+        assert tot == n
+    s = Shard(100, 4, 1)
+    rows = torch.tensor([-1, 0, 24, 25, 49, 50, 99, 100, 1000])
+    assert s.owner(rows).tolist() == [1, 0, 0, 1, 1, 2, 3, 1, 1]
