@@ -278,7 +278,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
 }
 
 struct AsmBufs {
-    float *head_logits, *head_lse, *head_picked, *xi, *tail_logits, *tail_lse, *tail_picked;
+    float *head_part, *head_lse, *head_picked, *xi, *tail_part, *tail_lse, *tail_picked;
     int32_t *head_pick, *band_rows, *band_pick, *band_count;
 };
 
@@ -290,7 +290,7 @@ void carve_asm(const gnnlm_adaptive_softmax_t& w, int64_t n, Carver& c, AsmBufs&
         max_size = std::max<int64_t>(max_size, w.cutoff[i] - w.cutoff[i - 1]);
         max_dim = std::max<int64_t>(max_dim, w.dim[i]);
     }
-    b.head_logits = c.take<float>(n * head_n);
+    b.head_part = c.take<float>(n * 4 * cdiv(head_n, 128));
     b.head_lse = c.take<float>(n);
     b.head_picked = c.take<float>(n);
     b.head_pick = c.take<int32_t>(n);
@@ -298,7 +298,7 @@ void carve_asm(const gnnlm_adaptive_softmax_t& w, int64_t n, Carver& c, AsmBufs&
     b.band_pick = c.take<int32_t>(std::max(nt, 1) * n);
     b.band_count = c.take<int32_t>(8);
     b.xi = c.take<float>(n * max_dim);
-    b.tail_logits = c.take<float>(n * max_size);
+    b.tail_part = c.take<float>(n * 4 * cdiv(std::max<int64_t>(max_size, 1), 128));
     b.tail_lse = c.take<float>(n);
     b.tail_picked = c.take<float>(n);
 }
@@ -324,11 +324,12 @@ int adaptive_impl(const gnnlm_adaptive_softmax_t& w, const float* x, int64_t ldx
 
     {   // head: [E_0 ; class_proj] (adaptive_softmax.py:24-47,184-188)
         GemmParams g{};
-        g.A = x; g.lda = ldx; g.W = w.head_w; g.ldw = w.d; g.C = b.head_logits; g.ldc = head_n;
+        g.A = x; g.lda = ldx; g.W = w.head_w; g.ldw = w.d;
+        g.lse_part = b.head_part; g.lse_pick = b.head_pick; g.lse_picked = b.head_picked;
         g.M = (int)n; g.N = head_n; g.K = w.d;
-        TRY(gemm_nt(g, s));
+        TRY(gemm_nt(g, s));     // logits are reduced in the epilogue, never written
     }
-    TRY(row_lse_pick(b.head_logits, head_n, n, nullptr, head_n, b.head_pick, b.head_lse, b.head_picked, s));
+    TRY(lse_reduce(b.head_part, 2 * (int)cdiv(head_n, 128), n, nullptr, b.head_lse, s));
     TRY(head_logp(b.head_picked, b.head_lse, lm_logp, n, s));
 
     for (int i = 1; i < w.n_bands; ++i) {   // tails (adaptive_softmax.py:91-115,199-203), target rows only
@@ -342,10 +343,11 @@ int adaptive_impl(const gnnlm_adaptive_softmax_t& w, const float* x, int64_t ldx
         g.M = (int)n; g.N = w.dim[i]; g.K = w.d; g.m_dev = cnt;
         TRY(gemm_nt(g, s));
         GemmParams t{};
-        t.A = b.xi; t.lda = w.dim[i]; t.W = w.emb[i]; t.ldw = w.dim[i]; t.C = b.tail_logits; t.ldc = size;
+        t.A = b.xi; t.lda = w.dim[i]; t.W = w.emb[i]; t.ldw = w.dim[i];
+        t.lse_part = b.tail_part; t.lse_pick = pick; t.lse_picked = b.tail_picked;
         t.M = (int)n; t.N = size; t.K = w.dim[i]; t.m_dev = cnt;
         TRY(gemm_nt(t, s));
-        TRY(row_lse_pick(b.tail_logits, size, n, cnt, size, pick, b.tail_lse, b.tail_picked, s));
+        TRY(lse_reduce(b.tail_part, 2 * (int)cdiv(size, 128), n, cnt, b.tail_lse, s));
         TRY(tail_combine(b.tail_picked, b.tail_lse, rows, cnt, n, lm_logp, s));
     }
     return OK;
@@ -385,6 +387,9 @@ size_t gnnlm_sizeof(const char* name) {
     }
 
 int gnnlm_gemm_nt(const gnnlm_gemm_t* d, void* stream) { GNNLM_DESC(d); return gemm_nt(*d, (hipStream_t)stream); }
+int gnnlm_lse_reduce(const float* part, int32_t n_parts, int64_t rows, const int32_t* m_dev, float* lse, void* stream) {
+    return lse_reduce(part, n_parts, rows, m_dev, lse, (hipStream_t)stream);
+}
 int gnnlm_pq_gather_decode(const gnnlm_gather_t* d, void* stream) { GNNLM_DESC(d); return gather_decode(*d, (hipStream_t)stream); }
 int gnnlm_star_attn(const gnnlm_star_attn_t* d, void* stream) { GNNLM_DESC(d); return star_attn(*d, (hipStream_t)stream); }
 int gnnlm_chain_attn(const gnnlm_chain_attn_t* d, void* stream) { GNNLM_DESC(d); return chain_attn(*d, (hipStream_t)stream); }

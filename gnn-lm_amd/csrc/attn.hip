@@ -48,47 +48,68 @@ __device__ __forceinline__ float reduce8(const float (&v)[HB], int lane) {
     return r;
 }
 
-// One workgroup (4 waves) per token.  QPL = float4 chunks of the feature row held per lane.
+// One workgroup (4 waves) per token.  QPL = float4 chunks of the feature row held per lane: lane l owns
+// the contiguous floats [16*QPL*l/4 ...), i.e. (for dsub = 8, QPL = 4) the two sub-quantizers 2l, 2l+1.
+// The token's kg code rows (kg x M bytes = 16 KiB at 128 x 128) are staged into LDS once with
+// coalesced 16-B loads -- one full 128-B line per neighbour, the only HBM traffic of the kernel --
+// so the per-neighbour dependent chain is LDS byte -> L2 centroid gather, and two neighbours are in
+// flight per wave to cover the L2 latency.
 template <int QPL>
 __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sc = smem;                               // [HB][kg] scores, then alphas
     float* zred = smem + HB * p.kg;                 // [HB][D]  cross-wave reduction of Z
+    int* okf = reinterpret_cast<int*>(zred + HB * p.D);          // [kg] neighbour validity
+    uint8_t* lcodes = reinterpret_cast<uint8_t*>(okf + ((p.kg + 3) & ~3));   // [kg][M] (PQ source only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x;
-    const int D = p.D, kg = p.kg, nq = D / 4;
+    const int D = p.D, kg = p.kg, nq = D / 4, M = p.M;
     const int64_t* ids = p.ids + (int64_t)i * kg;
     const int q_per_m = p.codes ? p.dsub / 4 : 1;
 
-    auto load_x = [&](int j, float4 (&x)[QPL]) -> bool {
-        const int64_t id = ids[j];
-        if (id < 0) return false;
-        if (p.codes) {
-            const int64_t lrow = p.codes_direct ? ((int64_t)i * kg + j) * p.codes_direct : id - p.row0;
-            const uint8_t* crow = p.codes + lrow * p.M;
+    for (int j = tid; j < kg; j += 256) okf[j] = ids[j] >= 0;
+    if (p.codes) {
+        if ((M & 15) == 0) {
+            const int per_row = M >> 4;
+            for (int e = tid; e < kg * per_row; e += 256) {
+                const int j = e / per_row, part = e - j * per_row;
+                const int64_t id = ids[j];
+                const int64_t lrow = p.codes_direct ? ((int64_t)i * kg + j) * p.codes_direct : id - p.row0;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (id >= 0) v = *reinterpret_cast<const uint4*>(p.codes + lrow * M + 16 * part);
+                *reinterpret_cast<uint4*>(lcodes + j * M + 16 * part) = v;
+            }
+        } else {
+            for (int e = tid; e < kg * M; e += 256) {
+                const int j = e / M, m = e - j * M;
+                const int64_t id = ids[j];
+                const int64_t lrow = p.codes_direct ? ((int64_t)i * kg + j) * p.codes_direct : id - p.row0;
+                lcodes[e] = id >= 0 ? p.codes[lrow * M + m] : 0;
+            }
+        }
+    }
+    __syncthreads();
+
+    // x_j chunk of this lane (zero for invalid neighbours / lanes beyond D)
+    auto load_x = [&](int j, float4 (&x)[QPL]) {
+        const bool ok = j < kg && okf[j];
 #pragma unroll
-            for (int t = 0; t < QPL; ++t) {
-                const int q = lane + 64 * t;
-                x[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (q < nq) {
+        for (int t = 0; t < QPL; ++t) {
+            const int q = QPL * lane + t;
+            x[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && q < nq) {
+                if (p.codes) {
                     const int m = q / q_per_m;
                     const int within = (q - m * q_per_m) * 4;
                     x[t] = *reinterpret_cast<const float4*>(
-                        p.centroids + ((int64_t)(m * 256 + crow[m])) * p.dsub + within);
+                        p.centroids + ((int64_t)(m * 256 + lcodes[j * M + m])) * p.dsub + within);
+                } else {
+                    x[t] = *reinterpret_cast<const float4*>(p.X + ((int64_t)i * kg + j) * p.x_group_stride * p.ldx + 4 * q);
                 }
             }
-        } else {
-            const float* xr = p.X + ((int64_t)i * kg + j) * p.x_group_stride * p.ldx;
-#pragma unroll
-            for (int t = 0; t < QPL; ++t) {
-                const int q = lane + 64 * t;
-                x[t] = q < nq ? *reinterpret_cast<const float4*>(xr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
         }
-        return true;
     };
 
-    int n_valid_total = 0;
     for (int h0 = 0; h0 < p.H; h0 += HB) {
         // ---- pass 1: scores s[h][j] = x_j . U[i,h,:]
         {
@@ -97,29 +118,34 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
             for (int h = 0; h < HB; ++h)
 #pragma unroll
                 for (int t = 0; t < QPL; ++t) {
-                    const int q = lane + 64 * t;
+                    const int q = QPL * lane + t;
                     u[h][t] = (h0 + h < p.H && q < nq)
                                   ? *reinterpret_cast<const float4*>(p.U + ((int64_t)i * p.H + h0 + h) * D + 4 * q)
                                   : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-            for (int j = wave; j < kg; j += 4) {
-                float4 x[QPL];
-                const bool ok = load_x(j, x);       // wave-uniform
-                float part[HB];
+            for (int j = wave; j < kg; j += 8) {
+                float4 xa[QPL], xb[QPL];
+                load_x(j, xa);
+                load_x(j + 4, xb);
+                float pa[HB], pb[HB];
 #pragma unroll
                 for (int h = 0; h < HB; ++h) {
-                    float a = 0.f;
+                    float a = 0.f, b = 0.f;
 #pragma unroll
                     for (int t = 0; t < QPL; ++t) {
-                        a = fmaf(x[t].x, u[h][t].x, a);
-                        a = fmaf(x[t].y, u[h][t].y, a);
-                        a = fmaf(x[t].z, u[h][t].z, a);
-                        a = fmaf(x[t].w, u[h][t].w, a);
+                        a = fmaf(xa[t].x, u[h][t].x, a); b = fmaf(xb[t].x, u[h][t].x, b);
+                        a = fmaf(xa[t].y, u[h][t].y, a); b = fmaf(xb[t].y, u[h][t].y, b);
+                        a = fmaf(xa[t].z, u[h][t].z, a); b = fmaf(xb[t].z, u[h][t].z, b);
+                        a = fmaf(xa[t].w, u[h][t].w, a); b = fmaf(xb[t].w, u[h][t].w, b);
                     }
-                    part[h] = a;
+                    pa[h] = a;
+                    pb[h] = b;
                 }
-                const float tot = reduce8(part, lane);
-                if ((lane & 7) == 0) sc[(lane >> 3) * kg + j] = ok ? tot : -INFINITY;
+                const float ta = reduce8(pa, lane), tb = reduce8(pb, lane);
+                if ((lane & 7) == 0) {
+                    sc[(lane >> 3) * kg + j] = okf[j] ? ta : -INFINITY;
+                    if (j + 4 < kg) sc[(lane >> 3) * kg + j + 4] = okf[j + 4] ? tb : -INFINITY;
+                }
             }
         }
         __syncthreads();
@@ -147,25 +173,28 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
             }
         }
         __syncthreads();
-        // ---- pass 2: Z[h,:] = sum_j alpha[h][j] x_j
+        // ---- pass 2: Z[h,:] = sum_j alpha[h][j] x_j   (alpha = 0 and x = 0 for invalid neighbours)
         {
             float4 z[HB][QPL];
 #pragma unroll
             for (int h = 0; h < HB; ++h)
 #pragma unroll
                 for (int t = 0; t < QPL; ++t) z[h][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int j = wave; j < kg; j += 4) {
-                float4 x[QPL];
-                if (!load_x(j, x)) continue;
+            for (int j = wave; j < kg; j += 8) {
+                float4 xa[QPL], xb[QPL];
+                load_x(j, xa);
+                load_x(j + 4, xb);
+                const bool hb = j + 4 < kg;
 #pragma unroll
                 for (int h = 0; h < HB; ++h) {
                     const float a = sc[h * kg + j];
+                    const float b = hb ? sc[h * kg + j + 4] : 0.f;
 #pragma unroll
                     for (int t = 0; t < QPL; ++t) {
-                        z[h][t].x = fmaf(a, x[t].x, z[h][t].x);
-                        z[h][t].y = fmaf(a, x[t].y, z[h][t].y);
-                        z[h][t].z = fmaf(a, x[t].z, z[h][t].z);
-                        z[h][t].w = fmaf(a, x[t].w, z[h][t].w);
+                        z[h][t].x = fmaf(a, xa[t].x, z[h][t].x); z[h][t].x = fmaf(b, xb[t].x, z[h][t].x);
+                        z[h][t].y = fmaf(a, xa[t].y, z[h][t].y); z[h][t].y = fmaf(b, xb[t].y, z[h][t].y);
+                        z[h][t].z = fmaf(a, xa[t].z, z[h][t].z); z[h][t].z = fmaf(b, xb[t].z, z[h][t].z);
+                        z[h][t].w = fmaf(a, xa[t].w, z[h][t].w); z[h][t].w = fmaf(b, xb[t].w, z[h][t].w);
                     }
                 }
             }
@@ -176,7 +205,7 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
                     for (int h = 0; h < HB; ++h)
 #pragma unroll
                         for (int t = 0; t < QPL; ++t) {
-                            const int q = lane + 64 * t;
+                            const int q = QPL * lane + t;
                             if (q < nq) {
                                 float4* dst = reinterpret_cast<float4*>(zred + h * D + 4 * q);
                                 if (w == 0) {
@@ -200,7 +229,6 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
         }
         __syncthreads();
     }
-    (void)n_valid_total;
 }
 
 constexpr int MAX_NG = 8;
@@ -320,7 +348,8 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
         GNNLM_REQUIRE(p.ldx % 4 == 0 && (uintptr_t)p.X % 16 == 0, "star_attn: X alignment");
     }
     if (p.T == 0) return OK;
-    const size_t shmem = (size_t)(HB * p.kg + HB * p.D) * sizeof(float);
+    const size_t shmem = (size_t)(HB * p.kg + HB * p.D + ((p.kg + 3) & ~3)) * sizeof(float) +
+                         (p.codes ? (((size_t)p.kg * p.M + 15) & ~size_t(15)) : 0);
     GNNLM_REQUIRE(shmem <= 160 * 1024, "star_attn: kg too large for LDS");
     const int nq = p.D / 4;
     const double rows = (double)p.T * p.kg;

@@ -13,6 +13,7 @@ typedef gnnlm_chain_attn_t ChainAttnParams;
 typedef gnnlm_knn_interp_t KnnInterpParams;
 
 int gemm_nt(const GemmParams& p, hipStream_t stream);
+int lse_reduce(const float* part, int n_parts, int64_t rows, const int32_t* m_dev, float* lse, hipStream_t stream);
 int gather_decode(const GatherParams& p, hipStream_t stream);
 int star_attn(const StarAttnParams& p, hipStream_t stream);
 int chain_attn(const ChainAttnParams& p, hipStream_t stream);

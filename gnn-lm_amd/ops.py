@@ -54,6 +54,32 @@ def gemm_nt(A, W, bias=None, residual=None, alpha=1.0, out=None, bias_mode=1, ga
     return out
 
 
+def gemm_lse(A, W, pick=None, alpha=1.0, m_dev=None):
+    """lse[r] = logsumexp_n(alpha * A[r] . W[n]) and picked[r] = alpha * A[r] . W[pick[r]], without
+    materialising the [M, N] logits (LSE epilogue of the GEMM + gnnlm_lse_reduce)."""
+    _f32(A), _f32(W)
+    _dev(A, W, pick, m_dev)
+    M, K = A.shape
+    N = W.shape[0]
+    n_parts = 2 * ((N + 127) // 128)
+    part = torch.empty(M, n_parts, 2, device=A.device, dtype=torch.float32)
+    lse = torch.empty(M, device=A.device, dtype=torch.float32)
+    picked = torch.zeros(M, device=A.device, dtype=torch.float32)
+    g = _lib.gnnlm_gemm_t()
+    g.A, g.lda, g.W, g.ldw = A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0)
+    g.lse_part = part.data_ptr()
+    if pick is not None:
+        assert pick.dtype == torch.int32
+        g.lse_pick, g.lse_picked = pick.data_ptr(), picked.data_ptr()
+    if m_dev is not None:
+        g.m_dev = m_dev.data_ptr()
+    g.alpha = alpha
+    g.M, g.N, g.K = M, N, K
+    call_desc("gnnlm_gemm_nt", g)
+    call("gnnlm_lse_reduce", ptr(part), n_parts, M, ptr(m_dev), ptr(lse), stream())
+    return lse, picked
+
+
 def pq_gather_decode(codes, centroids, ids, left=0, right=0, n_store=None, row0=0, vals=None,
                      want_x=True, want_codes=False, want_labels=False, want_valid=True):
     """Gather + decode the slots of each centre row in ``ids`` (flattened).  Returns a dict."""

@@ -64,8 +64,17 @@ typedef struct gnnlm_gemm {
     int32_t batch1, batch2;    /* 0 is read as 1; batch index (b1, b2) */
     int64_t sA1, sA2, sW1, sW2, sC1, sC2, sB1, sB2, sR1, sR2;   /* batch strides in elements */
     int32_t precision;         /* 0: f32 MFMA */
+    int32_t tile_order;        /* 0: auto (consecutive tiles share the larger operand's panel), 1: n fastest, 2: m fastest */
+    /* log-sum-exp epilogue (C may be NULL): instead of storing C, every (row, 64-column slab) writes a
+     * (max, sum exp(x - max)) pair to lse_part[row][slab], slab count = 2*ceil(N/128); lse_picked[row] =
+     * alpha * (A.W^T)[row, lse_pick[row]].  Finish with gnnlm_lse_reduce.  batch must be 1. */
+    float* lse_part;           /* [M, 2*ceil(N/128), 2] */
+    const int32_t* lse_pick;   /* optional [M] */
+    float* lse_picked;         /* [M] (with lse_pick) */
 } gnnlm_gemm_t;
 int gnnlm_gemm_nt(const gnnlm_gemm_t* desc, void* stream);
+/* lse[row] = log sum exp over the row, from the partial pairs of the LSE epilogue */
+int gnnlm_lse_reduce(const float* part, int32_t n_parts, int64_t rows, const int32_t* m_dev, float* lse, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PQ datastore row gather + decode (HBM-resident store).

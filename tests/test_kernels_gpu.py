@@ -83,6 +83,21 @@ def test_gemm_options(ops, dev):
     assert (out.double() - big.cpu().double()[:, :64] @ W.cpu().double().t()).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(5, 7, 8), (300, 20002, 64), (129, 1000, 256), (64, 128, 32)])
+def test_gemm_lse_epilogue(ops, dev, M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    pick = torch.randint(0, N, (M,), generator=g, dtype=torch.int32)
+    logits = 0.3 * (A.double() @ W.double().t())
+    lse, picked = ops.gemm_lse(A.to(dev), W.to(dev), pick.to(dev), alpha=0.3)
+    assert (lse.cpu().double() - torch.logsumexp(logits, 1)).abs().max() < 2e-5
+    assert (picked.cpu().double() - logits.gather(1, pick.long()[:, None])[:, 0]).abs().max() < 2e-5
+    m_dev = torch.tensor([M // 2], dtype=torch.int32, device=dev)
+    lse2, _ = ops.gemm_lse(A.to(dev), W.to(dev), pick.to(dev), alpha=0.3, m_dev=m_dev)
+    assert torch.equal(lse2[: M // 2], lse[: M // 2])
+
+
 def test_gemm_errors(ops, dev):
     from gnnlm_amd._lib import GnnlmError
     A = torch.randn(4, 6, device=dev)
