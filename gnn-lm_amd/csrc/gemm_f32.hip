@@ -51,13 +51,17 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmParams p) {
     int M = p.M;
     if (p.m_dev) M = min(M, *p.m_dev);
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    // Tile walk.  Host-known M: one tile per workgroup (XCD-chunked list).  Device-side M: the grid
+    // is a fixed pool of workgroups striding over the REAL tiles only -- launching one workgroup per
+    // worst-case tile costs ~10 ns of dispatch each, 3x the useful work on the 207,744-word tail band.
+    const int tiles_m = ((p.m_dev ? M : p.M) + BM - 1) / BM;
+    const unsigned n_tiles = (unsigned)(tiles_m * tiles_n);
+    const unsigned t_step = p.m_dev ? gridDim.x : n_tiles;
+    for (unsigned t = p.m_dev ? blockIdx.x : xcd_remap(blockIdx.x, n_tiles); t < n_tiles; t += t_step) {
     int tm, tn;
-    if (p.tile_order == 1) { tm = tile / tiles_n; tn = tile % tiles_n; }      // n fastest
-    else                   { tn = tile / tiles_m; tm = tile % tiles_m; }      // m fastest
+    if (p.tile_order == 1) { tm = t / tiles_n; tn = t % tiles_n; }      // n fastest
+    else                   { tn = t / tiles_m; tm = t % tiles_m; }      // m fastest
     const int m0 = tm * BM, n0 = tn * BN;
-    if (m0 >= M) return;
 
     const int b1 = blockIdx.y / p.batch2, b2 = blockIdx.y % p.batch2;
     const float* A = p.A + b1 * p.sA1 + b2 * p.sA2;
@@ -207,6 +211,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmParams p) {
                 }
             }
     }
+    __syncthreads();          // the next tile's prologue overwrites LDS buffer 0
+    }   // tile walk
 }
 
 // lse[row] = log sum exp over the row's partial (max, sum) pairs
@@ -261,7 +267,7 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     GNNLM_REQUIRE(tiles < (1ll << 31) && nb < 65536, "gemm: grid too large");
     if (p.tile_order == 0)      // share the larger operand's panel between consecutive tiles
         p.tile_order = (!p.m_dev && (double)p.M > (double)p.N) ? 1 : 2;
-    dim3 grid((unsigned)tiles, (unsigned)nb);
+    dim3 grid((unsigned)(p.m_dev ? std::min<int64_t>(tiles, 1024) : tiles), (unsigned)nb);
     const double work = 2.0 * p.M * (double)p.N * p.K * nb;
     ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N) * nb,
                    p.m_dev, (double)p.M);
