@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""``eval_lm`` -- the driver of the GNN+kNN eval path, mirror of ``fairseq_cli/eval_lm.py:61-336``
+for ``--graph --use-precompute-feat [--knnlm]`` with the reference's flag names
+(fairseq/options.py:472-501, fairseq/tasks/language_modeling.py:97-153,
+fairseq/models/transformer_lm.py:122-139; recipe values: gnnlm_scripts/wiki103/hgt_lm_wiki103_reproduce.sh:81-89,140-150).
+
+    python -m gnnlm_amd.eval_lm DATA --path CKPT --gen-subset test --graph --neighbor-context 2 --gcn-k 128 \\
+        --use-precompute-feat --sample-break-mode none --max-tokens 256 --tokens-per-sample 256 \\
+        --gcn-context-window 0 --knn-keytype gcn_feat \\
+        [--knnlm --k 1024 --lmbda 0.25 --dstore-dir DATA/train_dstore --index-file ... --temperature 0.01 \\
+         --knn-sim-func do_not_recomp_ip]
+
+What is NOT rebuilt (out of scope): the fairseq task/dataset/checkpoint machinery.
+The driver reads the data directory's own files instead: targets are ``{split}_dstore/vals.npy`` (the
+same tokens in the same order, eval_lm.py:238-242), features ``{split}_dstore/keys.npy``, graph
+neighbours ``neighbors.mmap.{gcn_k}``, PQ codes ``train_dstore/quantized-keys.npy``; blocks follow
+``--sample-break-mode none`` (token_block_utils_fast.pyx:22-35).  Every table is uploaded to HBM once.
+Output: the reference's two final lines (eval_lm.py:325-331).
+"""
+import argparse
+import ast
+import json
+import logging
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .data_store import DataStore, vals_dtype
+from .hgt import NeighborGraph
+from .knn_model import KNNModel
+from .model import GnnLmModel
+from .path_utils import dstore_path, feature_path, neighbor_path, quantized_feature_path, value_path
+from .sequence_scorer import SequenceScorer
+
+logger = logging.getLogger("gnnlm_amd.eval_lm")
+
+
+def get_parser():
+    p = argparse.ArgumentParser("gnnlm-eval-lm")
+    p.add_argument("data")
+    p.add_argument("--path", required=True, help="checkpoint ({'args','model'} torch pickle)")
+    p.add_argument("--gen-subset", default="test")
+    p.add_argument("--task", default="language_modeling")
+    p.add_argument("--graph", action="store_true", default=False)
+    p.add_argument("--neighbor-context", default="(2, 2)")
+    p.add_argument("--use-precompute-feat", action="store_true", default=False)
+    p.add_argument("--invalid-neighbor-context", default=1536, type=int)
+    p.add_argument("--gcn-k", default=1024, type=int)
+    p.add_argument("--gcn-context-window", default=0, type=int)
+    p.add_argument("--intra-context", default=0, type=int)
+    p.add_argument("--sample-break-mode", default="none")
+    p.add_argument("--tokens-per-sample", default=1024, type=int)
+    p.add_argument("--max-tokens", default=None, type=int)
+    p.add_argument("--max-sentences", default=None, type=int)
+    p.add_argument("--softmax-batch", default=sys.maxsize, type=int)
+    p.add_argument("--context-window", default=0, type=int)
+    p.add_argument("--model-overrides", default="{}")
+    p.add_argument("--knn-keytype", default=None)
+    p.add_argument("--knnlm", action="store_true")
+    p.add_argument("--k", default=1024, type=int)
+    p.add_argument("--probe", default=8, type=int)
+    p.add_argument("--lmbda", default=0.0, type=float)
+    p.add_argument("--dstore-dir", default=None)
+    p.add_argument("--index-file", default=None)
+    p.add_argument("--temperature", default=1.0, type=float)
+    p.add_argument("--knn-sim-func", default="do_not_recomp_ip")
+    p.add_argument("--first", default=0, type=int)
+    p.add_argument("--num-shards", default=1, type=int)
+    p.add_argument("--shard-id", default=0, type=int)
+    p.add_argument("--fp16", action="store_true")
+    p.add_argument("--cpu", action="store_true")
+    p.add_argument("--save-knnlm-dstore", action="store_true")
+    p.add_argument("--output-word-probs", action="store_true")
+    p.add_argument("--output-word-stats", action="store_true")
+    p.add_argument("--output-knn-recall", action="store_true")
+    p.add_argument("--log-format", default=None)
+    p.add_argument("--device", default="cuda:0")
+    return p
+
+
+class _Dict:
+    """pad/eos ids of a fairseq Dictionary (fairseq/data/dictionary.py: bos=0, pad=1, eos=2, unk=3)."""
+
+    def pad(self):
+        return 1
+
+    def eos(self):
+        return 2
+
+
+def block_ranges(n_tokens, block, context_window=0):
+    """(context_start, start, end) of every block under --sample-break-mode none
+    (token_block_utils_fast.pyx:22-35) with the --gcn-context-window prefix of
+    GraphTokenBlockDataset.get_basic_info (token_block_dataset.py:246-285)."""
+    out = []
+    for s in range(0, n_tokens, block):
+        e = min(n_tokens, s + block)
+        out.append((max(0, s - context_window) if s > 0 else s, s, e))
+    return out
+
+
+def load_tables(args, device):
+    split, data = args.gen_subset, args.data
+    info = json.load(open(os.path.join(dstore_path(data, split), "info.json")))
+    tinfo = json.load(open(os.path.join(dstore_path(data, "train"), "info.json")))        # language_modeling.py:266-272
+    n_tok, d = info["dstore_size"], info["hidden_size"]
+    if not os.path.exists(feature_path(data, split)):
+        raise FileNotFoundError("Dataset not found: {} ({})".format(split, feature_path(data, split)))
+    feats = np.memmap(feature_path(data, split), mode="r", shape=(n_tok, d),
+                      dtype=np.float16 if info["dstore_fp16"] else np.float32)
+    targets = np.memmap(value_path(data, split), mode="r", shape=(n_tok,),
+                        dtype=vals_dtype(info["dstore_fp16"], info.get("vocab_size")))
+    nbrs = np.memmap(neighbor_path(data, split, args.gcn_k), mode="r", dtype=np.int64, shape=(n_tok, args.gcn_k))
+    codes = np.load(quantized_feature_path(data, "train"), mmap_mode="r")                  # language_modeling.py:274-276
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return {"n_tok": n_tok, "d": d, "vocab": info.get("vocab_size"), "n_store": tinfo["dstore_size"],
+            "feats": up(feats), "targets": up(targets).long(), "nbrs": up(nbrs), "codes": up(codes)}
+
+
+def main(args):
+    if args.cpu or not torch.cuda.is_available():
+        raise RuntimeError("gnnlm_amd.eval_lm needs an MI355X: the product path has no CPU fallback")
+    if not (args.graph and args.use_precompute_feat):
+        raise NotImplementedError("only the --graph --use-precompute-feat eval path is built (the base LM is out of scope)")
+    if args.save_knnlm_dstore:
+        raise NotImplementedError("--save-knnlm-dstore needs the base LM forward (SURVEY.md 8f.4)")
+    if args.knnlm and args.save_knnlm_dstore:
+        raise ValueError("Cannot use knnlm while trying to build the datastore!")
+    if args.fp16:
+        logger.warning("--fp16 ignored: the HIP path computes in float32")
+    device = torch.device(args.device)
+    torch.cuda.set_device(device)
+    tabs = load_tables(args, device)
+    overrides = ast.literal_eval(args.model_overrides)
+    model, margs = GnnLmModel.from_checkpoint(args.path, device, overrides, vocab_size=tabs["vocab"])
+    nc = ast.literal_eval(str(args.neighbor_context))                                      # language_modeling.py:295
+    left, right = (nc, nc) if isinstance(nc, int) else nc
+    store = model.make_store(tabs["codes"], tabs["n_store"], device)
+    T = args.tokens_per_sample - args.context_window
+    blocks = block_ranges(tabs["n_tok"], T, args.gcn_context_window)
+    if args.first > 0:
+        blocks = blocks[:args.first]
+    blocks = blocks[args.shard_id::args.num_shards]                                        # eval_lm.py:131-132
+    per_batch = max(1, (args.max_tokens or 36000) // max(1, T + args.gcn_context_window))
+    if args.max_sentences:
+        per_batch = min(per_batch, args.max_sentences)
+    scorer = SequenceScorer(_Dict(), args.softmax_batch, args=args)
+    knn_dstore = None
+    if args.knnlm:
+        knn_dstore = KNNModel(index_file=args.index_file, dstore_dir=args.dstore_dir, cuda=-1, k=args.k,
+                              no_load_keys=("do_not_recomp" in args.knn_sim_func), use_memory=True,
+                              metric_type=args.knn_sim_func, device=device) if not getattr(args, "knn_model", None) \
+            else args.knn_model
+    acc = torch.zeros(1, device=device, dtype=torch.float64)
+    count, gen_time, ntok = 0, 0.0, 0
+    i = 0
+    while i < len(blocks):
+        group = [blocks[i]]
+        while len(group) < per_batch and i + len(group) < len(blocks) and \
+                (blocks[i + len(group)][2] - blocks[i + len(group)][0]) == (group[0][2] - group[0][0]):
+            group.append(blocks[i + len(group)])
+        i += len(group)
+        L = group[0][2] - group[0][0]
+        idx = torch.cat([torch.arange(c, e, device=device) for c, _, e in group])
+        target = tabs["targets"][idx].view(len(group), L)
+        graph = NeighborGraph(ids=tabs["nbrs"][idx].contiguous(), n_blocks=len(group), T=L, left=left, right=right,
+                              store=store, tgt_h=tabs["feats"][idx].contiguous(), max_intra_context=args.intra_context)
+        sample = {"id": torch.arange(len(group)), "nsentences": len(group), "ntokens": len(group) * L,
+                  "net_input": {"src_tokens": target, "src_lengths": torch.full((len(group),), L), "graph": graph},
+                  "target": target, "start_indices": [s - c for c, s, _ in group]}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()                                                            # gen_timer (eval_lm.py:214-219)
+        hypos = scorer.generate([model], sample, knn_dstore=knn_dstore, temperature=args.temperature) if args.knnlm \
+            else scorer.generate([model], sample)
+        torch.cuda.synchronize()
+        gen_time += time.perf_counter() - t0
+        ntok += sample["ntokens"]
+        for h in hypos:
+            pos = h[0]["positional_scores"].float().contiguous()
+            ops.masked_sum_f64(pos, None, acc)                                              # score_sum (:273), in f64
+            count += pos.numel()                                                            # :274
+    score_sum = acc.item()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        t = torch.tensor([score_sum, float(count)], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t)
+        score_sum, count = t[0].item(), int(t[1].item())
+    avg_nll_loss = -score_sum / count / math.log(2)
+    line1 = "Evaluated {} tokens in {:.1f}s ({:.2f} tokens/s)".format(ntok, gen_time, ntok / max(gen_time, 1e-9))
+    line2 = "Loss (base 2): {:.4f}, Perplexity: {:.2f}".format(avg_nll_loss, 2 ** avg_nll_loss)
+    logger.info(line1)
+    logger.info(line2)
+    print(line1)
+    print(line2)
+    return {"score_sum": score_sum, "count": count, "ppl": 2 ** avg_nll_loss, "tokens": ntok, "seconds": gen_time}
+
+
+def cli_main(argv=None):
+    logging.basicConfig(level=logging.INFO, stream=sys.stderr)
+    return main(get_parser().parse_args(argv))
+
+
+if __name__ == "__main__":
+    cli_main()

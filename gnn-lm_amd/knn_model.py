@@ -1,0 +1,183 @@
+"""``KNNModel`` -- mirror of ``knn/knn_model.py:25-217``: kNN-LM probabilities from a datastore.
+
+Same constructor arguments, attributes and ``get_knns`` / ``get_knn_prob`` contracts.  Differences:
+  * faiss is optional.  ``index_file`` is opened with faiss when it is importable; otherwise pass
+    ``index=`` (any object with ``search(queries_f32, k) -> (dists, ids)``, faiss's contract) or let the
+    model build an :class:`ExactIndex` (exact search on the GPU; NOT the reference's approximate
+    ``OPQ64_1024,IVF4096,PQ64`` index -- ANN results / ADC distances are parity-unpinned).
+  * the label table lives in HBM and the mask / distance-softmax / target-match / recall arithmetic
+    (knn_model.py:192-217) is one HIP kernel; ``interpolate`` additionally fuses
+    ``log(p + 1e-10)`` and the log-space mix of ``sequence_scorer.py:55-68,121``.
+  * "cosine" behaviour is keyed off the index file NAME exactly like the reference (:172,181).
+"""
+import logging
+import os
+from time import time
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .data_store import DataStore
+
+LOGGING = logging.getLogger(__name__)
+
+
+class ExactIndex:
+    """Exact top-k search on the device with faiss's ``search`` contract (IP: larger = closer, returned
+    descending; L2: squared distances ascending).  The similarity matrix runs on the f32 MFMA GEMM."""
+
+    def __init__(self, keys, metric="ip", cosine=False, device="cuda"):
+        k = torch.as_tensor(np.asarray(keys)).to(device, torch.float32)
+        if cosine:
+            k = k / (k ** 2).sum(-1, keepdim=True).sqrt()                 # index_builder.py:90-95,118
+        self.keys, self.metric = k.contiguous(), metric
+        self.ntotal = k.shape[0]
+
+    def search_device(self, q, k):
+        q = q.to(self.keys.device, torch.float32).contiguous()
+        ip = ops.gemm_nt(q, self.keys)
+        if self.metric == "ip":
+            d, i = torch.topk(ip, min(k, self.ntotal), dim=1, largest=True, sorted=True)
+        else:
+            l2 = (q ** 2).sum(-1, keepdim=True) + (self.keys ** 2).sum(-1)[None, :] - 2 * ip
+            d, i = torch.topk(l2, min(k, self.ntotal), dim=1, largest=False, sorted=True)
+        if i.shape[1] < k:                                               # faiss pads with -1
+            pad = k - i.shape[1]
+            i = torch.nn.functional.pad(i, (0, pad), value=-1)
+            d = torch.nn.functional.pad(d, (0, pad), value=float("-inf") if self.metric == "ip" else float("inf"))
+        return d, i
+
+    def search(self, queries, k):
+        d, i = self.search_device(torch.as_tensor(np.asarray(queries)), k)
+        return d.cpu().numpy(), i.cpu().numpy()
+
+
+class KNNModel(object):
+    def __init__(self, index_file, dstore_dir, probe: int = 32, no_load_keys: bool = False,
+                 metric_type: str = "do_not_recomp_ip", sim_func: str = None, k: int = 1024, cuda: int = -1,
+                 use_memory=False, efsearch=8, index=None, device=None):
+        self.index_file, self.dstore_dir = index_file or "", dstore_dir
+        self.probe, self.efsearch = probe, efsearch
+        self.no_load_keys, self.use_memory = no_load_keys, use_memory
+        if not os.path.exists(dstore_dir):
+            raise ValueError(f"Dstore path not found: {dstore_dir}")                     # knn_model.py:74
+        t = time()
+        self.data_store = DataStore.from_pretrained(dstore_dir=dstore_dir, use_memory=use_memory,
+                                                    no_load_keys=no_load_keys)
+        LOGGING.info(f"Reading datastore took {time() - t} s")
+        self.dstore_size, self.hidden_size = self.data_store.dstore_size, self.data_store.hidden_size
+        self.vocab_size, self.dstore_fp16 = self.data_store.vocab_size, self.data_store.dstore_fp16
+        self.vals = self.data_store.vals
+        if not no_load_keys:
+            self.keys = self.data_store.keys
+        self.k, self.metric_type, self.sim_func, self.cuda = k, metric_type, sim_func, cuda
+        assert self.metric_type in ["do_not_recomp_l2", "do_not_recomp_ip", "l2", "ip"]
+        self.device = torch.device(device if device is not None else "cuda")
+        self.index = index if index is not None else self.setup_faiss()
+        self._vals_dev = None
+
+    @property
+    def cosine(self):
+        return "cosine" in self.index_file
+
+    def setup_faiss(self):
+        """faiss index if faiss is importable, else an exact index over the keys (small stores)."""
+        try:
+            import faiss
+        except ImportError:
+            faiss = None
+        if faiss is not None and os.path.exists(self.index_file):
+            index = faiss.read_index(self.index_file, faiss.IO_FLAG_ONDISK_SAME_DIR)
+            try:
+                faiss.ParameterSpace().set_index_parameter(index, "nprobe", self.probe)
+                faiss.ParameterSpace().set_index_parameter(index, "quantizer_efSearch", self.efsearch)
+            except Exception:
+                LOGGING.warning(f"faiss index {self.index_file} does not have parameter nprobe or efSearch")
+            return index
+        if self.no_load_keys:
+            raise ValueError("faiss is not installed and the keys were not loaded: pass index=... "
+                             "(an object with faiss's search contract) or no_load_keys=False")
+        LOGGING.warning("faiss not available: exact search over %d keys on the GPU", self.dstore_size)
+        base = "l2" if self.metric_type.endswith("l2") else "ip"
+        return ExactIndex(self.keys, base, self.cosine, self.device)
+
+    def vals_device(self):
+        if self._vals_dev is None:
+            self._vals_dev = self.data_store.vals_to_device(self.device)
+        return self._vals_dev
+
+    # ------------------------------------------------------------------------------------------
+    def get_knns(self, queries, k: int = 0):
+        """-> (dists [num,k] f32, knns [num,k] i64) as numpy arrays (knn_model.py:87-101)."""
+        k = k or self.k
+        if isinstance(queries, torch.Tensor):
+            queries = queries.detach().cpu().float().data.numpy()
+        return self.index.search(queries.astype(np.float32), k)
+
+    def _search(self, knn_queries, k):
+        if hasattr(self.index, "search_device"):
+            return self.index.search_device(knn_queries, k)
+        d, i = self.get_knns(knn_queries, k)
+        return torch.from_numpy(d).to(self.device), torch.from_numpy(i).to(self.device)
+
+    def _sims(self, dists, knns, queries):
+        """sim_func dispatch of knn_model.py:137-177 (device tensors)."""
+        fn = self.metric_type
+        if fn == "do_not_recomp_l2":
+            return -1 * dists
+        if fn == "do_not_recomp_ip":
+            return dists
+        idx = knns.clamp(min=0)
+        if isinstance(self.keys, torch.Tensor):
+            vecs = self.keys[idx].float()
+        else:                                             # host memmap, as the reference (:163,170)
+            vecs = torch.from_numpy(np.asarray(self.keys)[idx.cpu().numpy()].astype(np.float32)).to(queries.device)
+            neg = (knns < 0).cpu().numpy()
+            if neg.any():                                 # numpy wraps -1 to the last row
+                vecs[knns < 0] = torch.from_numpy(np.asarray(self.keys[-1]).astype(np.float32)).to(queries.device)
+        if fn == "l2":
+            return -1 * torch.sum((queries[:, None, :] - vecs) ** 2, dim=2)
+        if fn == "ip":
+            if self.cosine:
+                vecs = vecs / (vecs ** 2).sum(-1, keepdims=True).sqrt()
+            return (vecs * queries[:, None, :]).sum(dim=-1)
+        raise ValueError("Invalid knn similarity function!")
+
+    def search_sims(self, queries, k=0):
+        """queries [n, d] (device) -> (sims [n,k] f32, knns [n,k] i64), before the -1 masking."""
+        k = k or self.k
+        q = queries.float()
+        if self.cosine:                                                                 # :181-184
+            q = q / (q ** 2).sum(-1, keepdims=True).sqrt()
+        dists, knns = self._search(q, k)
+        return self._sims(dists, knns, q).contiguous(), knns.contiguous()
+
+    def get_knn_prob(self, queries, k: int = 0, output_size: int = None, return_knn: bool = False, t: float = 1.0,
+                     targets: torch.Tensor = None, return_recall: bool = False):
+        """Return shapes as documented at knn_model.py:122-128."""
+        assert self.data_store.val_size == 1, "make sure self.data_store.val_size == 1 (which is labels)"
+        if not (output_size or self.vocab_size):
+            raise ValueError("DataStore.info does not have vocab_size, please set output_size manually")
+        if not queries.is_cuda:
+            raise _lib.GnnlmError("KNNModel.get_knn_prob runs on the GPU; there is no CPU fallback")
+        sims, knns = self.search_sims(queries, k)
+        vals = self.vals_device()
+        if targets is None:                     # dense [batch, V] variant: not on the eval path (torch ops)
+            masked = sims.masked_fill(knns == -1, -1e10)
+            probs = torch.softmax(masked / t, dim=-1)
+            knn_vals = vals[knns].long()
+            out = torch.zeros(sims.shape[0], output_size or self.vocab_size, device=sims.device)
+            out.scatter_add_(1, knn_vals, probs)
+            return (out, masked, knns.cpu().numpy()) if return_knn else out
+        n = sims.shape[0]
+        zeros = torch.zeros(n, device=sims.device, dtype=torch.float32)
+        _, p, recall = ops.knn_interp(zeros, sims, knns, targets.to(sims.device).long().contiguous(), t, 0.5,
+                                      vals=vals, n_store=self.dstore_size)
+        return (p, recall) if return_recall else p
+
+    def interpolate(self, queries, targets, lm_logp, t, lmbda, k=0):
+        """Fused hot-path form: search -> (interpolated log-prob [n], p_knn [n], recall [n])."""
+        sims, knns = self.search_sims(queries, k)
+        return ops.knn_interp(lm_logp.contiguous(), sims, knns, targets.long().contiguous(), t, lmbda,
+                              vals=self.vals_device(), n_store=self.dstore_size)

@@ -1,0 +1,93 @@
+"""``GnnLmModel`` -- the eval-path behaviour of ``TransformerLanguageModel`` with a
+``TokenGraphTransformerDecoder`` (fairseq/models/transformer.py:910-1085) under
+``--use-precompute-feat``: the base LM is bypassed (:974-976), the graph decoder (HGT) refines the
+precomputed features, and the tied adaptive softmax scores the targets.
+
+State-dict names follow the reference (prefix ``decoder.``): ``hgt_decoder.gcs.*``,
+``tgt_quantizer.*`` (convert_ckpt.py:40-45), ``embed_tokens.embeddings.{i}.{0,1}.weight``,
+``adaptive_softmax.head.class_proj.weight``.
+"""
+from argparse import Namespace
+
+import torch
+
+from .adaptive_softmax import AdaptiveSoftmax
+from .hgt import HGT, CodeStore, NeighborGraph
+from .pq_wrapper import TorchPQCodec
+
+
+class GnnLmModel(torch.nn.Module):
+    def __init__(self, hgt: HGT, asm: AdaptiveSoftmax, quantizer: TorchPQCodec = None, orig_prob_ratio: float = 0.0,
+                 short_cut: bool = False):
+        super().__init__()
+        if orig_prob_ratio > 0:
+            raise NotImplementedError("orig_prob_ratio > 0 needs the base-LM logits (transformer.py:987-1005); "
+                                      "the GNN-LM recipes evaluate with 0.0")
+        self.hgt_decoder, self.adaptive_softmax, self.tgt_quantizer = hgt, asm, quantizer
+        self.short_cut = short_cut
+
+    def eval(self):
+        return self
+
+    def forward(self, src_tokens, src_lengths=None, graph: NeighborGraph = None, **unused):
+        """-> (x [bsz, tgt_len, d], extra) like TokenGraphTransformerDecoder.forward (:943-1009)."""
+        bsz, tgt_len = src_tokens.shape
+        if graph is None or graph.tgt_h is None:
+            raise ValueError("graph.tgt_h (precomputed tgt features) is required: the base LM is not built "
+                             "(--use-precompute-feat path, transformer.py:974-976)")
+        assert graph.n_blocks == bsz and graph.T == tgt_len
+        h = graph.tgt_h
+        if h.dtype != torch.float32:
+            from . import ops
+            h = ops.half_to_float(h.contiguous()) if h.dtype == torch.float16 else h.float()
+        extra = {"inner_states": [h.view(bsz, tgt_len, -1).transpose(0, 1)]}
+        x = h if self.short_cut else self.hgt_decoder(graph, features={"tgt": h})["tgt"]
+        x = x.view(bsz, tgt_len, -1)
+        extra["gcn_feat"] = x.transpose(0, 1)                               # :997
+        return x, extra
+
+    def target_log_probs(self, net_output, target):
+        """log p(target) [bsz, tgt_len]: get_normalized_probs(log_probs=True) + gather
+        (transformer.py:1064-1079, sequence_scorer.py:48-53,89) without the dense [T, V] tensor."""
+        x = net_output[0]
+        bsz, T, d = x.shape
+        return self.adaptive_softmax.target_log_prob(x.reshape(-1, d).contiguous(), target.reshape(-1)).view(bsz, T)
+
+    def get_normalized_probs(self, net_output, log_probs, sample):
+        raise NotImplementedError("the dense [B, T, V] tensor is never materialised; use target_log_probs()")
+
+    @classmethod
+    def from_checkpoint(cls, path, device, overrides=None, vocab_size=None, quantizer=None):
+        """Load a reference ``.pt`` ({'args': Namespace, 'model': state_dict}, checkpoint_utils.py:161-176)."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        args = ckpt["args"] if isinstance(ckpt["args"], Namespace) else Namespace(**ckpt["args"])
+        for k_, v in (overrides or {}).items():
+            setattr(args, k_, v)
+        sd = ckpt["model"]
+        d, H, L = args.decoder_embed_dim, args.decoder_attention_heads, args.graph_layer
+        hgt = HGT(in_dim=d, hidden_dim=getattr(args, "decoder_gcn_dim", d), out_dim=d, n_layers=L, n_heads=H)
+        hgt.load_state_dict({k_[len("decoder.hgt_decoder."):]: v for k_, v in sd.items()
+                             if k_.startswith("decoder.hgt_decoder.")})
+        if quantizer is None:
+            if "decoder.tgt_quantizer.centroids_torch" in sd:
+                quantizer = TorchPQCodec.from_arrays(sd["decoder.tgt_quantizer.centroids_torch"].numpy(),
+                                                     sd["decoder.tgt_quantizer.A"].numpy() if "decoder.tgt_quantizer.A" in sd else None,
+                                                     sd["decoder.tgt_quantizer.b"].numpy() if "decoder.tgt_quantizer.b" in sd else None)
+            elif str(getattr(args, "quantizer_path", "")).endswith(".npz"):
+                quantizer = TorchPQCodec.from_file(args.quantizer_path)
+            else:
+                raise ValueError("no quantizer: the checkpoint has no decoder.tgt_quantizer.* buffers "
+                                 "(fairseq_cli/convert_ckpt.py) and quantizer_path is not an .npz; "
+                                 "a faiss index file needs faiss, which is not available")
+        cut = [int(c) for c in str(args.adaptive_softmax_cutoff).split(",")]
+        if vocab_size is None:
+            n_bands = sd["decoder.adaptive_softmax.head.class_proj.weight"].shape[0] + 1
+            vocab_size = cut[0] + sum(sd[f"decoder.embed_tokens.embeddings.{i}.0.weight"].shape[0] for i in range(1, n_bands))
+        asm = AdaptiveSoftmax.from_state_dict(sd, cut, vocab_size, device)
+        return cls(hgt, asm, quantizer, getattr(args, "orig_prob_ratio", 0.0), getattr(args, "short_cut", False)), args
+
+    def make_store(self, codes, n_store, device, vals=None, row0=0) -> CodeStore:
+        q = self.tgt_quantizer
+        t = lambda a: a.to(device).contiguous()
+        return CodeStore(codes=codes, centroids=t(q.centroids_torch), n_store=n_store, row0=row0, vals=vals,
+                         A=t(q.A) if q.pre_torch else None, b=t(q.b) if q.pre_torch and q.b.numel() else None)

@@ -119,6 +119,22 @@ def pq_gather_decode(codes, centroids, ids, left=0, right=0, n_store=None, row0=
     return out
 
 
+def pq_lookup_direct(codes, centroids):
+    """x[n, m*dsub:(m+1)*dsub] = centroids[m, codes[n, m]] for an explicit code matrix (no store)."""
+    _dev(codes, centroids)
+    n, M = codes.shape
+    dsub = centroids.shape[2]
+    x = torch.empty(n, M * dsub, device=codes.device, dtype=torch.float32)
+    valid = torch.ones(n, device=codes.device, dtype=torch.uint8)
+    d = _lib.gnnlm_gather_t()
+    d.codes, d.direct, d.in_valid = codes.data_ptr(), 1, valid.data_ptr()
+    d.M, d.dsub, d.centroids = M, dsub, centroids.data_ptr()
+    d.n_groups, d.vals_itemsize = n, 4
+    d.out_x, d.ld_x = x.data_ptr(), M * dsub
+    call_desc("gnnlm_pq_gather_decode", d)
+    return x
+
+
 def star_attn(U, ids, codes=None, centroids=None, row0=0, X=None, x_group_stride=1, codes_direct=0):
     _dev(U, ids, codes, centroids, X)
     T, H, D = U.shape

@@ -1,0 +1,78 @@
+"""``SequenceScorer`` -- mirror of ``fairseq/sequence_scorer.py:17-194`` for the LM eval path.
+
+Same constructor, same ``generate(models, sample, knn_dstore=..., temperature=...)`` call, same
+hypothesis dicts (``tokens, score, attention, alignment, positional_scores, dstore_keys, knn_recall``,
+:185-193).  What differs is only where the arithmetic runs: the dense ``[B, T, V]`` log-prob tensor and
+the host-side kNN gathers are replaced by the HIP kernels behind ``model.target_log_probs`` and
+``KNNModel.interpolate``.
+
+Reference behaviours kept on purpose:
+  * the kNN queries are ``extra[args.knn_keytype]`` if present else ``inner_states[-1]`` (:105) -- the
+    recipe's ``--knn-keytype keytype`` typo therefore selects the base-LM features;
+  * queries are flattened in [T, B] order but targets in [B, T] order (``orig_target.permute(0, 1)``
+    is a no-op, :117): identical for bsz == 1 (the recipe), reproduced as written otherwise;
+  * ``softmax_batch`` is accepted; the precondition B*T < softmax_batch of the kNN branch (:105 todo)
+    is asserted instead of silently using the last sub-batch.
+"""
+import sys
+
+import torch
+
+
+def strip_pad(tensor, pad):
+    return tensor[tensor.ne(pad)]                                   # fairseq/utils.py:190-191
+
+
+class SequenceScorer(object):
+    def __init__(self, tgt_dict, softmax_batch=None, compute_alignment=False, args=None):
+        self.pad, self.eos = tgt_dict.pad(), tgt_dict.eos()
+        self.softmax_batch = softmax_batch or sys.maxsize
+        assert self.softmax_batch > 0
+        self.compute_alignment, self.args = compute_alignment, args
+
+    @torch.no_grad()
+    def generate(self, models, sample, **kwargs):
+        if len(models) != 1:
+            raise ValueError("Only knn *log* probs are supported.")        # :108-109 (ensembles unused on this path)
+        model = models[0]
+        net_input = sample["net_input"]
+        temperature = kwargs.get("temperature", 1.0)
+        orig_target = sample["target"]
+        decoder_out = model(**net_input)
+        bsz, tsz = orig_target.shape
+        probs = model.target_log_probs(decoder_out, orig_target.clamp(min=0))
+        recall = None
+        lmbda = getattr(self.args, "lmbda", 0.0)
+        if "knn_dstore" in kwargs and lmbda > 0.0:
+            assert bsz * tsz < self.softmax_batch, "kNN scoring needs B*T < --softmax-batch (sequence_scorer.py:105)"
+            knn_model = kwargs["knn_dstore"]
+            extra = decoder_out[1]
+            kt = getattr(self.args, "knn_keytype", None)
+            queries = extra[kt] if kt in extra else extra["inner_states"][-1]          # [T, B, C]  (:105)
+            seq_len, b2, hidden = queries.shape
+            tq = orig_target.permute(0, 1).reshape(seq_len * b2)                        # as written (:117)
+            lm_flat = probs.transpose(0, 1).reshape(-1)                                 # [T*B] like the queries
+            mixed, _, rec = knn_model.interpolate(queries.contiguous().view(-1, hidden), tq.clamp(min=0),
+                                                  lm_flat, temperature, lmbda)
+            probs = mixed.view(seq_len, b2).transpose(0, 1)
+            recall = rec.view(seq_len, b2).transpose(0, 1)
+        start_idxs = sample["start_indices"] if "start_indices" in sample else [0] * bsz
+        kt = getattr(self.args, "knn_keytype", None)
+        feat = decoder_out[1][kt] if kt in decoder_out[1] else decoder_out[1]["inner_states"][-1]
+        hypos = []
+        for i in range(bsz):
+            s = int(start_idxs[i])
+            ref = strip_pad(sample["target"][i, s:], self.pad)
+            tgt_len = ref.numel()
+            p_i = probs[i][s:s + tgt_len]
+            mask = sample["target"][i, s:].ne(self.pad)
+            hypos.append([{
+                "tokens": ref,
+                "score": p_i.sum() / tgt_len,
+                "attention": None,
+                "alignment": None,
+                "positional_scores": p_i,
+                "dstore_keys": feat[s:, i, :][mask],
+                "knn_recall": recall[i, s:][mask] if recall is not None else None,
+            }])
+        return hypos

@@ -1,0 +1,90 @@
+"""Host-side mirrors of the reference interface, CPU parts (no kernel launches):
+DataStore / path layout / TorchPQCodec tables+encode+compute_sim / driver helpers, against the golden
+vectors produced by the reference's own code."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gnnlm_amd import path_utils
+from gnnlm_amd.data_store import DataStore
+from gnnlm_amd.eval_lm import block_ranges, get_parser
+from gnnlm_amd.pq_wrapper import TorchPQCodec
+
+
+@pytest.mark.parametrize("name", ["fp16_i16", "fp16_i32", "fp32_i32", "fp16_v2"])
+def test_datastore_mirror(golden, tmp_path, name):
+    g = golden("datastore")
+    info = json.loads(bytes(g[name + ".info"]).decode())
+    d = tmp_path / "x_dstore"
+    d.mkdir()
+    (d / "keys.npy").write_bytes(bytes(g[name + ".keys_raw"]))
+    (d / "vals.npy").write_bytes(bytes(g[name + ".vals_raw"]))
+    json.dump(info, open(d / "info.json", "w"))
+    for use_memory in (False, True):
+        ds = DataStore.from_pretrained(str(d), use_memory=use_memory)
+        assert ds.info == info
+        assert np.array_equal(np.array(ds.keys), g[name + ".keys"]) and ds.keys.dtype == g[name + ".keys"].dtype
+        assert np.array_equal(np.array(ds.vals), g[name + ".vals"]) and ds.vals.dtype == g[name + ".vals"].dtype
+    ds = DataStore.from_pretrained(str(d), no_load_keys=True)
+    assert not hasattr(ds, "keys")
+    assert DataStore.exists(str(d))
+    with pytest.raises(FileNotFoundError):
+        DataStore.from_pretrained(str(tmp_path / "missing"))
+
+
+def test_path_layout():
+    assert path_utils.feature_path("D", "test") == os.path.join("D", "test_dstore", "keys.npy")
+    assert path_utils.value_path("D", "train") == os.path.join("D", "train_dstore", "vals.npy")
+    assert path_utils.quantized_feature_path("D", "train") == os.path.join("D", "train_dstore", "quantized-keys.npy")
+    assert path_utils.neighbor_path("D", "valid", 128) == os.path.join("D", "valid_dstore", "neighbors.mmap.128")
+    assert path_utils.quantizer_path("D") == os.path.join("D", "quantizer")
+    assert path_utils.quantizer_path("D", "-x", True) == os.path.join("D", "quantizer-norm-x")
+    assert path_utils.dstore_path("D", "test") == os.path.join("D", "test_dstore")
+
+
+@pytest.mark.parametrize("case", ["sq_pre", "sq_pre_nob", "rect_pre", "nopre"])
+def test_codec_tables_encode_sim(golden, case):
+    g = golden("pq")
+    A = g[f"{case}.A"] if f"{case}.A" in g else None
+    b = g[f"{case}.b"] if f"{case}.b" in g else None
+    for metric in ("ip", "l2"):
+        c = TorchPQCodec.from_arrays(g[f"{case}.cen"], A, b, metric)
+        codes = c.encode(torch.from_numpy(g[f"{case}.x"].copy()))
+        assert np.array_equal(codes.numpy(), g[f"{case}.codes"])                      # integer: bit-exact
+        np.testing.assert_allclose(c.norm2_centroids_torch.numpy(), g[f"{case}.norm2"], rtol=1e-6)
+        np.testing.assert_allclose(c.sdc_table_torch.numpy()[:, :8, :8], g[f"{case}.{metric}.sdc_corner"], atol=2e-6)
+        np.testing.assert_allclose(c.compute_sim(codes[:5], codes).numpy(), g[f"{case}.{metric}.sim"], rtol=1e-5, atol=1e-4)
+    names = set(dict(c.named_buffers()))
+    assert {"centroids_torch", "norm2_centroids_torch", "sdc_table_torch"} <= names
+    assert ("A" in names) == (A is not None)
+    with pytest.raises(Exception):
+        c.decode(torch.zeros(2, c.centroids_torch.shape[0], dtype=torch.uint8))       # host tensor: no CPU fallback
+
+
+def test_codec_save_load(tmp_path, golden):
+    g = golden("pq")
+    c = TorchPQCodec.from_arrays(g["sq_pre.cen"], g["sq_pre.A"], g["sq_pre.b"])
+    c.save(str(tmp_path / "q.npz"))
+    c2 = TorchPQCodec.from_file(str(tmp_path / "q.npz"))
+    for (n1, b1), (n2, b2) in zip(c.named_buffers(), c2.named_buffers()):
+        assert n1 == n2 and torch.equal(b1, b2)
+
+
+def test_block_ranges_and_flags():
+    assert block_ranges(10, 4) == [(0, 0, 4), (4, 4, 8), (8, 8, 10)]
+    assert block_ranges(10, 4, 3) == [(0, 0, 4), (1, 4, 8), (5, 8, 10)]
+    assert block_ranges(0, 4) == []
+    a = get_parser().parse_args(["DATA", "--path", "m.pt"])
+    # defaults of the reference flags (language_modeling.py:97-153, options.py:472-501)
+    assert (a.gcn_k, a.k, a.lmbda, a.knn_sim_func, a.neighbor_context, a.temperature, a.gcn_context_window,
+            a.invalid_neighbor_context, a.probe) == (1024, 1024, 0.0, "do_not_recomp_ip", "(2, 2)", 1.0, 0, 1536, 8)
+    r = get_parser().parse_args("DATA --path m.pt --graph --neighbor-context 2 --gcn-k 128 --use-precompute-feat "
+                                "--sample-break-mode none --max-tokens 256 --tokens-per-sample 256 --softmax-batch 3072 "
+                                "--gcn-context-window 0 --gen-subset test --knn-keytype keytype --knnlm --k 1024 "
+                                "--lmbda 0.25 --dstore-dir D/train_dstore --index-file D/faiss_store.cosine "
+                                "--temperature 0.01 --knn-sim-func do_not_recomp_ip".split() +
+                                ["--model-overrides", "{'orig_prob_ratio': 0.0, 'max_target_positions': 256, 'add_bias': False}"])
+    assert r.graph and r.knnlm and r.gcn_k == 128 and r.lmbda == 0.25

@@ -1,0 +1,210 @@
+"""Host-side mirrors on the GPU: TorchPQCodec.decode, KNNModel.get_knn_prob, SequenceScorer.generate and
+the eval_lm driver, against the reference-generated golden vectors and the CPU oracle."""
+import json
+import os
+import types
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import knn as oknn
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("case", ["sq_pre", "sq_pre_nob", "rect_pre", "nopre"])
+def test_codec_decode_golden(dev, golden, case):
+    from gnnlm_amd.pq_wrapper import TorchPQCodec
+    g = golden("pq")
+    A = g[f"{case}.A"] if f"{case}.A" in g else None
+    b = g[f"{case}.b"] if f"{case}.b" in g else None
+    c = TorchPQCodec.from_arrays(g[f"{case}.cen"], A, b).to(dev)
+    out = c.decode(torch.from_numpy(g[f"{case}.codes"]).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(out, g[f"{case}.decode"], atol=2e-6, rtol=1e-5)            # pq_wrapper.py:233-237 uses 1e-6
+
+
+def test_codec_decode_full_size(dev, golden):
+    from gnnlm_amd.pq_wrapper import TorchPQCodec
+    from tests.test_oracle_golden import full_size_codec
+    g = golden("pq")
+    cen, A, b = full_size_codec()
+    c = TorchPQCodec.from_arrays(cen, A, b).to(dev)
+    out = c.decode(torch.from_numpy(g["full.codes"]).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(out, g["full.decode"], atol=3e-5, rtol=1e-5)
+
+
+class FixedIndex:
+    """Replays recorded search results (faiss contract)."""
+
+    def __init__(self, dists, ids):
+        self.d, self.i = dists, ids
+
+    def search(self, q, k):
+        return self.d[:, :k].copy(), self.i[:, :k].copy()
+
+
+def write_dstore(path, keys, vals, vocab, fp16=True):
+    os.makedirs(path, exist_ok=True)
+    keys.tofile(os.path.join(path, "keys.npy"))
+    vals.tofile(os.path.join(path, "vals.npy"))
+    json.dump({"dstore_size": len(vals), "hidden_size": keys.shape[1], "vocab_size": vocab, "dstore_fp16": fp16,
+               "val_size": 1}, open(os.path.join(path, "info.json"), "w"))
+
+
+@pytest.mark.parametrize("metric_type", ["do_not_recomp_ip", "do_not_recomp_l2", "ip", "l2"])
+def test_knn_model_golden(dev, golden, tmp_path, metric_type):
+    from gnnlm_amd.knn_model import KNNModel
+    g = golden("knn")
+    write_dstore(str(tmp_path / "d"), g["keys"], g["vals"].astype(np.int16), 50)
+    for cosine in (False, True):
+        for t in (1.0, 0.01):
+            tag = f"{metric_type}.{'cos' if cosine else 'raw'}.t{t}"
+            m = KNNModel("faiss_store.cosine" if cosine else "faiss_store.ip", str(tmp_path / "d"), k=8,
+                         metric_type=metric_type, index=FixedIndex(g[tag + ".dists"], g[tag + ".ids"]), device=dev)
+            p, rec = m.get_knn_prob(torch.from_numpy(g["queries"]).to(dev), targets=torch.from_numpy(g["targets"]).to(dev),
+                                    t=t, return_recall=True)
+            np.testing.assert_allclose(p.cpu().numpy(), g[tag + ".p"], rtol=3e-5, atol=1e-7)
+            assert np.array_equal(rec.cpu().numpy(), g[tag + ".recall"])
+            dense, sims, knns = m.get_knn_prob(torch.from_numpy(g["queries"]).to(dev), t=t, return_knn=True)
+            np.testing.assert_allclose(dense.cpu().numpy(), g[tag + ".dense"], rtol=3e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        KNNModel("x", str(tmp_path / "nope"), index=FixedIndex(None, None))
+
+
+def test_exact_index_matches_oracle_search(dev, golden):
+    from gnnlm_amd.knn_model import ExactIndex
+    g = golden("knn")
+    for metric, cosine in [("ip", False), ("ip", True), ("l2", False)]:
+        q = oknn.normalize_queries(torch.from_numpy(g["queries"]), cosine).numpy()
+        d_ref, i_ref = oknn.brute_force_search(q, g["keys"], 8, metric, cosine)
+        d, i = ExactIndex(g["keys"], metric, cosine, dev).search(q, 8)
+        assert np.array_equal(i, i_ref)
+        np.testing.assert_allclose(d, d_ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("keytype", ["gcn_feat", "keytype"])
+@pytest.mark.parametrize("lmbda,temp", [(0.25, 1.0), (0.1, 0.01), (0.0, 1.0)])
+def test_sequence_scorer_golden(dev, golden, tmp_path, keytype, lmbda, temp):
+    """SequenceScorer mirror vs the reference's own SequenceScorer.generate (scripted model)."""
+    from gnnlm_amd.adaptive_softmax import AdaptiveSoftmax
+    from gnnlm_amd.knn_model import ExactIndex, KNNModel
+    from gnnlm_amd.model import GnnLmModel
+    from gnnlm_amd.sequence_scorer import SequenceScorer
+    g, ga = golden("scorer"), golden("adaptive_softmax")
+    emb = [torch.from_numpy(ga[f"emb{i}"]) for i in range(3)]
+    proj = [None] + [torch.from_numpy(ga[f"proj{i}"]) for i in (1, 2)]
+    asm = AdaptiveSoftmax(list(ga["cutoff"]), emb, proj, torch.from_numpy(ga["class_proj"]), dev)
+    feats, inner = torch.from_numpy(g["feats"]).to(dev), torch.from_numpy(g["inner"]).to(dev)
+
+    class Scripted(GnnLmModel):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.adaptive_softmax = asm
+
+        def forward(self, src_tokens, src_lengths=None, graph=None):
+            return feats, {"inner_states": [inner], "gcn_feat": feats.transpose(0, 1)}
+
+    write_dstore(str(tmp_path / "d"), g["keys"], g["vals"].astype(np.int16), 24)
+
+    class PaddedExact(ExactIndex):               # the golden's stand-in pads every third row with one -1
+        def search_device(self, q, k):
+            d, i = super().search_device(q, k)
+            i[::3, -1:] = -1
+            d[::3, -1:] = -3.4e38
+            return d, i
+
+    knn = KNNModel("faiss_store.cosine", str(tmp_path / "d"), k=6, metric_type="do_not_recomp_ip",
+                   index=PaddedExact(g["keys"], "ip", True, dev), device=dev)
+    target = torch.from_numpy(g["target"]).to(dev)
+    bsz, T = target.shape
+    sample = {"id": torch.arange(bsz), "nsentences": bsz, "ntokens": bsz * T,
+              "net_input": {"src_tokens": torch.zeros(bsz, T, dtype=torch.long, device=dev),
+                            "src_lengths": torch.full((bsz,), T)},
+              "target": target, "start_indices": torch.tensor([[0], [2]])}
+    tgt_dict = types.SimpleNamespace(pad=lambda: 1, eos=lambda: 2)
+    scorer = SequenceScorer(tgt_dict, softmax_batch=3072, args=Namespace(lmbda=lmbda, knn_keytype=keytype))
+    hyp = scorer.generate([Scripted()], sample, knn_dstore=knn, temperature=temp)
+    for i, h in enumerate(hyp):
+        h = h[0]
+        tag = f"{keytype}.l{lmbda}.t{temp}.{i}"
+        assert np.array_equal(h["tokens"].cpu().numpy(), g[tag + ".tokens"])
+        np.testing.assert_allclose(h["positional_scores"].cpu().numpy(), g[tag + ".positional_scores"], rtol=3e-5, atol=5e-6)
+        np.testing.assert_allclose(h["score"].item(), g[tag + ".score"], rtol=3e-5, atol=5e-6)
+        np.testing.assert_allclose(h["dstore_keys"].cpu().numpy(), g[tag + ".dstore_keys"])
+        if lmbda > 0:
+            assert np.array_equal(h["knn_recall"].cpu().numpy(), g[tag + ".knn_recall"])
+        else:
+            assert h["knn_recall"] is None
+
+
+def test_eval_lm_end_to_end(dev, tmp_path):
+    """A synthetic data directory in the reference's on-disk formats -> the driver's ppl equals the
+    oracle's (float32 accumulation differences aside), with and without kNN, incl. a ragged last block."""
+    from gnnlm_amd import eval_lm
+    from gnnlm_amd.knn_model import ExactIndex, KNNModel
+    from gnnlm_amd.synthetic import make_problem
+    from oracle import knn as oknn_, pipeline
+    d, H, M, dsub, V, kg, T, L = 64, 4, 16, 4, 600, 6, 16, 2
+    n_train, n_test = 2000, 41                      # 41 = 2 full blocks + a 9-token block
+    prob = make_problem(n_store=n_train, d=d, n_heads=H, M=M, dsub=dsub, vocab=V, cutoff=[100, 300], T=n_test, kg=kg,
+                        left=2, right=2, n_layers=L, k=8, seed=3)
+    data = tmp_path / "data-bin"
+    rs = np.random.RandomState(0)
+    train_keys = rs.randn(n_train, d).astype(np.float16)
+    write_dstore(str(data / "train_dstore"), train_keys, prob["vals"].astype(np.int32), V)
+    np.save(str(data / "train_dstore" / "quantized-keys.npy"), prob["codes"])
+    blk = prob["block"]
+    write_dstore(str(data / "test_dstore"), blk["tgt_feats"], blk["targets"].astype(np.int32), V)
+    blk["ids"].tofile(str(data / "test_dstore" / f"neighbors.mmap.{kg}"))
+    sd = {"decoder.hgt_decoder." + k: v for k, v in prob["sd"].items()}
+    w = prob["asm"]
+    for i, e in enumerate(w["emb"]):
+        sd[f"decoder.embed_tokens.embeddings.{i}.0.weight"] = e
+        if i:
+            sd[f"decoder.embed_tokens.embeddings.{i}.1.weight"] = w["proj"][i]
+    sd["decoder.adaptive_softmax.head.class_proj.weight"] = w["class_proj"]
+    sd["decoder.tgt_quantizer.centroids_torch"] = torch.from_numpy(prob["cen"])
+    sd["decoder.tgt_quantizer.A"] = torch.from_numpy(prob["A"])
+    sd["decoder.tgt_quantizer.b"] = torch.from_numpy(prob["b"])
+    margs = Namespace(decoder_embed_dim=d, decoder_attention_heads=H, graph_layer=L, decoder_gcn_dim=d,
+                      adaptive_softmax_cutoff="100,300", orig_prob_ratio=0.0, short_cut=False, quantizer_path="")
+    torch.save({"args": margs, "model": sd}, str(tmp_path / "ckpt.pt"))
+    base = [str(data), "--path", str(tmp_path / "ckpt.pt"), "--gen-subset", "test", "--graph", "--neighbor-context", "2",
+            "--gcn-k", str(kg), "--use-precompute-feat", "--sample-break-mode", "none", "--max-tokens", str(2 * T),
+            "--tokens-per-sample", str(T), "--gcn-context-window", "0", "--knn-keytype", "gcn_feat",
+            "--model-overrides", "{'orig_prob_ratio': 0.0}"]
+    # oracle, block by block
+    model = {"sd": prob["sd"], "n_layers": L, "n_heads": H, "centroids": prob["cen"], "A": prob["A"], "b": prob["b"],
+             "codes": prob["codes"], "vals": prob["vals"], "n_store": n_train, "left": 2, "right": 2, "asm": w}
+    lam, temp, k = 0.25, 1.0, 8
+    ref_lm, ref_mix = [], []
+    for s in range(0, n_test, T):
+        e = min(n_test, s + T)
+        one = {"neighbor_idxs": blk["ids"][s:e], "tgt_feats": blk["tgt_feats"][s:e], "targets": blk["targets"][s:e]}
+        o = pipeline.eval_block(dict(one, knn_sims=None, knn_ids=None), model, 0.0, 1.0)
+        ref_lm.append(o["lm_logp"])
+        q = oknn_.normalize_queries(o["gcn_feat"].float(), True).numpy()
+        dd, ii = oknn_.brute_force_search(q, train_keys, k, "ip", cosine=True)
+        p, _ = oknn_.knn_target_prob(dd, ii, prob["vals"], blk["targets"][s:e], temp)
+        ref_mix.append(oknn_.combine_knn_and_vocab_probs(p, o["lm_logp"], lam))
+    ref_lm, ref_mix = torch.cat(ref_lm).double(), torch.cat(ref_mix).double()
+    res = eval_lm.cli_main(base)
+    assert res["count"] == n_test
+    assert abs(res["score_sum"] - ref_lm.sum().item()) < 1e-4 * n_test
+    assert abs(res["ppl"] - 2 ** (-ref_lm.sum().item() / n_test / np.log(2))) < 0.02      # north_star: ppl within 0.02
+    res = eval_lm.cli_main(base + ["--knnlm", "--k", str(k), "--lmbda", str(lam), "--dstore-dir", str(data / "train_dstore"),
+                                   "--index-file", str(data / "train_dstore" / "faiss_store.cosine"),
+                                   "--temperature", str(temp), "--knn-sim-func", "ip"])
+    assert abs(res["score_sum"] - ref_mix.sum().item()) < 2e-4 * n_test
+    # --num-shards / --shard-id partition the blocks (eval_lm.py:131-132)
+    parts = [eval_lm.cli_main(base + ["--num-shards", "2", "--shard-id", str(i)]) for i in range(2)]
+    assert sum(p["count"] for p in parts) == n_test
+    assert abs(sum(p["score_sum"] for p in parts) - ref_lm.sum().item()) < 1e-4 * n_test
