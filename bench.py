@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--store", choices=["sharded", "replicated"], default="sharded")
     ap.add_argument("--pool", type=int, default=4, help="distinct input batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=48)
+    ap.add_argument("--cpu-tokens", type=int, default=192)
     ap.add_argument("--small", action="store_true", help="tiny shapes (plumbing check only)")
     return ap.parse_args()
 

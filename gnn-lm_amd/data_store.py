@@ -72,7 +72,7 @@ class DataStore:
         assert self.val_size == 1, "make sure self.data_store.val_size == 1 (which is labels)"
         n_rows = self.dstore_size - row0 if n_rows is None else n_rows
         if self._device_vals is None or self._device_vals[0] != (str(device), row0, n_rows):
-            t = torch.from_numpy(np.ascontiguousarray(self.vals[row0:row0 + n_rows])).to(device)
+            t = torch.from_numpy(np.array(self.vals[row0:row0 + n_rows])).to(device)
             self._device_vals = ((str(device), row0, n_rows), t)
         return self._device_vals[1]
 

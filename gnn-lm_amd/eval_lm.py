@@ -117,7 +117,7 @@ def load_tables(args, device):
                         dtype=vals_dtype(info["dstore_fp16"], info.get("vocab_size")))
     nbrs = np.memmap(neighbor_path(data, split, args.gcn_k), mode="r", dtype=np.int64, shape=(n_tok, args.gcn_k))
     codes = np.load(quantized_feature_path(data, "train"), mmap_mode="r")                  # language_modeling.py:274-276
-    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    up = lambda a: torch.from_numpy(np.array(a)).to(device)
     return {"n_tok": n_tok, "d": d, "vocab": info.get("vocab_size"), "n_store": tinfo["dstore_size"],
             "feats": up(feats), "targets": up(targets).long(), "nbrs": up(nbrs), "codes": up(codes)}
 
