@@ -54,6 +54,13 @@ __device__ __forceinline__ float reduce8(const float (&v)[HB], int lane) {
 // coalesced 16-B loads -- one full 128-B line per neighbour, the only HBM traffic of the kernel --
 // so the per-neighbour dependent chain is LDS byte -> L2 centroid gather, and two neighbours are in
 // flight per wave to cover the L2 latency.
+//
+// Measured dead ends (round 1, 2048 tokens x 128 neighbours, this kernel = 405 us): streaming the centroid
+// table through LDS in 32/64-dim chunks with lane = neighbour (no cross-lane reduction) and U either on
+// the scalar path (s_load -> SGPR operands; 1230 us: SGPR spills + exposed scalar latency at 1 wave/SIMD)
+// or broadcast from LDS with two neighbours per lane (640 us: random 32-B LDS reads conflict, 128 barriers
+// per workgroup, 1 workgroup per CU).  The L2 gather below moves a 128-B line per 32 useful bytes but keeps
+// 8 waves per CU in flight; it stays until a formulation with >= 2 workgroups per CU is found.
 template <int QPL>
 __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
