@@ -58,9 +58,13 @@ class AdaptiveSoftmax:
         out = torch.empty(n, device=x.device, dtype=torch.float32)
         L = _lib.lib()
         need = L.gnnlm_adaptive_workspace_bytes(ctypes.byref(self._w), n)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+        key = torch.cuda.current_stream().cuda_stream           # one arena per stream
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(need, device=x.device, dtype=torch.uint8)
         _lib.check(L.gnnlm_adaptive_target_logp(ctypes.byref(self._w), _lib.ptr(x), x.stride(0), _lib.ptr(target), n,
-                                                _lib.ptr(out), _lib.ptr(self._ws), self._ws.numel(), _lib.stream()),
+                                                _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream()),
                    "gnnlm_adaptive_target_logp")
         return out

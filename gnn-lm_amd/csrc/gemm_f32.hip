@@ -73,21 +73,17 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmParams p) {
     const int srow = tid >> 3;
     const float* ap[LA];
     const float* wp[LW];
-    bool av[LA], wv[LW];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int gr = m0 + srow + 32 * i;
-        bool ok = gr < M;
-        int64_t ar = ok ? (p.a_rows ? (int64_t)p.a_rows[gr] : (int64_t)gr) : 0;
-        if (ar < 0) { ok = false; ar = 0; }
-        av[i] = ok;
+        int64_t ar = gr < M ? (p.a_rows ? (int64_t)p.a_rows[gr] : (int64_t)gr) : 0;
+        if (ar < 0) ar = 0;                      // negative gather index = zero row, applied in the epilogue
         ap[i] = A + ar * p.lda;
     }
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
         const int gn = n0 + srow + 32 * i;
-        wv[i] = gn < p.N;
-        wp[i] = W + (int64_t)(wv[i] ? gn : 0) * p.ldw;
+        wp[i] = W + (int64_t)(gn < p.N ? gn : 0) * p.ldw;
     }
 
     f32x16 acc[TM][TN];
@@ -99,21 +95,34 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[LA], rw[LW];
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_full = p.K / BK;              // full k-tiles: loaded without any guard
+    const bool k_tail = (p.K % BK) != 0;       // one partial tile, peeled after the main loop
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // No select on the loaded data in the main loop: a select would need the value and so put an
+    // s_waitcnt right behind every global load, serialising HBM latency with the 64 MFMAs of the
+    // k-tile.  Out-of-range rows read a clamped (valid) address instead; their garbage only reaches
+    // output rows / columns that are never stored.
 #define GNNLM_LOAD_TILE(kt)                                                                  \
+    {                                                                                        \
+        const int k_ = (kt) * BK + kq;                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < LA; ++i_)                                    \
+            ra[i_] = *reinterpret_cast<const float4*>(ap[i_] + k_);                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < LW; ++i_)                                    \
+            rw[i_] = *reinterpret_cast<const float4*>(wp[i_] + k_);                          \
+    }
+#define GNNLM_LOAD_TILE_GUARDED(kt)                                                          \
     {                                                                                        \
         int k_ = (kt) * BK + kq;                                                             \
         const bool kin_ = k_ < p.K;                                                          \
         k_ = kin_ ? k_ : 0;                                                                  \
         _Pragma("unroll") for (int i_ = 0; i_ < LA; ++i_) {                                  \
             ra[i_] = *reinterpret_cast<const float4*>(ap[i_] + k_);                          \
-            if (!(av[i_] && kin_)) ra[i_] = z4;                                              \
+            if (!kin_) ra[i_] = z4;                                                          \
         }                                                                                    \
         _Pragma("unroll") for (int i_ = 0; i_ < LW; ++i_) {                                  \
             rw[i_] = *reinterpret_cast<const float4*>(wp[i_] + k_);                          \
-            if (!(wv[i_] && kin_)) rw[i_] = z4;                                              \
+            if (!kin_) rw[i_] = z4;                                                          \
         }                                                                                    \
     }
 #define GNNLM_STORE_TILE(buf)                                                                \
@@ -125,36 +134,47 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmParams p) {
         _Pragma("unroll") for (int i_ = 0; i_ < LW; ++i_)                                    \
             *reinterpret_cast<float4*>(w_ + 32 * i_ * LDS_LD) = rw[i_];                      \
     }
+#define GNNLM_COMPUTE(buf)                                                                   \
+    {                                                                                        \
+        const float* a_base = &lds[(buf) * STAGE + (wm * (BM / 2) + l32) * LDS_LD + 4 * half];            \
+        const float* w_base = &lds[(buf) * STAGE + (BM + wn * (BN / 2) + l32) * LDS_LD + 4 * half];       \
+        _Pragma("unroll") for (int s_ = 0; s_ < BK / 8; ++s_) {                              \
+            float4 a[TM], b[TN];                                                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                   \
+                a[i] = *reinterpret_cast<const float4*>(a_base + 32 * i * LDS_LD + 8 * s_);  \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                   \
+                b[j] = *reinterpret_cast<const float4*>(w_base + 32 * j * LDS_LD + 8 * s_);  \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                   \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                             \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0); \
+                }                                                                            \
+        }                                                                                    \
+    }
 
-    GNNLM_LOAD_TILE(0);
-    GNNLM_STORE_TILE(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) GNNLM_LOAD_TILE(kt + 1);
-        const float* a_base = &lds[buf * STAGE + (wm * (BM / 2) + l32) * LDS_LD + 4 * half];
-        const float* w_base = &lds[buf * STAGE + (BM + wn * (BN / 2) + l32) * LDS_LD + 4 * half];
-#pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            float4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(a_base + 32 * i * LDS_LD + 8 * s);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(w_base + 32 * j * LDS_LD + 8 * s);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
+    if (nk_full > 0) {
+        GNNLM_LOAD_TILE(0);
+        GNNLM_STORE_TILE(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk_full; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk_full) GNNLM_LOAD_TILE(kt + 1);
+            GNNLM_COMPUTE(buf);
+            if (kt + 1 < nk_full) GNNLM_STORE_TILE(buf ^ 1);
+            __syncthreads();
         }
-        if (kt + 1 < nk) GNNLM_STORE_TILE(buf ^ 1);
+    }
+    if (k_tail) {
+        GNNLM_LOAD_TILE_GUARDED(nk_full);
+        GNNLM_STORE_TILE(0);
+        __syncthreads();
+        GNNLM_COMPUTE(0);
         __syncthreads();
     }
+#undef GNNLM_LOAD_TILE_GUARDED
+#undef GNNLM_COMPUTE
 #undef GNNLM_LOAD_TILE
 #undef GNNLM_STORE_TILE
 
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmParams p) {
                     const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (row >= M) continue;
                     const int64_t crow = p.c_rows ? (int64_t)p.c_rows[row] : (int64_t)row;
-                    float v = acc[i][j][r] * p.alpha;
+                    float v = (p.a_rows && p.a_rows[row] < 0) ? 0.f : acc[i][j][r] * p.alpha;
                     if (bias) v += (p.gate ? p.gate[row] : 1.f) * (p.bias_mode == 1 ? bias[col] : bias[row]);
                     if (R) v += R[crow * p.ldr + col];
                     C[crow * p.ldc + col] = v;

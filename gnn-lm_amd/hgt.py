@@ -238,9 +238,14 @@ class HGT(nn.Module):
             io.out_ntgt, io.out_valid = out_ntgt.data_ptr(), out_valid.data_ptr()
         L = _lib.lib()
         need = L.gnnlm_hgt_workspace_bytes(ctypes.byref(m), ctypes.byref(io))
-        if prep["ws"] is None or prep["ws"].numel() < need or prep["ws"].device != tgt.device:
-            prep["ws"] = torch.empty(need, device=tgt.device, dtype=torch.uint8)
-        _lib.check(L.gnnlm_hgt_forward(ctypes.byref(m), ctypes.byref(io), _lib.ptr(prep["ws"]), prep["ws"].numel(),
+        # one arena per stream: concurrent forwards on different streams must not share scratch
+        key = torch.cuda.current_stream().cuda_stream
+        if prep["ws"] is None:
+            prep["ws"] = {}
+        ws = prep["ws"].get(key)
+        if ws is None or ws.numel() < need or ws.device != tgt.device:
+            ws = prep["ws"][key] = torch.empty(need, device=tgt.device, dtype=torch.uint8)
+        _lib.check(L.gnnlm_hgt_forward(ctypes.byref(m), ctypes.byref(io), _lib.ptr(ws), ws.numel(),
                                        _lib.stream()), "gnnlm_hgt_forward")
         out = {"tgt": out_tgt}
         if return_ntgt:

@@ -19,7 +19,8 @@ SHAPES = [  # name, M, N, K, batch1, batch2
     ("ntgt 163840x1024x1024", 163840, 1024, 1024, 1, 1),
     ("sq 4096^3", 4096, 4096, 4096, 1, 1),
 ]
-for name, M, N, K, b1, b2 in SHAPES:
+sel = sys.argv[1] if len(sys.argv) > 1 else ""
+for name, M, N, K, b1, b2 in [s_ for s_ in SHAPES if sel in s_[0]]:
     nb = b1 * b2
     A = torch.randn(nb * M, K, device=dev)
     W = torch.randn(nb * N, K, device=dev)
