@@ -52,7 +52,7 @@ def parse():
                     help="HIP streams per GPU: the step's blocks are split into this many independent sub-batches "
                          "enqueued on separate streams (HBM/L2-bound and MFMA-bound kernels of different sub-batches overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=192)
+    ap.add_argument("--cpu-tokens", type=int, default=384)
     ap.add_argument("--small", action="store_true", help="tiny shapes (plumbing check only)")
     return ap.parse_args()
 

@@ -35,14 +35,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 constexpr int BK = 32, LDS_LD = BK + 4;
+#ifndef GNNLM_GEMM_NBUF
+#define GNNLM_GEMM_NBUF 1
+#endif
+constexpr int NBUF = GNNLM_GEMM_NBUF;
 enum { EPI_STORE = 0, EPI_LSE = 1 };
 
 template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p) {
     constexpr int TM = BM / 64, TN = BN / 64;            // 32x32 accumulators per wave
     constexpr int LA = BM / 32, LW = BN / 32;            // staging float4 per thread
     constexpr int STAGE = (BM + BN) * LDS_LD;
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -60,7 +64,17 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmParams p) {
     for (unsigned t = p.m_dev ? blockIdx.x : xcd_remap(blockIdx.x, n_tiles); t < n_tiles; t += t_step) {
     int tm, tn;
     if (p.tile_order == 1) { tm = t / tiles_n; tn = t % tiles_n; }      // n fastest
-    else                   { tn = t / tiles_m; tm = t % tiles_m; }      // m fastest
+    else if (p.tile_order == 2) { tn = t / tiles_m; tm = t % tiles_m; } // m fastest
+    else {
+        // grouped: bands of GM m-tiles; inside a band n is the slow index.  GM A-panels (GM x 512 KiB at
+        // K = 1024) stay in the XCD's 4-MiB L2 while the W panels stream through once per band.
+        const int GM = p.tile_order - 2;
+        const int band = t / (GM * tiles_n);
+        const int m_in = min(GM, tiles_m - band * GM);
+        const int r = t - band * GM * tiles_n;
+        tn = r / m_in;
+        tm = band * GM + r % m_in;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int b1 = blockIdx.y / p.batch2, b2 = blockIdx.y % p.batch2;
@@ -159,10 +173,11 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmParams p) {
         GNNLM_STORE_TILE(0);
         __syncthreads();
         for (int kt = 0; kt < nk_full; ++kt) {
-            const int buf = kt & 1;
+            const int buf = NBUF == 2 ? (kt & 1) : 0;
             if (kt + 1 < nk_full) GNNLM_LOAD_TILE(kt + 1);
             GNNLM_COMPUTE(buf);
-            if (kt + 1 < nk_full) GNNLM_STORE_TILE(buf ^ 1);
+            if (NBUF == 1) __syncthreads();
+            if (kt + 1 < nk_full) GNNLM_STORE_TILE(NBUF == 2 ? (buf ^ 1) : 0);
             __syncthreads();
         }
     }
@@ -276,7 +291,7 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     GNNLM_REQUIRE(p.batch1 >= 1 && p.batch2 >= 1, "gemm: bad batch");
     GNNLM_REQUIRE(p.precision == 0, "gemm: unknown precision");
     GNNLM_REQUIRE(!p.lse_part || p.batch1 * p.batch2 == 1, "gemm: the LSE epilogue does not support batches");
-    GNNLM_REQUIRE(p.tile_order >= 0 && p.tile_order <= 2, "gemm: tile_order must be 0 (auto), 1 (n fastest) or 2 (m fastest)");
+    GNNLM_REQUIRE(p.tile_order >= 0 && p.tile_order <= 66, "gemm: tile_order must be 0 (auto), 1 (n fastest), 2 (m fastest) or 2+GM (bands of GM m-tiles)");
     if (p.M == 0) return OK;
     const int64_t nb = (int64_t)p.batch1 * p.batch2;
     // 128x128 tiles unless they would leave CUs without a workgroup (256 CUs)

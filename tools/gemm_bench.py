@@ -18,7 +18,9 @@ SHAPES = [  # name, M, N, K, batch1, batch2
     ("tail2 256x207744x64", 256, 207744, 64, 1, 1),
     ("ntgt 163840x1024x1024", 163840, 1024, 1024, 1, 1),
     ("sq 4096^3", 4096, 4096, 4096, 1, 1),
+    ("head8k 8192x20002x1024", 8192, 20002, 1024, 1, 1),
 ]
+ORDER = int(os.environ.get("TILE_ORDER", "0"))
 sel = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, M, N, K, b1, b2 in [s_ for s_ in SHAPES if sel in s_[0]]:
     nb = b1 * b2
@@ -28,6 +30,7 @@ for name, M, N, K, b1, b2 in [s_ for s_ in SHAPES if sel in s_[0]]:
     g = _lib.gnnlm_gemm_t()
     g.A, g.lda, g.W, g.ldw, g.C, g.ldc = A.data_ptr(), K, W.data_ptr(), K, C.data_ptr(), N
     g.M, g.N, g.K, g.batch1, g.batch2 = M, N, K, b1, b2
+    g.tile_order = ORDER
     g.sA1, g.sA2, g.sW1, g.sW2, g.sC1, g.sC2 = b2 * M * K, M * K, b2 * N * K, N * K, b2 * M * N, M * N
     for _ in range(3):
         _lib.call_desc("gnnlm_gemm_nt", g)
