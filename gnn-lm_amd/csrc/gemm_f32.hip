@@ -217,8 +217,12 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
             }
     } else {
         // per row: m = max over this wave's valid columns, s = sum exp(x - m); the 32 lanes of a half
-        // hold the 32 columns of one accumulator row
+        // hold the 32 columns of one accumulator row.  The tile's pick columns are staged in LDS once
+        // (a global load per accumulator row inside the loop costs ~30 us per tile in exposed latency).
         const int n_parts = 2 * tiles_n;
+        int* lpick = reinterpret_cast<int*>(lds);            // the k-loop's last barrier freed the buffer
+        if (tid < BM) lpick[tid] = (p.lse_pick && m0 + tid < M) ? p.lse_pick[m0 + tid] : -1;
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
                     const int col = n0 + wn * (BN / 2) + j * 32 + l32;
                     v[j] = col < p.N ? acc[i][j][r] * p.alpha : -INFINITY;
                     mx = fmaxf(mx, v[j]);
-                    if (p.lse_pick && row < M && col < p.N && p.lse_pick[row] == col) p.lse_picked[row] = v[j];
+                    if (col < p.N && lpick[row - m0] == col) p.lse_picked[row] = v[j];
                 }
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -302,7 +306,8 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     GNNLM_REQUIRE(tiles < (1ll << 31) && nb < 65536, "gemm: grid too large");
     if (p.tile_order == 0)      // share the larger operand's panel between consecutive tiles
         p.tile_order = (!p.m_dev && (double)p.M > (double)p.N) ? 1 : 2;
-    dim3 grid((unsigned)(p.m_dev ? std::min<int64_t>(tiles, 1024) : tiles), (unsigned)nb);
+    // device-side M: a pool of resident workgroups (256 CUs x 3 per CU) walks the real tiles
+    dim3 grid((unsigned)(p.m_dev ? std::min<int64_t>(tiles, 768) : tiles), (unsigned)nb);
     const double work = 2.0 * p.M * (double)p.N * p.K * nb;
     ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N) * nb,
                    p.m_dev, (double)p.M);

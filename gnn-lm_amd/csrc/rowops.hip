@@ -80,12 +80,14 @@ __global__ __launch_bounds__(256) void row_lse_pick_kernel(const float* logits, 
     }
 }
 
-// single wave: stable compaction of the rows whose target falls into each tail band
-__global__ __launch_bounds__(64) void band_split_kernel(BandSplitParams p) {
-    const int lane = threadIdx.x;
+// one workgroup: stable compaction of the rows whose target falls into each tail band.  Rows are taken
+// in chunks of 256; per band a ballot per wave + a 4-entry LDS prefix gives every row its slot.
+__global__ __launch_bounds__(256) void band_split_kernel(BandSplitParams p) {
+    __shared__ int wcnt[8][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int count[8] = {0};
-    for (int64_t base = 0; base < p.n; base += 64) {
-        const int64_t r = base + lane;
+    for (int64_t base = 0; base < p.n; base += 256) {
+        const int64_t r = base + tid;
         const bool in = r < p.n;
         const int64_t t = in ? p.target[r] : 0;
         int band = 0;
@@ -93,21 +95,35 @@ __global__ __launch_bounds__(64) void band_split_kernel(BandSplitParams p) {
         for (int b = 1; b < 8; ++b)
             if (b < p.n_bands && t >= p.cutoff[b - 1]) band = b;
         if (in) p.head_pick[r] = band == 0 ? (int32_t)t : p.cutoff[0] + band - 1;
+        unsigned long long mask[8];
+#pragma unroll
+        for (int b = 1; b < 8; ++b) {
+            mask[b] = 0;
+            if (b < p.n_bands) {
+                mask[b] = __ballot(in && band == b);
+                if (lane == 0) wcnt[b][wave] = __popcll(mask[b]);
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int b = 1; b < 8; ++b) {
             if (b >= p.n_bands) break;
-            const bool mine = in && band == b;
-            const unsigned long long mask = __ballot(mine);
-            const int before = __popcll(mask & ((1ull << lane) - 1ull));
-            if (mine) {
-                const int64_t dst = (int64_t)(b - 1) * p.n + count[b] + before;
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                before += w < wave ? wcnt[b][w] : 0;
+                total += wcnt[b][w];
+            }
+            if (in && band == b) {
+                const int64_t dst = (int64_t)(b - 1) * p.n + count[b] + before + __popcll(mask[b] & ((1ull << lane) - 1ull));
                 p.band_rows[dst] = (int32_t)r;
                 p.band_pick[dst] = (int32_t)(t - p.cutoff[b - 1]);
             }
-            count[b] += __popcll(mask);
+            count[b] += total;
         }
+        __syncthreads();
     }
-    if (lane == 0)
+    if (tid == 0)
         for (int b = 1; b < p.n_bands; ++b) p.band_count[b - 1] = count[b];
 }
 
@@ -231,7 +247,7 @@ int row_lse_pick(const float* logits, int64_t ld, int64_t rows, const int32_t* m
 int band_split(const BandSplitParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(p.target && p.head_pick && p.n_bands >= 1 && p.n_bands <= 8, "band_split: bad arguments");
     GNNLM_REQUIRE(p.n_bands == 1 || (p.band_rows && p.band_pick && p.band_count), "band_split: null band outputs");
-    hipLaunchKernelGGL(band_split_kernel, dim3(1), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(band_split_kernel, dim3(1), dim3(256), 0, stream, p);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }
