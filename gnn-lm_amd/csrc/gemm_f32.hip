@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
                 for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
                 float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) s += v[j] == -INFINITY ? 0.f : expf(v[j] - mx);
+                for (int j = 0; j < TN; ++j) s += v[j] == -INFINITY ? 0.f : __expf(v[j] - mx);   // v_exp_f32: arg <= 0, rel. err ~1e-7
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
                 if (l32 == 0 && row < M) {
