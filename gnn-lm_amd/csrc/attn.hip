@@ -12,6 +12,8 @@
 //        (group, head), operands live in registers.
 //   ('tgt','intra','tgt')    causal_softmax : dense causal attention over the block; the two
 //        contractions run on the GEMM kernel, this is the masked row softmax in between.
+#include <algorithm>
+#include <cstdlib>
 #include "kernels.h"
 
 namespace gnnlm {
@@ -238,6 +240,172 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Chunk-swept star attention for the PQ source (layer 1): k_g <= 128, dsub in {4, 8}, D in {512, 1024},
+// <= 8 heads per launch.
+//
+// The generic kernel above lets every lane own a fixed slice of the 1-MiB centroid table, so a wave's
+// gathers spray over the whole table: every 32-B row costs a 128-B line from L2 (measured 1.57 ms per
+// 8192 tokens; 50 % of the wave time is spent in s_waitcnt, TA stalled by the L2).  Here the four waves of
+// a workgroup sweep the feature dimension in 32-dim chunks together.  Per chunk the token's 128 x 32 slab
+// of decoded neighbour features is built ONCE in LDS by all 256 threads (4 independent 16-B gathers per
+// thread, all inside the chunk's 4 sub-tables = 32 KiB, which stay in the CU's L1), double-buffered so the
+// gathers of chunk c+1 fly under the math of chunk c; the math itself only reads LDS.
+//   pass 1: lane = (dq, ng) (float4 of the chunk, neighbour group); acc[it][h] += x . U[h]; the partial
+//           dot products are reduced over the 8 dq-lanes ONCE per token (96 DPP shuffles).
+//   softmax per head over the neighbours (LDS).
+//   pass 2: wave w owns heads 2w, 2w+1 for ALL neighbours; lane = (dq, head, neighbour group of 4); two
+//           xor-shuffle steps (fixed order, deterministic) finish a chunk, whose 128-B pieces of Z are
+//           stored straight away -- 4 accumulator registers, no cross-wave reduction.
+template <int DSUB, int NCH>
+__global__ __launch_bounds__(256, 3) void star_attn_sweep_kernel(StarAttnParams p, int h0) {
+    constexpr int CD = 32;                     // dims per chunk
+    constexpr int D = NCH * CD;
+    constexpr int KGM = 128;
+    constexpr int SCS = KGM + 4;                // score row stride: heads land on different banks
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xc = smem;                                              // [2][KGM][CD] decoded slabs
+    float* sc = smem + 2 * KGM * CD;                               // [HB][SCS] scores -> alphas
+    uint8_t* lcodes = reinterpret_cast<uint8_t*>(sc + HB * SCS);  // [KGM][M + 4]: rows 33 dwords apart (conflict-free column reads)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x;
+    const int kg = p.kg, M = p.M, H = p.H;
+    const int MS = M + 4;                       // padded code row stride (bytes)
+    const int64_t* ids = p.ids + (int64_t)i * kg;
+
+    {   // stage the code rows (zeros for invalid neighbours): 16-B global pieces, coalesced
+        const int per_row = M >> 4;
+        for (int e = tid; e < KGM * per_row; e += 256) {
+            const int j = e / per_row, part = e - j * per_row;
+            const int64_t id = j < kg ? ids[j] : -1;
+            const int64_t lrow = p.codes_direct ? ((int64_t)i * kg + j) * p.codes_direct : id - p.row0;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (id >= 0) v = *reinterpret_cast<const uint4*>(p.codes + lrow * M + 16 * part);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(lcodes + j * MS + 16 * part);
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    }
+    __syncthreads();
+
+    const float* cen = p.centroids;
+    // slab builder: thread t decodes float4 `t & 7` of the four neighbours (t >> 3) + 32 q.  For a fixed q
+    // consecutive lanes write consecutive 16-B pieces (conflict-free ds_write_b128) and lane pairs fetch the
+    // two halves of one 32-B centroid row.
+    const int ddq = tid & 7, dj0 = tid >> 3;
+    const int dm_in = (4 * ddq) / DSUB, dwithin = (4 * ddq) % DSUB;
+    float4 xr0, xr1, xr2, xr3;
+#define GNNLM_FETCH1(XR, Q, c)                                                                          \
+    {                                                                                                   \
+        const int m_ = (c) * (CD / DSUB) + dm_in;                                                       \
+        XR = *reinterpret_cast<const float4*>(                                                          \
+            cen + ((int64_t)(m_ * 256 + lcodes[(dj0 + 32 * (Q)) * MS + m_])) * DSUB + dwithin);         \
+    }
+#define GNNLM_FETCH(c) { GNNLM_FETCH1(xr0, 0, c) GNNLM_FETCH1(xr1, 1, c) GNNLM_FETCH1(xr2, 2, c) GNNLM_FETCH1(xr3, 3, c) }
+#define GNNLM_COMMIT(buf)                                                                               \
+    {                                                                                                   \
+        float* d_ = xc + ((buf) * KGM + dj0) * CD + 4 * ddq;                                            \
+        *reinterpret_cast<float4*>(d_) = xr0;                                                           \
+        *reinterpret_cast<float4*>(d_ + 32 * CD) = xr1;                                                 \
+        *reinterpret_cast<float4*>(d_ + 64 * CD) = xr2;                                                 \
+        *reinterpret_cast<float4*>(d_ + 96 * CD) = xr3;                                                 \
+    }
+
+    // ---------------- pass 1
+    {
+        const int dq = lane & 7, ng = lane >> 3;
+        float acc[4][HB];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int h = 0; h < HB; ++h) acc[it][h] = 0.f;
+        const float* Ui = p.U + ((int64_t)i * H + h0) * D + 4 * dq;
+        float4 u[HB], un[HB];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) un[h] = *reinterpret_cast<const float4*>(Ui + (int64_t)min(h, H - 1 - h0) * D);
+        GNNLM_FETCH(0);
+        GNNLM_COMMIT(0);
+        __syncthreads();
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int h = 0; h < HB; ++h) u[h] = un[h];
+            if (c + 1 < NCH) {
+                GNNLM_FETCH(c + 1);
+#pragma unroll
+                for (int h = 0; h < HB; ++h)
+                    un[h] = *reinterpret_cast<const float4*>(Ui + (int64_t)min(h, H - 1 - h0) * D + (c + 1) * CD);
+            }
+            const float* xb = xc + ((c & 1) * KGM + 32 * wave + ng) * CD + 4 * dq;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float4 x = *reinterpret_cast<const float4*>(xb + 8 * it * CD);
+#pragma unroll
+                for (int h = 0; h < HB; ++h)
+                    acc[it][h] = fmaf(x.x, u[h].x, fmaf(x.y, u[h].y, fmaf(x.z, u[h].z, fmaf(x.w, u[h].w, acc[it][h]))));
+            }
+            if (c + 1 < NCH) GNNLM_COMMIT((c + 1) & 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int j = 32 * wave + ng + 8 * it;
+            const bool ok = j < kg && ids[j] >= 0;
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                float v = acc[it][h];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                if (dq == 0) sc[h * SCS + j] = ok ? v : -INFINITY;
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------- softmax over j per head (wave w: heads w, w+4)
+    for (int h = wave; h < HB; h += 4) {
+        const float v0 = sc[h * SCS + lane], v1 = sc[h * SCS + 64 + lane];
+        const float mx = wave_max(fmaxf(v0, v1));
+        const float e0 = v0 == -INFINITY ? 0.f : expf(v0 - mx), e1 = v1 == -INFINITY ? 0.f : expf(v1 - mx);
+        const float sum = wave_sum(e0 + e1);
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+        sc[h * SCS + lane] = e0 * inv;
+        sc[h * SCS + 64 + lane] = e1 * inv;
+        if (h == 0 && h0 == 0 && lane == 0 && p.has_nb) p.has_nb[i] = sum > 0.f ? 1.f : 0.f;
+    }
+    // ---------------- pass 2: wave w owns heads 2w, 2w+1 over ALL neighbours; lane = (dq, hh, ng)
+    {
+        const int dq = lane & 7, hh = (lane >> 3) & 1, ng = lane >> 4;
+        const int h = 2 * wave + hh;
+        const float* al = sc + h * SCS;
+        GNNLM_FETCH(0);
+        GNNLM_COMMIT(0);
+        __syncthreads();                       // also orders the softmax writes before the alpha reads
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) GNNLM_FETCH(c + 1);
+            const float* xb = xc + ((c & 1) * KGM + ng) * CD + 4 * dq;
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int jj = 0; jj < 32; ++jj) {
+                const float4 x = *reinterpret_cast<const float4*>(xb + 4 * jj * CD);
+                const float a = al[ng + 4 * jj];
+                z.x = fmaf(a, x.x, z.x); z.y = fmaf(a, x.y, z.y);
+                z.z = fmaf(a, x.z, z.z); z.w = fmaf(a, x.w, z.w);
+            }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {            // reduce the 4 neighbour groups (fixed order)
+                z.x += __shfl_xor(z.x, o, 64); z.y += __shfl_xor(z.y, o, 64);
+                z.z += __shfl_xor(z.z, o, 64); z.w += __shfl_xor(z.w, o, 64);
+            }
+            if (ng == 0 && h0 + h < H)
+                *reinterpret_cast<float4*>(p.Z + ((int64_t)i * H + h0 + h) * D + c * CD + 4 * dq) = z;
+            if (c + 1 < NCH) GNNLM_COMMIT((c + 1) & 1);
+            __syncthreads();
+        }
+    }
+#undef GNNLM_FETCH
+#undef GNNLM_FETCH1
+#undef GNNLM_COMMIT
+}
+
 constexpr int MAX_NG = 8;
 constexpr int MAX_EPT = 4;
 
@@ -360,6 +528,20 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(shmem <= 160 * 1024, "star_attn: kg too large for LDS");
     const int nq = p.D / 4;
     const double rows = (double)p.T * p.kg;
+    if (p.codes && p.kg <= 128 && (p.dsub == 4 || p.dsub == 8) && p.M % 16 == 0 && (p.D == 1024 || p.D == 512) &&
+        (uintptr_t)p.codes % 16 == 0 && !getenv("GNNLM_STAR_GENERIC")) {
+        ProfScope prof(K_STAR, stream, 4.0 * rows * p.H * p.D, rows * (8.0 + p.M) + 8.0 * p.T * p.H * p.D);
+        const size_t lds = (size_t)(HB * 132 + 2 * 128 * 32) * sizeof(float) + (size_t)128 * (p.M + 4);
+        dim3 grid(p.T), block(256);
+        for (int h0 = 0; h0 < p.H; h0 += HB) {
+            if (p.dsub == 8 && p.D == 1024) hipLaunchKernelGGL((star_attn_sweep_kernel<8, 32>), grid, block, lds, stream, p, h0);
+            else if (p.dsub == 8) hipLaunchKernelGGL((star_attn_sweep_kernel<8, 16>), grid, block, lds, stream, p, h0);
+            else if (p.D == 1024) hipLaunchKernelGGL((star_attn_sweep_kernel<4, 32>), grid, block, lds, stream, p, h0);
+            else hipLaunchKernelGGL((star_attn_sweep_kernel<4, 16>), grid, block, lds, stream, p, h0);
+        }
+        GNNLM_LAUNCH_CHECK();
+        return OK;
+    }
     ProfScope prof(K_STAR, stream, 4.0 * rows * p.H * p.D,
                    rows * (8.0 + (p.codes ? (double)p.M : 4.0 * p.D)) + 8.0 * p.T * p.H * p.D);
     dim3 grid(p.T), block(256);
