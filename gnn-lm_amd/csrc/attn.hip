@@ -257,20 +257,28 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
 //   pass 2: wave w owns heads 2w, 2w+1 for ALL neighbours; lane = (dq, head, neighbour group of 4); two
 //           xor-shuffle steps (fixed order, deterministic) finish a chunk, whose 128-B pieces of Z are
 //           stored straight away -- 4 accumulator registers, no cross-wave reduction.
-template <int DSUB, int NCH>
-__global__ __launch_bounds__(256, 3) void star_attn_sweep_kernel(StarAttnParams p, int h0) {
-    constexpr int CD = 32;                     // dims per chunk
-    constexpr int D = NCH * CD;
+template <int DSUB, int CD, int KT>
+__global__ __launch_bounds__(256 * KT) void star_attn_sweep_kernel(StarAttnParams p, int h0) {
+    // KT tokens per workgroup (256 threads each) sweep the chunks in lockstep so that a chunk's sub-tables
+    // (CD/DSUB x 8 KiB) could serve all KT tokens from the CU's L1.  Measured: it does not pay (the wider
+    // barriers cost more than the L1 reuse saves), KT = 1 is the default; the template stays for re-tuning.
     constexpr int KGM = 128;
+    constexpr int NDQ = CD / 4;                 // float4 per chunk row (4 or 8)
     constexpr int SCS = KGM + 4;                // score row stride: heads land on different banks
+    constexpr int NG1 = 64 / NDQ, ITS = 32 / NG1;          // pass 1: neighbour groups per wave, iterations
+    constexpr int NG2 = 32 / NDQ, JJ2 = KGM / NG2;         // pass 2: neighbour groups (2 heads per wave)
+    constexpr int NF = KGM * NDQ / 256;         // float4 decoded per thread per chunk (2 or 4)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xc = smem;                                              // [2][KGM][CD] decoded slabs
-    float* sc = smem + 2 * KGM * CD;                               // [HB][SCS] scores -> alphas
-    uint8_t* lcodes = reinterpret_cast<uint8_t*>(sc + HB * SCS);  // [KGM][M + 4]: rows 33 dwords apart (conflict-free column reads)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = blockIdx.x;
+    const int D = p.D, NCH = D / CD;
     const int kg = p.kg, M = p.M, H = p.H;
-    const int MS = M + 4;                       // padded code row stride (bytes)
+    const int MS = M + 4;                       // padded code row stride (bytes): conflict-free column reads
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const size_t grp_floats = 2 * KGM * CD + HB * SCS + (size_t)(KGM * MS + 3) / 4;
+    float* xc = smem + grp * grp_floats;                            // [2][KGM][CD] decoded slabs
+    float* sc = xc + 2 * KGM * CD;                                  // [HB][SCS] scores -> alphas
+    uint8_t* lcodes = reinterpret_cast<uint8_t*>(sc + HB * SCS);    // [KGM][MS]
+    const int i = min(KT * (int)blockIdx.x + grp, p.T - 1);         // surplus groups redo the last token
+    const bool live = KT * (int)blockIdx.x + grp < p.T;
     const int64_t* ids = p.ids + (int64_t)i * kg;
 
     {   // stage the code rows (zeros for invalid neighbours): 16-B global pieces, coalesced
@@ -288,56 +296,55 @@ __global__ __launch_bounds__(256, 3) void star_attn_sweep_kernel(StarAttnParams 
     __syncthreads();
 
     const float* cen = p.centroids;
-    // slab builder: thread t decodes float4 `t & 7` of the four neighbours (t >> 3) + 32 q.  For a fixed q
-    // consecutive lanes write consecutive 16-B pieces (conflict-free ds_write_b128) and lane pairs fetch the
-    // two halves of one 32-B centroid row.
-    const int ddq = tid & 7, dj0 = tid >> 3;
+    // slab builder: thread t decodes float4 `t % NDQ` of the neighbours (t / NDQ) + (256/NDQ) q.  For a fixed
+    // q consecutive lanes write consecutive 16-B pieces (conflict-free ds_write_b128) and lane pairs fetch
+    // the two halves of one 32-B centroid row.
+    const int ddq = tid % NDQ, dj0 = tid / NDQ;
     const int dm_in = (4 * ddq) / DSUB, dwithin = (4 * ddq) % DSUB;
     float4 xr0, xr1, xr2, xr3;
-#define GNNLM_FETCH1(XR, Q, c)                                                                          \
+    xr2 = xr3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define GNNLM_FETCH1(XR, Q, m_)                                                                         \
+    XR = *reinterpret_cast<const float4*>(                                                              \
+        cen + ((int64_t)((m_) * 256 + lcodes[(dj0 + (256 / NDQ) * (Q)) * MS + (m_)])) * DSUB + dwithin);
+#define GNNLM_FETCH(c)                                                                                  \
     {                                                                                                   \
         const int m_ = (c) * (CD / DSUB) + dm_in;                                                       \
-        XR = *reinterpret_cast<const float4*>(                                                          \
-            cen + ((int64_t)(m_ * 256 + lcodes[(dj0 + 32 * (Q)) * MS + m_])) * DSUB + dwithin);         \
+        GNNLM_FETCH1(xr0, 0, m_) GNNLM_FETCH1(xr1, 1, m_)                                               \
+        if constexpr (NF > 2) { GNNLM_FETCH1(xr2, 2, m_) GNNLM_FETCH1(xr3, 3, m_) }                     \
     }
-#define GNNLM_FETCH(c) { GNNLM_FETCH1(xr0, 0, c) GNNLM_FETCH1(xr1, 1, c) GNNLM_FETCH1(xr2, 2, c) GNNLM_FETCH1(xr3, 3, c) }
 #define GNNLM_COMMIT(buf)                                                                               \
     {                                                                                                   \
         float* d_ = xc + ((buf) * KGM + dj0) * CD + 4 * ddq;                                            \
         *reinterpret_cast<float4*>(d_) = xr0;                                                           \
-        *reinterpret_cast<float4*>(d_ + 32 * CD) = xr1;                                                 \
-        *reinterpret_cast<float4*>(d_ + 64 * CD) = xr2;                                                 \
-        *reinterpret_cast<float4*>(d_ + 96 * CD) = xr3;                                                 \
+        *reinterpret_cast<float4*>(d_ + (256 / NDQ) * CD) = xr1;                                        \
+        if constexpr (NF > 2) {                                                                         \
+            *reinterpret_cast<float4*>(d_ + 2 * (256 / NDQ) * CD) = xr2;                                \
+            *reinterpret_cast<float4*>(d_ + 3 * (256 / NDQ) * CD) = xr3;                                \
+        }                                                                                               \
     }
 
-    // ---------------- pass 1
+    // ---------------- pass 1: lane = (dq, ng); acc[it][h] += x . U[h]
     {
-        const int dq = lane & 7, ng = lane >> 3;
-        float acc[4][HB];
+        const int dq = lane % NDQ, ng = lane / NDQ;
+        float acc[ITS][HB];
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < ITS; ++it)
 #pragma unroll
             for (int h = 0; h < HB; ++h) acc[it][h] = 0.f;
         const float* Ui = p.U + ((int64_t)i * H + h0) * D + 4 * dq;
-        float4 u[HB], un[HB];
-#pragma unroll
-        for (int h = 0; h < HB; ++h) un[h] = *reinterpret_cast<const float4*>(Ui + (int64_t)min(h, H - 1 - h0) * D);
         GNNLM_FETCH(0);
         GNNLM_COMMIT(0);
         __syncthreads();
         for (int c = 0; c < NCH; ++c) {
+            float4 u[HB];
 #pragma unroll
-            for (int h = 0; h < HB; ++h) u[h] = un[h];
-            if (c + 1 < NCH) {
-                GNNLM_FETCH(c + 1);
-#pragma unroll
-                for (int h = 0; h < HB; ++h)
-                    un[h] = *reinterpret_cast<const float4*>(Ui + (int64_t)min(h, H - 1 - h0) * D + (c + 1) * CD);
-            }
+            for (int h = 0; h < HB; ++h)
+                u[h] = *reinterpret_cast<const float4*>(Ui + (int64_t)min(h, H - 1 - h0) * D + c * CD);
+            if (c + 1 < NCH) GNNLM_FETCH(c + 1);
             const float* xb = xc + ((c & 1) * KGM + 32 * wave + ng) * CD + 4 * dq;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const float4 x = *reinterpret_cast<const float4*>(xb + 8 * it * CD);
+            for (int it = 0; it < ITS; ++it) {
+                const float4 x = *reinterpret_cast<const float4*>(xb + NG1 * it * CD);
 #pragma unroll
                 for (int h = 0; h < HB; ++h)
                     acc[it][h] = fmaf(x.x, u[h].x, fmaf(x.y, u[h].y, fmaf(x.z, u[h].z, fmaf(x.w, u[h].w, acc[it][h]))));
@@ -346,15 +353,14 @@ __global__ __launch_bounds__(256, 3) void star_attn_sweep_kernel(StarAttnParams 
             __syncthreads();
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int j = 32 * wave + ng + 8 * it;
+        for (int it = 0; it < ITS; ++it) {
+            const int j = 32 * wave + ng + NG1 * it;
             const bool ok = j < kg && ids[j] >= 0;
 #pragma unroll
             for (int h = 0; h < HB; ++h) {
                 float v = acc[it][h];
-                v += __shfl_xor(v, 1, 64);
-                v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64);
+#pragma unroll
+                for (int o = 1; o < NDQ; o <<= 1) v += __shfl_xor(v, o, 64);
                 if (dq == 0) sc[h * SCS + j] = ok ? v : -INFINITY;
             }
         }
@@ -369,11 +375,11 @@ __global__ __launch_bounds__(256, 3) void star_attn_sweep_kernel(StarAttnParams 
         const float inv = sum > 0.f ? 1.f / sum : 0.f;
         sc[h * SCS + lane] = e0 * inv;
         sc[h * SCS + 64 + lane] = e1 * inv;
-        if (h == 0 && h0 == 0 && lane == 0 && p.has_nb) p.has_nb[i] = sum > 0.f ? 1.f : 0.f;
+        if (h == 0 && h0 == 0 && lane == 0 && p.has_nb && live) p.has_nb[i] = sum > 0.f ? 1.f : 0.f;
     }
     // ---------------- pass 2: wave w owns heads 2w, 2w+1 over ALL neighbours; lane = (dq, hh, ng)
     {
-        const int dq = lane & 7, hh = (lane >> 3) & 1, ng = lane >> 4;
+        const int dq = lane % NDQ, hh = (lane / NDQ) & 1, ng = lane / (2 * NDQ);
         const int h = 2 * wave + hh;
         const float* al = sc + h * SCS;
         GNNLM_FETCH(0);
@@ -384,18 +390,18 @@ __global__ __launch_bounds__(256, 3) void star_attn_sweep_kernel(StarAttnParams 
             const float* xb = xc + ((c & 1) * KGM + ng) * CD + 4 * dq;
             float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-            for (int jj = 0; jj < 32; ++jj) {
-                const float4 x = *reinterpret_cast<const float4*>(xb + 4 * jj * CD);
-                const float a = al[ng + 4 * jj];
+            for (int jj = 0; jj < JJ2; ++jj) {
+                const float4 x = *reinterpret_cast<const float4*>(xb + NG2 * jj * CD);
+                const float a = al[ng + NG2 * jj];
                 z.x = fmaf(a, x.x, z.x); z.y = fmaf(a, x.y, z.y);
                 z.z = fmaf(a, x.z, z.z); z.w = fmaf(a, x.w, z.w);
             }
 #pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {            // reduce the 4 neighbour groups (fixed order)
+            for (int o = 2 * NDQ; o < 64; o <<= 1) {        // reduce the neighbour groups (fixed order)
                 z.x += __shfl_xor(z.x, o, 64); z.y += __shfl_xor(z.y, o, 64);
                 z.z += __shfl_xor(z.z, o, 64); z.w += __shfl_xor(z.w, o, 64);
             }
-            if (ng == 0 && h0 + h < H)
+            if (ng == 0 && h0 + h < H && live)
                 *reinterpret_cast<float4*>(p.Z + ((int64_t)i * H + h0 + h) * D + c * CD + 4 * dq) = z;
             if (c + 1 < NCH) GNNLM_COMMIT((c + 1) & 1);
             __syncthreads();
@@ -528,16 +534,29 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(shmem <= 160 * 1024, "star_attn: kg too large for LDS");
     const int nq = p.D / 4;
     const double rows = (double)p.T * p.kg;
-    if (p.codes && p.kg <= 128 && (p.dsub == 4 || p.dsub == 8) && p.M % 16 == 0 && (p.D == 1024 || p.D == 512) &&
+    if (p.codes && p.kg <= 128 && (p.dsub == 4 || p.dsub == 8) && p.M % 16 == 0 && p.D % 32 == 0 &&
         (uintptr_t)p.codes % 16 == 0 && !getenv("GNNLM_STAR_GENERIC")) {
         ProfScope prof(K_STAR, stream, 4.0 * rows * p.H * p.D, rows * (8.0 + p.M) + 8.0 * p.T * p.H * p.D);
-        const size_t lds = (size_t)(HB * 132 + 2 * 128 * 32) * sizeof(float) + (size_t)128 * (p.M + 4);
-        dim3 grid(p.T), block(256);
+        // tokens per workgroup: 1 measured fastest (T = 8192: KT=1 1.42 ms, KT=2 1.74 ms, KT=4 1.79 ms; generic 1.57 ms)
+        static const int kt = getenv("GNNLM_STAR_KT") ? atoi(getenv("GNNLM_STAR_KT")) : 1;
+        const int MS = p.M + 4;
+        auto lds_bytes = [&](int cd, int k) {
+            return (size_t)k * 4 * (2 * 128 * cd + HB * 132 + (size_t)(128 * MS + 3) / 4);
+        };
         for (int h0 = 0; h0 < p.H; h0 += HB) {
-            if (p.dsub == 8 && p.D == 1024) hipLaunchKernelGGL((star_attn_sweep_kernel<8, 32>), grid, block, lds, stream, p, h0);
-            else if (p.dsub == 8) hipLaunchKernelGGL((star_attn_sweep_kernel<8, 16>), grid, block, lds, stream, p, h0);
-            else if (p.D == 1024) hipLaunchKernelGGL((star_attn_sweep_kernel<4, 32>), grid, block, lds, stream, p, h0);
-            else hipLaunchKernelGGL((star_attn_sweep_kernel<4, 16>), grid, block, lds, stream, p, h0);
+            if (kt == 4) {
+                dim3 grid((p.T + 3) / 4), block(1024);
+                if (p.dsub == 8) hipLaunchKernelGGL((star_attn_sweep_kernel<8, 16, 4>), grid, block, lds_bytes(16, 4), stream, p, h0);
+                else hipLaunchKernelGGL((star_attn_sweep_kernel<4, 16, 4>), grid, block, lds_bytes(16, 4), stream, p, h0);
+            } else if (kt == 2) {
+                dim3 grid((p.T + 1) / 2), block(512);
+                if (p.dsub == 8) hipLaunchKernelGGL((star_attn_sweep_kernel<8, 32, 2>), grid, block, lds_bytes(32, 2), stream, p, h0);
+                else hipLaunchKernelGGL((star_attn_sweep_kernel<4, 32, 2>), grid, block, lds_bytes(32, 2), stream, p, h0);
+            } else {
+                dim3 grid(p.T), block(256);
+                if (p.dsub == 8) hipLaunchKernelGGL((star_attn_sweep_kernel<8, 32, 1>), grid, block, lds_bytes(32, 1), stream, p, h0);
+                else hipLaunchKernelGGL((star_attn_sweep_kernel<4, 32, 1>), grid, block, lds_bytes(32, 1), stream, p, h0);
+            }
         }
         GNNLM_LAUNCH_CHECK();
         return OK;
