@@ -135,8 +135,9 @@ int linear(const float* A, int64_t lda, const float* W, const float* bias, float
 int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, size_t ws_bytes, hipStream_t s) {
     GNNLM_REQUIRE(m.layers && m.n_layers >= 1, "hgt: no layers");
     GNNLM_REQUIRE(m.d > 0 && m.n_heads > 0 && m.d % m.n_heads == 0, "hgt: d must be divisible by n_heads");
-    GNNLM_REQUIRE(io.tgt_feats && io.ids && io.out_tgt, "hgt: null io");
     GNNLM_REQUIRE(io.n_blocks >= 0 && io.T >= 0 && io.kg > 0, "hgt: bad io shape");
+    if ((int64_t)io.n_blocks * io.T == 0) return OK;                 // empty batch: nothing to do
+    GNNLM_REQUIRE(io.tgt_feats && io.ids && io.out_tgt, "hgt: null io");
     GNNLM_REQUIRE(m.centroids && m.M > 0 && m.dsub > 0, "hgt: codec missing");
     GNNLM_REQUIRE(io.fetched_codes || m.codes, "hgt: no code store");
     const bool ntgt = needs_ntgt(m, io);

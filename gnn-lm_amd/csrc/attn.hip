@@ -64,7 +64,9 @@ __device__ __forceinline__ float reduce8(const float (&v)[HB], int lane) {
 // per workgroup, 1 workgroup per CU).  The L2 gather below moves a 128-B line per 32 useful bytes but keeps
 // 8 waves per CU in flight; it stays until a formulation with >= 2 workgroups per CU is found.
 template <int QPL>
-__global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
+__global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool stage_codes) {
+    // stage_codes = false (k_g too large for LDS, e.g. the k_g = 1024 stress): code bytes are read from
+    // the store directly
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sc = smem;                               // [HB][kg] scores, then alphas
     float* zred = smem + HB * p.kg;                 // [HB][D]  cross-wave reduction of Z
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
     const int q_per_m = p.codes ? p.dsub / 4 : 1;
 
     for (int j = tid; j < kg; j += 256) okf[j] = ids[j] >= 0;
-    if (p.codes) {
+    if (p.codes && stage_codes) {
         if ((M & 15) == 0) {
             const int per_row = M >> 4;
             for (int e = tid; e < kg * per_row; e += 256) {
@@ -110,8 +112,14 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p) {
                 if (p.codes) {
                     const int m = q / q_per_m;
                     const int within = (q - m * q_per_m) * 4;
-                    x[t] = *reinterpret_cast<const float4*>(
-                        p.centroids + ((int64_t)(m * 256 + lcodes[j * M + m])) * p.dsub + within);
+                    int code;
+                    if (stage_codes) {
+                        code = lcodes[j * M + m];
+                    } else {
+                        const int64_t lrow = p.codes_direct ? ((int64_t)i * kg + j) * p.codes_direct : ids[j] - p.row0;
+                        code = p.codes[lrow * M + m];
+                    }
+                    x[t] = *reinterpret_cast<const float4*>(p.centroids + ((int64_t)(m * 256 + code)) * p.dsub + within);
                 } else {
                     x[t] = *reinterpret_cast<const float4*>(p.X + ((int64_t)i * kg + j) * p.x_group_stride * p.ldx + 4 * q);
                 }
@@ -529,8 +537,10 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
         GNNLM_REQUIRE(p.ldx % 4 == 0 && (uintptr_t)p.X % 16 == 0, "star_attn: X alignment");
     }
     if (p.T == 0) return OK;
-    const size_t shmem = (size_t)(HB * p.kg + HB * p.D + ((p.kg + 3) & ~3)) * sizeof(float) +
-                         (p.codes ? (((size_t)p.kg * p.M + 15) & ~size_t(15)) : 0);
+    const size_t base_lds = (size_t)(HB * p.kg + HB * p.D + ((p.kg + 3) & ~3)) * sizeof(float);
+    const size_t code_lds = p.codes ? (((size_t)p.kg * p.M + 15) & ~size_t(15)) : 0;
+    const bool stage = base_lds + code_lds <= 64 * 1024;          // keep >= 2 workgroups per CU
+    const size_t shmem = base_lds + (stage ? code_lds : 0);
     GNNLM_REQUIRE(shmem <= 160 * 1024, "star_attn: kg too large for LDS");
     const int nq = p.D / 4;
     const double rows = (double)p.T * p.kg;
@@ -565,11 +575,11 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
                    rows * (8.0 + (p.codes ? (double)p.M : 4.0 * p.D)) + 8.0 * p.T * p.H * p.D);
     dim3 grid(p.T), block(256);
     if (nq <= 64) {
-        hipLaunchKernelGGL(star_attn_kernel<1>, grid, block, shmem, stream, p);
+        hipLaunchKernelGGL(star_attn_kernel<1>, grid, block, shmem, stream, p, stage);
     } else if (nq <= 128) {
-        hipLaunchKernelGGL(star_attn_kernel<2>, grid, block, shmem, stream, p);
+        hipLaunchKernelGGL(star_attn_kernel<2>, grid, block, shmem, stream, p, stage);
     } else {
-        hipLaunchKernelGGL(star_attn_kernel<4>, grid, block, shmem, stream, p);
+        hipLaunchKernelGGL(star_attn_kernel<4>, grid, block, shmem, stream, p, stage);
     }
     GNNLM_LAUNCH_CHECK();
     return OK;

@@ -145,13 +145,9 @@ def test_sequence_scorer_golden(dev, golden, tmp_path, keytype, lmbda, temp):
             assert h["knn_recall"] is None
 
 
-def test_eval_lm_end_to_end(dev, tmp_path):
-    """A synthetic data directory in the reference's on-disk formats -> the driver's ppl equals the
-    oracle's (float32 accumulation differences aside), with and without kNN, incl. a ragged last block."""
-    from gnnlm_amd import eval_lm
-    from gnnlm_amd.knn_model import ExactIndex, KNNModel
+def make_data_dir(tmp_path):
+    """A synthetic data directory in the reference's on-disk formats + a reference-style checkpoint."""
     from gnnlm_amd.synthetic import make_problem
-    from oracle import knn as oknn_, pipeline
     d, H, M, dsub, V, kg, T, L = 64, 4, 16, 4, 600, 6, 16, 2
     n_train, n_test = 2000, 41                      # 41 = 2 full blocks + a 9-token block
     prob = make_problem(n_store=n_train, d=d, n_heads=H, M=M, dsub=dsub, vocab=V, cutoff=[100, 300], T=n_test, kg=kg,
@@ -182,9 +178,43 @@ def test_eval_lm_end_to_end(dev, tmp_path):
             "--gcn-k", str(kg), "--use-precompute-feat", "--sample-break-mode", "none", "--max-tokens", str(2 * T),
             "--tokens-per-sample", str(T), "--gcn-context-window", "0", "--knn-keytype", "gcn_feat",
             "--model-overrides", "{'orig_prob_ratio': 0.0}"]
-    # oracle, block by block
     model = {"sd": prob["sd"], "n_layers": L, "n_heads": H, "centroids": prob["cen"], "A": prob["A"], "b": prob["b"],
              "codes": prob["codes"], "vals": prob["vals"], "n_store": n_train, "left": 2, "right": 2, "asm": w}
+    return dict(prob=prob, blk=blk, data=data, base=base, model=model, train_keys=train_keys, T=T, n_test=n_test,
+                n_train=n_train, w=w, L=L, H=H)
+
+
+def test_eval_lm_gcn_context_window(dev, tmp_path):
+    """--gcn-context-window w: every block is prefixed by the w previous tokens, which take part in the
+    graph but are not scored (token_block_dataset.py:264-285,331; sequence_scorer.py:156-162)."""
+    from gnnlm_amd import eval_lm
+    from oracle import pipeline
+    c = make_data_dir(tmp_path)
+    blk, T, n_test, w_ctx = c["blk"], c["T"], c["n_test"], 5
+    total = 0.0
+    for s in range(0, n_test, T):
+        e = min(n_test, s + T)
+        cs = max(0, s - w_ctx) if s > 0 else s
+        one = {"neighbor_idxs": blk["ids"][cs:e], "tgt_feats": blk["tgt_feats"][cs:e], "targets": blk["targets"][cs:e],
+               "knn_sims": None, "knn_ids": None}
+        total += pipeline.eval_block(one, c["model"], 0.0, 1.0)["lm_logp"][s - cs:].double().sum().item()
+    base = list(c["base"])
+    base[base.index("--gcn-context-window") + 1] = str(w_ctx)
+    base[base.index("--max-tokens") + 1] = str(T + w_ctx)
+    res = eval_lm.cli_main(base)
+    assert res["count"] == n_test
+    assert abs(res["score_sum"] - total) < 1e-4 * n_test
+
+
+def test_eval_lm_end_to_end(dev, tmp_path):
+    """A synthetic data directory in the reference's on-disk formats -> the driver's ppl equals the
+    oracle's (float32 accumulation differences aside), with and without kNN, incl. a ragged last block."""
+    from gnnlm_amd import eval_lm
+    from oracle import knn as oknn_, pipeline
+    c = make_data_dir(tmp_path)
+    prob, blk, data, base, model, train_keys = c["prob"], c["blk"], c["data"], c["base"], c["model"], c["train_keys"]
+    T, n_test, L, H, w = c["T"], c["n_test"], c["L"], c["H"], c["w"]
+    # oracle, block by block
     lam, temp, k = 0.25, 1.0, 8
     ref_lm, ref_mix = [], []
     for s in range(0, n_test, T):
