@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=384)
     ap.add_argument("--small", action="store_true", help="tiny shapes (plumbing check only)")
+    ap.add_argument("--shard-vals", action="store_true", help="also range-shard the label table (default: replicated)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the sharded-store exchange even with one rank (exercises the RCCL path on one GPU)")
     return ap.parse_args()
 
 
@@ -74,7 +77,7 @@ def build(args, dev, rank, world):
         d, H, M, dsub, vocab, cutoff = 1024, 8, 128, 8, 267744, [20000, 60000]
     rs = np.random.RandomState(1234)
     cen, A, b = make_codec(rs, M, dsub, d, opq=True)
-    sharded = world > 1 and args.store == "sharded"
+    sharded = (world > 1 or args.force_exchange) and args.store == "sharded"
     shard = Shard(args.n_store, world if sharded else 1, rank if sharded else 0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + shard.row0)
@@ -84,9 +87,15 @@ def build(args, dev, rank, world):
     for s in range(0, n_local, step):                                     # uint8 i.i.d. uniform
         e = min(n_local, s + step)
         codes[s:e] = torch.randint(0, 256, (e - s, M), generator=gen, device=dev, dtype=torch.uint8)
-    vals = zipf_dev(n_local, vocab, gen, dev).to(torch.int32)
+    # the label table (413 MB for WikiText-103) is replicated on every rank unless --shard-vals: only the
+    # 13.2-GB code table needs the range sharding, and replicated labels save the k=1024-per-token exchange
+    shard_vals = sharded and args.shard_vals
+    vgen = torch.Generator(device=dev)
+    vgen.manual_seed(4321 + (shard.row0 if shard_vals else 0))
+    vals = zipf_dev(n_local if shard_vals else args.n_store, vocab, vgen, dev).to(torch.int32)
     t = lambda a: torch.from_numpy(a).to(dev)
     store = CodeStore(codes=codes, centroids=t(cen), n_store=args.n_store, row0=shard.row0, vals=vals, A=t(A), b=t(b))
+    store.vals_row0 = shard.row0 if shard_vals else 0
     torch.manual_seed(1234)
     hgt = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=args.layers, n_heads=H)
     w = make_asm_weights(rs, vocab, d, cutoff)
@@ -151,8 +160,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if world > 1 or args.force_exchange:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from gnnlm_amd import _lib, ops
     from gnnlm_amd.dist import ShardedFetcher
@@ -166,24 +178,49 @@ def main():
     side = [torch.cuda.Stream(device=dev) for _ in range(args.streams - 1)]
     accs = [acc] + [torch.zeros(1, device=dev, dtype=torch.float64) for _ in side]
 
-    def score_one(b, a):
-        if fetcher is not None:                                   # RCCL all-to-all row fetch
-            b.fetched_codes, b.fetched_valid = fetcher.fetch_codes(b.ids, 2, 2, centres_only)
+    # Sharded store: the all-to-all row fetch of step i+1 runs on its own stream under the math of step i
+    # (the inputs of every step are known up front); RCCL orders itself after the stream it is issued on.
+    fetch_stream = torch.cuda.Stream(device=dev) if fetcher is not None else None
+    pending = {}
+
+    def issue_fetch(bi):
+        b = batches[bi % len(batches)]
+        with torch.cuda.stream(fetch_stream):
+            codes, valid, index = fetcher.fetch_codes(b.ids, 2, 2, centres_only)
+            kv = fetcher.fetch_knn_vals(b.knn_ids) if args.shard_vals else None
+            ev = torch.cuda.Event()
+            ev.record(fetch_stream)
+        pending[bi] = (codes, valid, index, kv, ev)
+
+    def score_one(bi, a, prefetch_next):
+        b = batches[bi % len(batches)]
+        if fetcher is not None:
+            if bi not in pending:
+                issue_fetch(bi)
+            codes, valid, index, kv, ev = pending.pop(bi)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for t in (codes, valid, index, kv):
+                if t is not None:
+                    t.record_stream(cur)
+            b.fetched_codes, b.fetched_valid, b.fetched_index, b.knn_vals = codes, valid, index, kv
             b.fetched_centres_only = centres_only
-            b.knn_vals = fetcher.fetch_knn_vals(b.knn_ids)
         out = eng.score(b, args.lmbda, args.temperature)
         ops.masked_sum_f64(out["logp"], None, a)                  # score_sum (eval_lm.py:273)
+        if fetcher is not None and prefetch_next is not None:
+            issue_fetch(prefetch_next)                            # host waits for the split sizes while the GPU computes
 
-    def step(i):
+    def step(i, last=False):
         main = torch.cuda.current_stream()
         for s_i in range(args.streams):
-            b = batches[(i * args.streams + s_i) % len(batches)]
+            bi = i * args.streams + s_i
+            nxt = None if (last or args.streams > 1) else bi + 1
             if s_i == 0:
-                score_one(b, accs[0])
+                score_one(bi, accs[0], nxt)
             else:
                 side[s_i - 1].wait_stream(main) if i == 0 else None
                 with torch.cuda.stream(side[s_i - 1]):
-                    score_one(b, accs[s_i])
+                    score_one(bi, accs[s_i], None)
 
     def barrier():
         torch.cuda.synchronize()                                  # all streams of this device
@@ -205,11 +242,12 @@ def main():
     # ---- timed region: exactly K steps, the dominant kernel bracketed by HIP events on its stream
     for a in accs:
         a.zero_()
+    pending.clear()                                               # nothing fetched ahead of the timed region
     barrier()
     _lib.profile_begin(1 << names.index(dominant))
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, last=(i == args.steps - 1))
     barrier()
     dt = time.perf_counter() - t0
     prof = _lib.profile_end()[dominant]
@@ -255,7 +293,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, cpu_model)
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

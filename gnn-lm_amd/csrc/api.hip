@@ -166,6 +166,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         g.codes = io.fetched_codes ? io.fetched_codes : m.codes;
         g.direct = io.fetched_codes ? 1 : 0;
         g.in_valid = io.fetched_valid;
+        g.in_index = io.fetched_index;
         g.vals = nullptr; g.vals_itemsize = 4;
         g.n_store = m.n_store; g.row0 = m.row0; g.n_local = m.n_local;
         g.M = m.M; g.dsub = m.dsub; g.centroids = m.centroids;
@@ -238,6 +239,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             if (l == 0) {
                 a.codes = io.fetched_codes ? io.fetched_codes : m.codes;
                 a.codes_direct = io.fetched_codes ? (io.fetched_centres_only ? 1 : n_g) : 0;
+                a.codes_index = io.fetched_codes ? io.fetched_index : nullptr;
                 a.row0 = m.row0; a.n_local = m.n_local; a.M = m.M; a.dsub = m.dsub; a.centroids = m.centroids;
             } else {
                 a.X = hn_cur; a.ldx = d; a.x_group_stride = n_g;
@@ -390,6 +392,10 @@ size_t gnnlm_sizeof(const char* name) {
 int gnnlm_gemm_nt(const gnnlm_gemm_t* d, void* stream) { GNNLM_DESC(d); return gemm_nt(*d, (hipStream_t)stream); }
 int gnnlm_lse_reduce(const float* part, int32_t n_parts, int64_t rows, const int32_t* m_dev, float* lse, void* stream) {
     return lse_reduce(part, n_parts, rows, m_dev, lse, (hipStream_t)stream);
+}
+int gnnlm_bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t rows_per_rank, int32_t world,
+                      int32_t self_rank, int64_t* counts, int64_t* cursor, int64_t* send_rows, int32_t* inv, void* stream) {
+    return bucket_rows(rows, n, n_store, rows_per_rank, world, self_rank, counts, cursor, send_rows, inv, (hipStream_t)stream);
 }
 int gnnlm_pq_gather_decode(const gnnlm_gather_t* d, void* stream) { GNNLM_DESC(d); return gather_decode(*d, (hipStream_t)stream); }
 int gnnlm_star_attn(const gnnlm_star_attn_t* d, void* stream) { GNNLM_DESC(d); return star_attn(*d, (hipStream_t)stream); }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
             for (int e = tid; e < kg * per_row; e += 256) {
                 const int j = e / per_row, part = e - j * per_row;
                 const int64_t id = ids[j];
-                const int64_t lrow = p.codes_direct ? ((int64_t)i * kg + j) * p.codes_direct : id - p.row0;
+                const int64_t lrow = p.codes_direct ? (p.codes_index ? (int64_t)p.codes_index[((int64_t)i * kg + j) * p.codes_direct] : ((int64_t)i * kg + j) * p.codes_direct) : id - p.row0;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (id >= 0) v = *reinterpret_cast<const uint4*>(p.codes + lrow * M + 16 * part);
                 *reinterpret_cast<uint4*>(lcodes + j * M + 16 * part) = v;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
             for (int e = tid; e < kg * M; e += 256) {
                 const int j = e / M, m = e - j * M;
                 const int64_t id = ids[j];
-                const int64_t lrow = p.codes_direct ? ((int64_t)i * kg + j) * p.codes_direct : id - p.row0;
+                const int64_t lrow = p.codes_direct ? (p.codes_index ? (int64_t)p.codes_index[((int64_t)i * kg + j) * p.codes_direct] : ((int64_t)i * kg + j) * p.codes_direct) : id - p.row0;
                 lcodes[e] = id >= 0 ? p.codes[lrow * M + m] : 0;
             }
         }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
                     if (stage_codes) {
                         code = lcodes[j * M + m];
                     } else {
-                        const int64_t lrow = p.codes_direct ? ((int64_t)i * kg + j) * p.codes_direct : ids[j] - p.row0;
+                        const int64_t lrow = p.codes_direct ? (p.codes_index ? (int64_t)p.codes_index[((int64_t)i * kg + j) * p.codes_direct] : ((int64_t)i * kg + j) * p.codes_direct) : ids[j] - p.row0;
                         code = p.codes[lrow * M + m];
                     }
                     x[t] = *reinterpret_cast<const float4*>(p.centroids + ((int64_t)(m * 256 + code)) * p.dsub + within);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256 * KT) void star_attn_sweep_kernel(StarAttnParam
         for (int e = tid; e < KGM * per_row; e += 256) {
             const int j = e / per_row, part = e - j * per_row;
             const int64_t id = j < kg ? ids[j] : -1;
-            const int64_t lrow = p.codes_direct ? ((int64_t)i * kg + j) * p.codes_direct : id - p.row0;
+            const int64_t lrow = p.codes_direct ? (p.codes_index ? (int64_t)p.codes_index[((int64_t)i * kg + j) * p.codes_direct] : ((int64_t)i * kg + j) * p.codes_direct) : id - p.row0;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (id >= 0) v = *reinterpret_cast<const uint4*>(p.codes + lrow * M + 16 * part);
             uint32_t* dst = reinterpret_cast<uint32_t*>(lcodes + j * MS + 16 * part);

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(GatherParams p) {
         bool local;
         int64_t lrow;
         if (p.direct) {
-            lrow = s;
+            lrow = p.in_index ? (int64_t)p.in_index[s] : s;
             local = p.in_valid[s] != 0;
         } else {
             const int64_t centre = p.ids[g];
@@ -71,7 +71,101 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(GatherParams p) {
     }
 }
 
+// codes / labels only (the owner-side lookup of the sharded store): 8 lanes move one 128-B row with
+// 16-B pieces, 8 rows per wave -- the byte-wise path above would spend a whole wave per row.
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherParams p) {
+    const int per_row = p.M >> 4;                                   // 16-B pieces per row
+    const int64_t n = p.n_groups;
+    const int64_t total = n * per_row;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t s = e / per_row;
+        const int part = (int)(e - s * per_row);
+        const int64_t row = p.ids[s];
+        const int64_t lrow = row - p.row0;
+        const bool local = row >= 0 && row < p.n_store && lrow >= 0 && lrow < p.n_local;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (local) v = *reinterpret_cast<const uint4*>(p.codes + lrow * p.M + 16 * part);
+        *reinterpret_cast<uint4*>(p.out_codes + s * p.M + 16 * part) = v;
+        if (part == 0) {
+            if (p.out_valid) p.out_valid[s] = local ? 1 : 0;
+            if (p.out_labels) {
+                int32_t lab = -1;
+                if (local && p.vals)
+                    lab = p.vals_itemsize == 2 ? (int32_t) reinterpret_cast<const int16_t*>(p.vals)[lrow]
+                                               : reinterpret_cast<const int32_t*>(p.vals)[lrow];
+                p.out_labels[s] = lab;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int owner_of(int64_t row, int64_t n_store, int64_t per, int world, int self) {
+    if (row < 0 || row >= n_store) return self;
+    const int64_t o = row / per;
+    return (int)(o < world ? o : world - 1);
+}
+
+__global__ __launch_bounds__(256) void bucket_count_kernel(const int64_t* rows, int64_t n, int64_t n_store, int64_t per,
+                                                           int world, int self, unsigned long long* counts) {
+    __shared__ unsigned int h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        atomicAdd(&h[owner_of(rows[i], n_store, per, world, self)], 1u);
+    __syncthreads();
+    if ((int)threadIdx.x < world && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// cursor[o] starts at the exclusive prefix of counts; every block reserves a range per owner
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const int64_t* rows, int64_t n, int64_t n_store, int64_t per,
+                                                             int world, int self, unsigned long long* cursor,
+                                                             int64_t* send_rows, int32_t* inv) {
+    __shared__ unsigned int h[64];
+    __shared__ unsigned long long base[64];
+    const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per_block, hi = min(n, lo + per_block);
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&h[owner_of(rows[i], n_store, per, world, self)], 1u);
+    __syncthreads();
+    if ((int)threadIdx.x < world) {
+        base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)h[threadIdx.x]) : 0ull;
+        h[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int64_t row = rows[i];
+        const int o = owner_of(row, n_store, per, world, self);
+        const unsigned long long pos = base[o] + atomicAdd(&h[o], 1u);
+        send_rows[pos] = row;
+        inv[i] = (int32_t)pos;
+    }
+}
+
+__global__ void bucket_prefix_kernel(const unsigned long long* counts, unsigned long long* cursor, int world) {
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 0;
+        for (int o = 0; o < world; ++o) { cursor[o] = acc; acc += counts[o]; }
+    }
+}
+
 }  // namespace
+
+int bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t per, int world, int self, int64_t* counts,
+                int64_t* cursor, int64_t* send_rows, int32_t* inv, hipStream_t stream) {
+    GNNLM_REQUIRE(rows && counts && cursor && send_rows && inv, "bucket_rows: null operand");
+    GNNLM_REQUIRE(world >= 1 && world <= 64 && per > 0 && self >= 0 && self < world && n < (1ll << 31), "bucket_rows: bad arguments");
+    if (n == 0) return OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 1024), 1024);
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(blocks), dim3(256), 0, stream, rows, n, n_store, per, world, self,
+                       reinterpret_cast<unsigned long long*>(counts));
+    hipLaunchKernelGGL(bucket_prefix_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const unsigned long long*>(counts),
+                       reinterpret_cast<unsigned long long*>(cursor), world);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, stream, rows, n, n_store, per, world, self,
+                       reinterpret_cast<unsigned long long*>(cursor), send_rows, inv);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
 
 int gather_decode(const GatherParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(p.codes && (p.direct ? p.in_valid != nullptr : p.ids != nullptr), "gather_decode: null codes/ids");
@@ -82,6 +176,14 @@ int gather_decode(const GatherParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(p.vals_itemsize == 2 || p.vals_itemsize == 4, "gather_decode: vals must be int16 or int32");
     const int64_t n_slots = p.n_groups * (1 + p.left + p.right);
     if (n_slots == 0) return OK;
+    if (!p.direct && !p.out_x && p.out_codes && p.left == 0 && p.right == 0 && p.M % 16 == 0 &&
+        (uintptr_t)p.codes % 16 == 0 && (uintptr_t)p.out_codes % 16 == 0) {
+        ProfScope prof(K_GATHER, stream, 0.0, (2.0 * p.M + 8.0) * n_slots);
+        const int64_t blocks = std::min<int64_t>(cdiv(n_slots * (p.M >> 4), 256), 256 * 16);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        GNNLM_LAUNCH_CHECK();
+        return OK;
+    }
     const int64_t blocks = std::min<int64_t>(cdiv(n_slots, 4), 256 * 16);
     const double row_bytes = (double)p.M + (p.out_x ? 4.0 * p.M * p.dsub : 0.0) + (p.out_codes ? p.M : 0.0) +
                              (p.out_labels ? 4.0 + p.vals_itemsize : 0.0) + (p.out_valid ? 1.0 : 0.0);

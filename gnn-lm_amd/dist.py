@@ -6,9 +6,12 @@ is the row fetch from the range-sharded PQ code table / label table:
 
     rank g owns rows [g*per, (g+1)*per)   with per = ceil(n_store / world)
 
-Per step: bucket the requested rows by owner -> all_to_all of the counts -> all_to_all of the row
-ids (8 B/row) -> every owner gathers its rows with the HIP gather kernel -> all_to_all of the
-payload back (M = 128 B/row of codes, 4 B/row of labels) -> un-permute.  xGMI is point-to-point
+Per step: bucket the requested rows by owner (HIP histogram + scatter, no sort) -> all_to_all of the
+counts -> all_to_all of the row ids (8 B/row) -> every owner gathers its rows with the HIP gather
+kernel -> all_to_all of the payload back (M = 128 B/row of codes).  The payload stays in bucketed order:
+the consumer kernels read row ``index[s]`` for request s, so the 128-B rows are not shuffled again.
+The label table (4 B/row, 413 MB for WikiText-103) is replicated by default -- sharding it would add a
+k = 1024-per-token exchange for 3 % of the store's bytes (``bench.py --shard-vals`` does it anyway).  xGMI is point-to-point
 (7 links x ~153 GB/s per GPU): an all-to-all drives all 7 links at once, unlike a ring, so one fused
 exchange per table per step is the right shape.  Row validity needs no communication: a row is valid
 iff 0 <= row < n_store, which the requester knows.
@@ -48,19 +51,41 @@ class Shard:
         return torch.where(ok, own, torch.full_like(own, self.rank))
 
 
+def bucket_torch(rows: torch.Tensor, shard: Shard):
+    """Backend-agnostic bucketing (stable sort by owner).  -> (counts [world] i64, send_rows, inv)."""
+    owner = shard.owner(rows)
+    order = torch.sort(owner, stable=True).indices
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel(), device=order.device)
+    return torch.bincount(owner, minlength=shard.world).to(torch.int64), rows[order].contiguous(), inv
+
+
+def bucket_hip(rows: torch.Tensor, shard: Shard):
+    """Bucketing by the HIP kernel pair of gnnlm_bucket_rows (histogram + scatter; no sort)."""
+    from . import _lib
+    n = rows.numel()
+    dev = rows.device
+    counts = torch.zeros(shard.world, dtype=torch.int64, device=dev)
+    cursor = torch.empty(shard.world, dtype=torch.int64, device=dev)
+    send_rows = torch.empty(n, dtype=torch.int64, device=dev)
+    inv = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.call("gnnlm_bucket_rows", _lib.ptr(rows), n, shard.n_store, shard.per, shard.world, shard.rank,
+              _lib.ptr(counts), _lib.ptr(cursor), _lib.ptr(send_rows), _lib.ptr(inv), _lib.stream())
+    return counts, send_rows, inv
+
+
 def exchange_fetch(rows: torch.Tensor, shard: Shard, local_gather: Callable[[torch.Tensor], torch.Tensor],
-                   group=None) -> torch.Tensor:
+                   group=None, bucket=bucket_torch, unpermute: bool = True):
     """Fetch ``payload[row]`` for every global row in ``rows`` (int64 [S]) from its owning rank.
 
     ``local_gather(global_rows) -> [n, C]`` is evaluated on the owner for the rows it receives (all of
     them inside its shard, or out of range, for which it must return zeros).  Returns [S, C] in the
-    order of ``rows``.  Two host syncs per call (the variable split sizes)."""
+    order of ``rows``; with ``unpermute=False`` returns (payload in bucketed order, index) where
+    ``payload[index[s]]`` answers request s -- the consumer kernels apply the index themselves and the
+    128-B rows are never shuffled a second time.  Two host syncs per call (the variable split sizes)."""
     S = rows.numel()
-    rows = rows.reshape(-1)
-    owner = shard.owner(rows)
-    order = torch.sort(owner, stable=True).indices
-    send_rows = rows[order].contiguous()
-    counts = torch.bincount(owner, minlength=shard.world).to(torch.int64)
+    rows = rows.reshape(-1).contiguous()
+    counts, send_rows, inv = bucket(rows, shard)
     recv_counts = torch.empty_like(counts)
     dist.all_to_all_single(recv_counts, counts, group=group)
     in_splits, out_splits = counts.tolist(), recv_counts.tolist()
@@ -70,9 +95,9 @@ def exchange_fetch(rows: torch.Tensor, shard: Shard, local_gather: Callable[[tor
     assert payload.shape[0] == recv_rows.numel()
     back = torch.empty((S,) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
     dist.all_to_all_single(back, payload, output_split_sizes=in_splits, input_split_sizes=out_splits, group=group)
-    out = torch.empty_like(back)
-    out[order] = back
-    return out
+    if not unpermute:
+        return back, inv
+    return back[inv.long()]
 
 
 def slot_rows(ids: torch.Tensor, left: int, right: int, n_store: int) -> torch.Tensor:
@@ -103,13 +128,14 @@ class ShardedFetcher:
                                          vals=st.vals, want_x=False, want_labels=True, want_valid=False)["labels"]
 
     def fetch_codes(self, ids, left, right, centres_only):
-        """-> (fetched_codes uint8 [S, M], fetched_valid uint8 [S]) for the slots of ``ids`` [n, kg]."""
+        """-> (fetched_codes uint8 [S, M] in bucketed order, fetched_valid uint8 [S], fetched_index int32 [S])
+        for the slots of ``ids`` [n, kg]: slot s lives in row ``fetched_index[s]``."""
         rows = ids.reshape(-1) if centres_only else slot_rows(ids, left, right, self.store.n_store)
         rows = torch.where((rows >= 0) & (rows < self.store.n_store), rows, torch.full_like(rows, -1))
-        codes = exchange_fetch(rows, self.shard, self._gather_codes, self.group)
-        return codes, (rows >= 0).to(torch.uint8)
+        codes, index = exchange_fetch(rows, self.shard, self._gather_codes, self.group, bucket=bucket_hip, unpermute=False)
+        return codes, (rows >= 0).to(torch.uint8), index
 
     def fetch_knn_vals(self, knn_ids):
         """vals[knn_ids] with numpy's negative-index wrap for the -1 padding (knn_model.py:198)."""
         rows = torch.where(knn_ids < 0, knn_ids + self.store.n_store, knn_ids).reshape(-1)
-        return exchange_fetch(rows, self.shard, self._gather_vals, self.group).reshape(knn_ids.shape)
+        return exchange_fetch(rows, self.shard, self._gather_vals, self.group, bucket=bucket_hip).reshape(knn_ids.shape)

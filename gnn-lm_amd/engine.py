@@ -36,6 +36,7 @@ class BlockBatch:
     fetched_codes: Optional[torch.Tensor] = None
     fetched_valid: Optional[torch.Tensor] = None
     fetched_centres_only: bool = False
+    fetched_index: Optional[torch.Tensor] = None
 
 
 class GnnLmEngine:
@@ -51,7 +52,8 @@ class GnnLmEngine:
             tgt = ops.half_to_float(tgt.contiguous())           # token_block_dataset.py:328
         G = NeighborGraph(ids=batch.ids, n_blocks=batch.n_blocks, T=batch.T, left=self.left, right=self.right,
                           store=self.store, fetched_codes=batch.fetched_codes, fetched_valid=batch.fetched_valid,
-                          fetched_centres_only=batch.fetched_centres_only, max_intra_context=self.max_intra_context)
+                          fetched_centres_only=batch.fetched_centres_only, fetched_index=batch.fetched_index,
+                          max_intra_context=self.max_intra_context)
         return self.hgt(G, features={"tgt": tgt})["tgt"]
 
     def score(self, batch: BlockBatch, lmbda: float = 0.0, temperature: float = 1.0):
@@ -64,6 +66,7 @@ class GnnLmEngine:
                 raise ValueError("lmbda > 0 needs knn_sims / knn_ids (results of the kNN search)")
             logp, p_knn, recall = ops.knn_interp(
                 lm_logp, batch.knn_sims, batch.knn_ids, batch.targets, temperature, lmbda,
-                vals=self.store.vals, n_store=self.store.n_store, row0=self.store.row0, knn_vals=batch.knn_vals)
+                vals=self.store.vals, n_store=self.store.n_store,
+                row0=getattr(self.store, "vals_row0", self.store.row0), knn_vals=batch.knn_vals)
             out.update(logp=logp, p_knn=p_knn, recall=recall)
         return out

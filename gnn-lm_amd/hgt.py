@@ -53,6 +53,7 @@ class NeighborGraph:
     fetched_codes: Optional[torch.Tensor] = None    # sharded store: codes of every slot, already fetched
     fetched_valid: Optional[torch.Tensor] = None
     fetched_centres_only: bool = False
+    fetched_index: Optional[torch.Tensor] = None    # int32: slot s lives in row fetched_index[s] of fetched_codes
     max_intra_context: int = 0
 
     @property
@@ -228,6 +229,8 @@ class HGT(nn.Module):
             if G.fetched_valid is not None:
                 io.fetched_valid = G.fetched_valid.data_ptr()
             io.fetched_centres_only = int(G.fetched_centres_only)
+            if G.fetched_index is not None:
+                io.fetched_index = G.fetched_index.data_ptr()
         out_tgt = torch.empty_like(tgt)
         io.out_tgt = out_tgt.data_ptr()
         n_g = 1 + G.left + G.right

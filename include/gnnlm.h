@@ -103,6 +103,7 @@ typedef struct gnnlm_gather {
     uint8_t* out_valid;        /* optional [n_slots] */
     int32_t direct;            /* 1: `codes` is an already-fetched [n_slots, M] buffer (slot s = row s), */
     const uint8_t* in_valid;   /*    validity comes from in_valid[n_slots]; ids is ignored */
+    const int32_t* in_index;   /*    optional with direct: slot s reads row in_index[s] of `codes` */
 } gnnlm_gather_t;
 int gnnlm_pq_gather_decode(const gnnlm_gather_t* desc, void* stream);
 
@@ -123,6 +124,7 @@ typedef struct gnnlm_star_attn {
     const float* X;  int64_t ldx;  int64_t x_group_stride;   /* dense row of (i,j) = X + (i*kg+j)*x_group_stride*ldx */
     float* Z;                  /* [T, H, D] */
     float* has_nb;             /* optional [T]: 1.0 if >= 1 valid neighbour */
+    const int32_t* codes_index;   /* optional with codes_direct: row of (i,j) = codes_index[(i*kg+j)*codes_direct] */
 } gnnlm_star_attn_t;
 int gnnlm_star_attn(const gnnlm_star_attn_t* desc, void* stream);
 
@@ -230,6 +232,8 @@ typedef struct gnnlm_hgt_io {
     const int64_t* ids;        /* [n_blocks*T, kg] neighbour rows, -1 = none */
     const uint8_t* fetched_codes;   /* optional [n_blocks*T*kg*(1+l+r), M]: slots already fetched (sharded store) */
     const uint8_t* fetched_valid;   /* with fetched_codes: [n_slots] */
+    const int32_t* fetched_index;   /* optional: slot s lives in row fetched_index[s] of fetched_codes (the exchange
+                                       returns rows bucketed by owner; the permutation is applied by the consumer) */
     int32_t fetched_centres_only;   /* 1: fetched_* hold only the centre slot of each group ([n_blocks*T*kg, M]);
                                        legal only when no ntgt update is needed (n_layers == 1, out_ntgt == NULL) */
     float* out_tgt;            /* [n_blocks*T, d] */
@@ -239,6 +243,18 @@ typedef struct gnnlm_hgt_io {
 size_t gnnlm_hgt_workspace_bytes(const gnnlm_hgt_t* model, const gnnlm_hgt_io_t* io);
 int gnnlm_hgt_forward(const gnnlm_hgt_t* model, const gnnlm_hgt_io_t* io, void* workspace,
                       size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sharded store, requester side: bucket the requested global rows by owning rank
+ * (owner = row / rows_per_rank, out-of-range rows stay on `self_rank`).
+ *   counts[world]   rows per owner (device, int64)
+ *   send_rows[n]    the rows grouped by owner (order inside a bucket is unspecified)
+ *   inv[n]          position of request s inside send_rows (so payload[inv[s]] answers request s)
+ * counts must be zeroed by the caller; `cursor` is an int64[world] scratch.
+ * ---------------------------------------------------------------------------------------------- */
+int gnnlm_bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t rows_per_rank, int32_t world,
+                      int32_t self_rank, int64_t* counts, int64_t* cursor, int64_t* send_rows, int32_t* inv,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Opt-in live timing (bench.py's roofline): while a profile is open every launch of the selected

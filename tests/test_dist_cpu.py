@@ -58,6 +58,8 @@ def _worker(rank, world, port, n_store, M, seed, q):
             got = exchange_fetch(rows, shard, gather_codes).numpy()
             v = ref_valid.reshape(-1)
             assert np.array_equal(got[v], codes[ref_rows.reshape(-1)[v]]) and not got[~v].any()
+            payload, index = exchange_fetch(rows, shard, gather_codes, unpermute=False)     # what the HIP consumers use
+            assert np.array_equal(payload.numpy()[index.numpy()], got)
         knn = rs2.randint(0, n_store, size=(6, 9)).astype(np.int64)
         knn[0, -2:] = -1
         rows = torch.from_numpy(np.where(knn < 0, knn + n_store, knn).reshape(-1))

@@ -16,7 +16,7 @@ for L in (1, 2):
     b = to_batch(prob["block"], dev)
     ref = eng.score(b, 0.25, 0.01)
     f = ShardedFetcher(eng.store, Shard(prob["n_store"], 1, 0))
-    b.fetched_codes, b.fetched_valid = f.fetch_codes(b.ids, 2, 2, centres_only=(L == 1))
+    b.fetched_codes, b.fetched_valid, b.fetched_index = f.fetch_codes(b.ids, 2, 2, centres_only=(L == 1))
     b.fetched_centres_only = (L == 1)
     b.knn_vals = f.fetch_knn_vals(b.knn_ids)
     out = eng.score(b, 0.25, 0.01)
