@@ -153,9 +153,9 @@ __global__ void bucket_prefix_kernel(const unsigned long long* counts, unsigned 
 
 int bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t per, int world, int self, int64_t* counts,
                 int64_t* cursor, int64_t* send_rows, int32_t* inv, hipStream_t stream) {
-    GNNLM_REQUIRE(rows && counts && cursor && send_rows && inv, "bucket_rows: null operand");
-    GNNLM_REQUIRE(world >= 1 && world <= 64 && per > 0 && self >= 0 && self < world && n < (1ll << 31), "bucket_rows: bad arguments");
+    GNNLM_REQUIRE(world >= 1 && world <= 64 && per > 0 && self >= 0 && self < world && n >= 0 && n < (1ll << 31), "bucket_rows: bad arguments");
     if (n == 0) return OK;
+    GNNLM_REQUIRE(rows && counts && cursor && send_rows && inv, "bucket_rows: null operand");
     const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 1024), 1024);
     hipLaunchKernelGGL(bucket_count_kernel, dim3(blocks), dim3(256), 0, stream, rows, n, n_store, per, world, self,
                        reinterpret_cast<unsigned long long*>(counts));
