@@ -393,6 +393,10 @@ int gnnlm_gemm_nt(const gnnlm_gemm_t* d, void* stream) { GNNLM_DESC(d); return g
 int gnnlm_lse_reduce(const float* part, int32_t n_parts, int64_t rows, const int32_t* m_dev, float* lse, void* stream) {
     return lse_reduce(part, n_parts, rows, m_dev, lse, (hipStream_t)stream);
 }
+int gnnlm_pq_encode(const float* x, int64_t ldx, const float* centroids, const float* norm2, int32_t M, int32_t dsub,
+                    int64_t n, uint8_t* codes, void* stream) {
+    return pq_encode(x, ldx, centroids, norm2, M, dsub, n, codes, (hipStream_t)stream);
+}
 int gnnlm_bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t rows_per_rank, int32_t world,
                       int32_t self_rank, int64_t* counts, int64_t* cursor, int64_t* send_rows, int32_t* inv, void* stream) {
     return bucket_rows(rows, n, n_store, rows_per_rank, world, self_rank, counts, cursor, send_rows, inv, (hipStream_t)stream);

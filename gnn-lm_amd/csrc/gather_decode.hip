@@ -99,6 +99,38 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherParams p) {
     }
 }
 
+// PQ encode (TorchPQCodec.encode, knn/pq_wrapper.py:131-167; an offline producer in the reference --
+// knn/quantize_features.py:122-146 -- and a "next" row here): codes[r][m] = argmin_c ||c||^2 - 2 x_m . c.
+// One wave per row; per sub-quantizer every lane scores 4 of the 256 centroids (32-B rows, coalesced),
+// then a (value, index) wave reduction picks the smallest distance, lowest index on ties (torch.argmin).
+__global__ __launch_bounds__(256) void pq_encode_kernel(const float* x, int64_t ldx, const float* cen, const float* norm2,
+                                                        int M, int dsub, int64_t n, uint8_t* codes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* xr = x + row * ldx;
+    for (int m = 0; m < M; ++m) {
+        float best = INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = lane + 64 * t;
+            const float* cr = cen + ((int64_t)m * 256 + c) * dsub;
+            float dot = 0.f;
+            for (int e = 0; e < dsub; ++e) dot = fmaf(xr[m * dsub + e], cr[e], dot);
+            const float dis = norm2[m * 256 + c] - 2.f * dot;
+            if (dis < best) { best = dis; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) codes[row * M + m] = (uint8_t)bi;
+    }
+}
+
 __device__ __forceinline__ int owner_of(int64_t row, int64_t n_store, int64_t per, int world, int self) {
     if (row < 0 || row >= n_store) return self;
     const int64_t o = row / per;
@@ -163,6 +195,16 @@ int bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t per, in
                        reinterpret_cast<unsigned long long*>(cursor), world);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, stream, rows, n, n_store, per, world, self,
                        reinterpret_cast<unsigned long long*>(cursor), send_rows, inv);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int pq_encode(const float* x, int64_t ldx, const float* cen, const float* norm2, int M, int dsub, int64_t n, uint8_t* codes,
+              hipStream_t stream) {
+    GNNLM_REQUIRE(M > 0 && dsub > 0 && n >= 0, "pq_encode: bad shape");
+    if (n == 0) return OK;
+    GNNLM_REQUIRE(x && cen && norm2 && codes, "pq_encode: null operand");
+    hipLaunchKernelGGL(pq_encode_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream, x, ldx, cen, norm2, M, dsub, n, codes);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

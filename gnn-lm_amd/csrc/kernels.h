@@ -15,6 +15,8 @@ typedef gnnlm_knn_interp_t KnnInterpParams;
 int gemm_nt(const GemmParams& p, hipStream_t stream);
 int lse_reduce(const float* part, int n_parts, int64_t rows, const int32_t* m_dev, float* lse, hipStream_t stream);
 int gather_decode(const GatherParams& p, hipStream_t stream);
+int pq_encode(const float* x, int64_t ldx, const float* cen, const float* norm2, int M, int dsub, int64_t n, uint8_t* codes,
+              hipStream_t stream);
 int bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t per, int world, int self, int64_t* counts,
                 int64_t* cursor, int64_t* send_rows, int32_t* inv, hipStream_t stream);
 int star_attn(const StarAttnParams& p, hipStream_t stream);

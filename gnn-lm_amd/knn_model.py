@@ -28,7 +28,7 @@ class ExactIndex:
     descending; L2: squared distances ascending).  The similarity matrix runs on the f32 MFMA GEMM."""
 
     def __init__(self, keys, metric="ip", cosine=False, device="cuda"):
-        k = torch.as_tensor(np.asarray(keys)).to(device, torch.float32)
+        k = torch.as_tensor(np.array(keys)).to(device, torch.float32)
         if cosine:
             k = k / (k ** 2).sum(-1, keepdim=True).sqrt()                 # index_builder.py:90-95,118
         self.keys, self.metric = k.contiguous(), metric

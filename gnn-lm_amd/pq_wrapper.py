@@ -9,9 +9,9 @@ checkpoint load with ``load_state_dict``.  The reference builds the tables from 
 still accepted when faiss is importable.
 
 ``decode`` is the hot-path half (transformer.py:1043-1045): table lookup by the HIP gather kernel,
-then ``(x - b) @ A`` on the f32 MFMA GEMM (as ``x @ A - b @ A``).  ``encode`` / ``compute_sim`` are
-offline tools in the reference (quantize_features.py); they are plain torch
-expressions of pq_wrapper.py:104-167 on whatever device the tensors live on -- no HIP kernel yet.
+then ``(x - b) @ A`` on the f32 MFMA GEMM (as ``x @ A - b @ A``).  ``encode`` (an offline tool in the
+reference: quantize_features.py) runs on the GPU as GEMM + HIP argmin kernel for device
+tensors; ``compute_sim`` is the plain torch expression of pq_wrapper.py:104-129.
 """
 import numpy as np
 import torch
@@ -97,7 +97,19 @@ class TorchPQCodec(torch.nn.Module):
         return ops.gemm_nt(x, At, bias=nba)
 
     def encode(self, x):
-        """x [n, d_in] -> codes uint8 [n, M]   (pq_wrapper.py:131-167).  Offline tool: torch ops."""
+        """x [n, d_in] -> codes uint8 [n, M]   (pq_wrapper.py:131-167).  Device tensors: OPQ rotation on the
+        f32 MFMA GEMM + the HIP argmin kernel (gnnlm_pq_encode); host tensors: the plain torch expression
+        (offline tool in the reference, not on the eval path)."""
+        if x.is_cuda:
+            from . import ops
+            x = x.to(torch.float32).contiguous()
+            if self.pre_torch:
+                x = ops.gemm_nt(x, self.A.contiguous(), bias=self.b if self.b.numel() > 0 else None)
+            M, ksub, dsub = self.centroids_torch.shape
+            codes = torch.empty(x.shape[0], M, dtype=torch.uint8, device=x.device)
+            _lib.call("gnnlm_pq_encode", _lib.ptr(x), x.stride(0), _lib.ptr(self.centroids_torch.contiguous()),
+                      _lib.ptr(self.norm2_centroids_torch.contiguous()), M, dsub, x.shape[0], _lib.ptr(codes), _lib.stream())
+            return codes
         if self.pre_torch:
             x = x @ self.A.t()
             if self.b.numel() > 0:

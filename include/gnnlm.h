@@ -107,6 +107,13 @@ typedef struct gnnlm_gather {
 } gnnlm_gather_t;
 int gnnlm_pq_gather_decode(const gnnlm_gather_t* desc, void* stream);
 
+/* PQ encode of already-rotated rows: codes[r, m] = argmin_c norm2[m, c] - 2 x[r, m*dsub:(m+1)*dsub] . centroids[m, c]
+ * (lowest index on ties).  Replaces the argmin of TorchPQCodec.encode (knn/pq_wrapper.py:131-167); the OPQ
+ * rotation `x @ A.T + b` in front of it is a gnnlm_gemm_nt.  Offline producer in the reference
+ * (knn/quantize_features.py:122-146), a "next" row of the hot-path table. */
+int gnnlm_pq_encode(const float* x, int64_t ldx, const float* centroids, const float* norm2, int32_t M, int32_t dsub,
+                    int64_t n, uint8_t* codes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ('ntgt','inter','tgt') attention with the neighbour-side projections absorbed into the query:
  *   s[i,h,j] = x_j . U[i,h,:]  (valid j only),  alpha = softmax_j,  Z[i,h,:] = sum_j alpha x_j

@@ -31,6 +31,28 @@ def test_codec_decode_golden(dev, golden, case):
     np.testing.assert_allclose(out, g[f"{case}.decode"], atol=2e-6, rtol=1e-5)            # pq_wrapper.py:233-237 uses 1e-6
 
 
+@pytest.mark.parametrize("case", ["sq_pre", "sq_pre_nob", "rect_pre", "nopre"])
+def test_codec_encode_hip(dev, golden, case):
+    """HIP encode == the reference's codes (integer output: exact), and == the oracle on a larger batch
+    wherever the two best distances are not within float rounding of each other."""
+    from gnnlm_amd.pq_wrapper import TorchPQCodec
+    from oracle import pq as opq_
+    g = golden("pq")
+    A = g[f"{case}.A"] if f"{case}.A" in g else None
+    b = g[f"{case}.b"] if f"{case}.b" in g else None
+    c = TorchPQCodec.from_arrays(g[f"{case}.cen"], A, b).to(dev)
+    codes = c.encode(torch.from_numpy(g[f"{case}.x"].copy()).to(dev)).cpu().numpy()
+    assert np.array_equal(codes, g[f"{case}.codes"])
+    rs = np.random.RandomState(0)
+    x = rs.randn(2000, g[f"{case}.x"].shape[1]).astype(np.float32)
+    got = c.encode(torch.from_numpy(x).to(dev)).cpu().numpy()
+    ref = opq_.pq_encode(x, g[f"{case}.cen"], A, b)
+    assert (got != ref).mean() < 1e-3                      # near-ties may resolve differently in float32
+    dec_got = opq_.pq_lookup(got, g[f"{case}.cen"]); dec_ref = opq_.pq_lookup(ref, g[f"{case}.cen"])
+    xr = x @ A.T + (b if b is not None and b.size else 0) if A is not None else x
+    assert np.allclose(((xr - dec_got) ** 2).sum(1), ((xr - dec_ref) ** 2).sum(1), rtol=1e-4, atol=1e-4)   # equally good codes
+
+
 def test_codec_decode_full_size(dev, golden):
     from gnnlm_amd.pq_wrapper import TorchPQCodec
     from tests.test_oracle_golden import full_size_codec
@@ -243,3 +265,24 @@ def test_eval_lm_end_to_end(dev, tmp_path):
     parts = [eval_lm.cli_main(base + ["--num-shards", "2", "--shard-id", str(i)]) for i in range(2)]
     assert sum(p["count"] for p in parts) == n_test
     assert abs(sum(p["score_sum"] for p in parts) - ref_lm.sum().item()) < 1e-4 * n_test
+
+
+def test_find_knn_producer(dev, tmp_path):
+    """neighbors.mmap.{k} written by the find_knn mirror == exact search of the oracle (cosine index,
+    un-normalised queries as in knn/find_knn.py:63-65), incl. the truncated copies."""
+    from gnnlm_amd import find_knn
+    rs = np.random.RandomState(4)
+    d, n_train, n_test, k = 32, 700, 90, 16
+    train = rs.randn(n_train, d).astype(np.float16)
+    test = rs.randn(n_test, d).astype(np.float16)
+    data = tmp_path / "data-bin"
+    write_dstore(str(data / "train_dstore"), train, rs.randint(4, 100, n_train).astype(np.int16), 100)
+    write_dstore(str(data / "test_dstore"), test, rs.randint(4, 100, n_test).astype(np.int16), 100)
+    f = find_knn.main(find_knn.get_parser().parse_args(["--data-dir", str(data), "--subset", "test", "--k", str(k),
+                                                        "--bsz", "37", "--truncate-to", "8", "4"]))
+    got = np.memmap(f, dtype=np.int64, mode="r", shape=(n_test, k))
+    _, ref = oknn.brute_force_search(test.astype(np.float32), train, k, "ip", cosine=True)
+    assert np.array_equal(np.array(got), ref)
+    for k2 in (8, 4):
+        t = np.memmap(str(data / "test_dstore" / f"neighbors.mmap.{k2}"), dtype=np.int64, mode="r", shape=(n_test, k2))
+        assert np.array_equal(np.array(t), ref[:, :k2])
