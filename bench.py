@@ -29,7 +29,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-PEAK = {"mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}           # MI355X_MICROARCH.md chip table
+PEAK = {"mfma_f32_tflops": 157.3, "mfma_bf16_tflops": 2500.0, "hbm_gbs": 8000.0}   # MI355X_MICROARCH.md chip table
+SPLIT_PRODUCTS = {"f32": 1, "bf16x3": 3, "bf16x6": 6}            # bf16 MFMA products issued per f32 multiply-add
 KERNEL_BOUND = {"gemm_nt_f32_kernel": "mfma"}                    # everything else on this path: hbm
 
 
@@ -54,6 +55,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=384)
     ap.add_argument("--small", action="store_true", help="tiny shapes (plumbing check only)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16x6"], default="f32",
+                    help="GEMM arithmetic: f32 = native f32 MFMA (headline, the reference's precision); bf16x3 / bf16x6 = "
+                         "opt-in split-bf16 emulation of the f32 product on the bf16 MFMA (max |dlogp| vs f32 is reported)")
     ap.add_argument("--shard-vals", action="store_true", help="also range-shard the label table (default: replicated)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the sharded-store exchange even with one rank (exercises the RCCL path on one GPU)")
@@ -101,6 +105,8 @@ def build(args, dev, rank, world):
     w = make_asm_weights(rs, vocab, d, cutoff)
     asm = AdaptiveSoftmax(w["cutoff"], w["emb"], w["proj"], w["class_proj"], dev)
     eng = GnnLmEngine(hgt, asm, store, 2, 2)
+    from gnnlm_amd.ops import PRECISIONS
+    hgt.gemm_precision = asm.gemm_precision = PRECISIONS[args.precision]
     cpu_model = {"sd": hgt.state_dict(), "asm": w, "cen": cen, "A": A, "b": b, "d": d, "H": H, "M": M, "vocab": vocab}
     return eng, shard, sharded, cpu_model, (d, vocab)
 
@@ -231,6 +237,13 @@ def main():
     # ---- warm-up; the first warm-up step after initialisation is profiled kernel by kernel
     step(0)
     barrier()
+    dlogp = None
+    if args.precision != "f32" and fetcher is None:               # accuracy of the opt-in mode on one real batch
+        got = eng.score(batches[0], args.lmbda, args.temperature)["logp"].clone()
+        eng.hgt.gemm_precision = eng.asm.gemm_precision = 0
+        ref = eng.score(batches[0], args.lmbda, args.temperature)["logp"]
+        eng.hgt.gemm_precision = eng.asm.gemm_precision = ops.PRECISIONS[args.precision]
+        dlogp = (got.double() - ref.double()).abs().max().item()
     _lib.profile_begin()
     step(1)
     torch.cuda.synchronize()
@@ -264,7 +277,9 @@ def main():
     def roof(name, e):
         bound = KERNEL_BOUND.get(name, "hbm")
         sec = e["total_ms"] / 1e3
-        if bound == "mfma":
+        if bound == "mfma" and args.precision != "f32":           # priced in the bf16 MFMA flops actually issued
+            a, p, unit = SPLIT_PRODUCTS[args.precision] * e["flops"] / sec / 1e12, PEAK["mfma_bf16_tflops"], "TFLOP/s"
+        elif bound == "mfma":
             a, p, unit = e["flops"] / sec / 1e12, PEAK["mfma_f32_tflops"], "TFLOP/s"
         else:
             a, p, unit = e["bytes"] / sec / 1e9, PEAK["hbm_gbs"], "GB/s"
@@ -279,13 +294,15 @@ def main():
             "metric": "eval tokens/sec on WikiText-103 (k=1024, GNN+KNN); test ppl match",
             "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else f"f32 via {args.precision} split-bf16 MFMA", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: WikiText-103 full PQ datastore in HBM, k_g=128, "
                                    "context 2+2, HGT 1 layer, kNN k=1024 (search results given), 256-token blocks",
                        "n_store": args.n_store, "blocks_per_step_per_gpu": args.blocks, "streams": args.streams, "tokens_per_block": args.tokens_per_sample,
                        "gcn_k": args.gcn_k, "knn_k": args.k, "hgt_layers": args.layers, "d": d, "vocab": vocab,
                        "lmbda": args.lmbda, "temperature": args.temperature,
                        "store": ("range-sharded + RCCL all-to-all" if sharded else "replicated" if world > 1 else "single GPU"),
+                       "gemm_precision": args.precision, "max_abs_dlogp_vs_f32": dlogp,
                        "synthetic_ppl": round(float(2 ** (-score_sum / tokens / np.log(2))), 4)},
             "roofline": r,
             "kernels": [roof(k_, v) for k_, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"])],

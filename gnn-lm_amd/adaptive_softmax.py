@@ -40,6 +40,7 @@ class AdaptiveSoftmax:
             w.dim[i] = self.emb[i].shape[1]
         self._w = w
         self._ws = None
+        self.gemm_precision = 0     # 0 exact f32 MFMA | 1 bf16x3 | 2 bf16x6
 
     @classmethod
     def from_state_dict(cls, sd, cutoff, vocab, device, prefix="decoder."):
@@ -56,6 +57,7 @@ class AdaptiveSoftmax:
         target = target.contiguous()
         assert x.dtype == torch.float32 and target.dtype == torch.int64
         out = torch.empty(n, device=x.device, dtype=torch.float32)
+        self._w.gemm_precision = self.gemm_precision
         L = _lib.lib()
         need = L.gnnlm_adaptive_workspace_bytes(ctypes.byref(self._w), n)
         key = torch.cuda.current_stream().cuda_stream           # one arena per stream

@@ -134,6 +134,8 @@ int linear(const float* A, int64_t lda, const float* W, const float* bias, float
 
 int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, size_t ws_bytes, hipStream_t s) {
     GNNLM_REQUIRE(m.layers && m.n_layers >= 1, "hgt: no layers");
+    GNNLM_REQUIRE(m.gemm_precision >= 0 && m.gemm_precision <= 2, "hgt: gemm_precision must be 0, 1 or 2");
+    GemmPrecisionScope prec_scope(m.gemm_precision);
     GNNLM_REQUIRE(m.d > 0 && m.n_heads > 0 && m.d % m.n_heads == 0, "hgt: d must be divisible by n_heads");
     GNNLM_REQUIRE(io.n_blocks >= 0 && io.T >= 0 && io.kg > 0, "hgt: bad io shape");
     if ((int64_t)io.n_blocks * io.T == 0) return OK;                 // empty batch: nothing to do
@@ -309,6 +311,8 @@ void carve_asm(const gnnlm_adaptive_softmax_t& w, int64_t n, Carver& c, AsmBufs&
 int adaptive_impl(const gnnlm_adaptive_softmax_t& w, const float* x, int64_t ldx, const int64_t* target, int64_t n,
                   float* lm_logp, void* ws, size_t ws_bytes, hipStream_t s) {
     GNNLM_REQUIRE(w.n_bands >= 1 && w.n_bands <= 8 && w.head_w && w.d > 0 && w.d % 4 == 0, "adaptive: bad weights");
+    GNNLM_REQUIRE(w.gemm_precision >= 0 && w.gemm_precision <= 2, "adaptive: gemm_precision must be 0, 1 or 2");
+    GemmPrecisionScope prec_scope(w.gemm_precision);
     GNNLM_REQUIRE(x && target && lm_logp, "adaptive: null io");
     if (n == 0) return OK;
     GNNLM_REQUIRE(n < (1ll << 31), "adaptive: too many rows");

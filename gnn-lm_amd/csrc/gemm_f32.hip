@@ -32,6 +32,7 @@
 namespace gnnlm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int BK = 32, LDS_LD = BK + 4;
@@ -41,12 +42,27 @@ constexpr int BK = 32, LDS_LD = BK + 4;
 constexpr int NBUF = GNNLM_GEMM_NBUF;
 enum { EPI_STORE = 0, EPI_LSE = 1 };
 
-template <int BM, int BN, int EPI>
+// round-to-nearest-even f32 -> bf16 (bit pattern in the low 16 bits)
+__device__ __forceinline__ unsigned bf16_rn(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+
+// NS = 0: native f32 MFMA (exact fmaf chain).
+// NS = 2 / 3: split-bf16 emulation on the bf16 matrix cores (precision 1 / 2 of the C ABI): every f32
+//   operand is split while staged into NS bf16 planes (x = x0 + x1 (+ x2)) and the product is assembled from the 3 (NS=2: x0y0, x0y1, x1y0; ~2^-16 relative
+//   per product) or 6 (NS=3: adds x0y2, x1y1, x2y0; ~2^-24, i.e. f32-level) cross terms with
+//   v_mfma_f32_32x32x16_bf16, f32 accumulate.  3/16 resp. 6/16 of the f32-MFMA cycles per flop.
+template <int BM, int BN, int EPI, int NS>
 __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p) {
     constexpr int TM = BM / 64, TN = BN / 64;            // 32x32 accumulators per wave
     constexpr int LA = BM / 32, LW = BN / 32;            // staging float4 per thread
     constexpr int STAGE = (BM + BN) * LDS_LD;
-    __shared__ __attribute__((aligned(16))) float lds[NBUF * STAGE];
+    constexpr int SPLIT_LD = 20;                         // floats (80 B) per bf16 row of 32 k: conflict-free b128 reads
+    constexpr int PLANE = (BM + BN) * SPLIT_LD;          // floats per bf16 plane
+    constexpr int LDS_FLOATS = NS == 0 ? NBUF * STAGE : NS * PLANE;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -139,17 +155,68 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
             if (!kin_) rw[i_] = z4;                                                          \
         }                                                                                    \
     }
-#define GNNLM_STORE_TILE(buf)                                                                \
+    // Split of 4 consecutive k of one row into NS bf16 planes, 8 bytes per plane.
+    //   bf16x6 (NS = 3): every plane is a TRUNCATION (x & 0xFFFF0000: one v_and; the residual x - hi is
+    //     exact); three 8-bit pieces cover the 24-bit significand, so x0 + x1 + x2 == x bit for bit and only
+    //     the three dropped cross products (<= 2^-24 |a||b| each) separate the result from an f32 product.
+    //   bf16x3 (NS = 2): both planes are round-to-nearest (x0 = rn(x), x1 = rn(x - x0)): unbiased, residual
+    //     2^-18 |x|; truncation would be cheaper but biases the dropped x1*y1 term (same sign as x*y).
+#define GNNLM_PK_TRUNC(lo_, hi_) ((__float_as_uint(hi_) & 0xFFFF0000u) | (__float_as_uint(lo_) >> 16))
+#define GNNLM_SPLIT_STORE(v_, row_)                                                          \
     {                                                                                        \
+        char* dst_ = reinterpret_cast<char*>(lds) + (row_) * (SPLIT_LD * 4) + kq * 2;        \
+        float r0_ = (v_).x, r1_ = (v_).y, r2_ = (v_).z, r3_ = (v_).w;                        \
+        if constexpr (NS == 3) {                                                             \
+            _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) {                            \
+                *reinterpret_cast<uint2*>(dst_ + pl_ * (PLANE * 4)) =                        \
+                    make_uint2(GNNLM_PK_TRUNC(r0_, r1_), GNNLM_PK_TRUNC(r2_, r3_));          \
+                r0_ -= __uint_as_float(__float_as_uint(r0_) & 0xFFFF0000u);                  \
+                r1_ -= __uint_as_float(__float_as_uint(r1_) & 0xFFFF0000u);                  \
+                r2_ -= __uint_as_float(__float_as_uint(r2_) & 0xFFFF0000u);                  \
+                r3_ -= __uint_as_float(__float_as_uint(r3_) & 0xFFFF0000u);                  \
+            }                                                                                \
+        } else {                                                                             \
+            _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) {                            \
+                const unsigned b0_ = bf16_rn(r0_), b1_ = bf16_rn(r1_), b2_ = bf16_rn(r2_), b3_ = bf16_rn(r3_); \
+                *reinterpret_cast<uint2*>(dst_ + pl_ * (PLANE * 4)) = make_uint2(b0_ | (b1_ << 16), b2_ | (b3_ << 16)); \
+                r0_ -= __uint_as_float(b0_ << 16);                                           \
+                r1_ -= __uint_as_float(b1_ << 16);                                           \
+                r2_ -= __uint_as_float(b2_ << 16);                                           \
+                r3_ -= __uint_as_float(b3_ << 16);                                           \
+            }                                                                                \
+        }                                                                                    \
+    }
+#define GNNLM_STORE_TILE(buf)                                                                \
+    if constexpr (NS == 0) {                                                                 \
         float* a_ = &lds[(buf) * STAGE + srow * LDS_LD + kq];                                \
         float* w_ = a_ + BM * LDS_LD;                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < LA; ++i_)                                    \
             *reinterpret_cast<float4*>(a_ + 32 * i_ * LDS_LD) = ra[i_];                      \
         _Pragma("unroll") for (int i_ = 0; i_ < LW; ++i_)                                    \
             *reinterpret_cast<float4*>(w_ + 32 * i_ * LDS_LD) = rw[i_];                      \
+    } else {                                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < LA; ++i_) GNNLM_SPLIT_STORE(ra[i_], srow + 32 * i_)        \
+        _Pragma("unroll") for (int i_ = 0; i_ < LW; ++i_) GNNLM_SPLIT_STORE(rw[i_], BM + srow + 32 * i_)   \
     }
+#define GNNLM_SPLIT_MFMA(PA, PB)                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                       \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][i], fb[PB][j], acc[i][j], 0, 0, 0);
 #define GNNLM_COMPUTE(buf)                                                                   \
-    {                                                                                        \
+    if constexpr (NS != 0) {                                                                 \
+        const char* base_ = reinterpret_cast<const char*>(lds);                              \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < BK / 16; ++ks_) {                          \
+            bf16x8 fa[NS][TM], fb[NS][TN];                                                   \
+            _Pragma("unroll") for (int pl_ = 0; pl_ < NS; ++pl_) {                           \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                               \
+                    fa[pl_][i] = *reinterpret_cast<const bf16x8*>(base_ + (pl_ * (BM + BN) + wm * (BM / 2) + 32 * i + l32) * SPLIT_LD * 4 + 32 * ks_ + 16 * half); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                               \
+                    fb[pl_][j] = *reinterpret_cast<const bf16x8*>(base_ + (pl_ * (BM + BN) + BM + wn * (BN / 2) + 32 * j + l32) * SPLIT_LD * 4 + 32 * ks_ + 16 * half); \
+            }                                                                                \
+            if constexpr (NS == 3) { GNNLM_SPLIT_MFMA(2, 0) GNNLM_SPLIT_MFMA(1, 1) GNNLM_SPLIT_MFMA(0, 2) }   \
+            GNNLM_SPLIT_MFMA(1, 0) GNNLM_SPLIT_MFMA(0, 1) GNNLM_SPLIT_MFMA(0, 0)             \
+        }                                                                                    \
+    } else {                                                                                 \
         const float* a_base = &lds[(buf) * STAGE + (wm * (BM / 2) + l32) * LDS_LD + 4 * half];            \
         const float* w_base = &lds[(buf) * STAGE + (BM + wn * (BN / 2) + l32) * LDS_LD + 4 * half];       \
         _Pragma("unroll") for (int s_ = 0; s_ < BK / 8; ++s_) {                              \
@@ -173,11 +240,12 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
         GNNLM_STORE_TILE(0);
         __syncthreads();
         for (int kt = 0; kt < nk_full; ++kt) {
-            const int buf = NBUF == 2 ? (kt & 1) : 0;
+            constexpr bool ONE_BUF = NBUF == 1 || NS != 0;
+            const int buf = ONE_BUF ? 0 : (kt & 1);
             if (kt + 1 < nk_full) GNNLM_LOAD_TILE(kt + 1);
             GNNLM_COMPUTE(buf);
-            if (NBUF == 1) __syncthreads();
-            if (kt + 1 < nk_full) GNNLM_STORE_TILE(NBUF == 2 ? (buf ^ 1) : 0);
+            if (ONE_BUF) __syncthreads();
+            if (kt + 1 < nk_full) { GNNLM_STORE_TILE(ONE_BUF ? 0 : (buf ^ 1)); }
             __syncthreads();
         }
     }
@@ -190,6 +258,9 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
     }
 #undef GNNLM_LOAD_TILE_GUARDED
 #undef GNNLM_COMPUTE
+#undef GNNLM_SPLIT_MFMA
+#undef GNNLM_SPLIT_STORE
+#undef GNNLM_PK_TRUNC
 #undef GNNLM_LOAD_TILE
 #undef GNNLM_STORE_TILE
 
@@ -273,17 +344,26 @@ __global__ __launch_bounds__(256) void lse_reduce_kernel(const float2* part, int
     if (lane == 0) lse[row] = m + logf(s);
 }
 
+template <int BM, int BN, int NS>
+void launch_ns(const GemmParams& p, dim3 grid, hipStream_t stream) {
+    if (p.lse_part)
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, EPI_LSE, NS>), grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, EPI_STORE, NS>), grid, dim3(256), 0, stream, p);
+}
 template <int BM, int BN>
 void launch(const GemmParams& p, dim3 grid, hipStream_t stream) {
-    if (p.lse_part)
-        hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, EPI_LSE>), grid, dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, EPI_STORE>), grid, dim3(256), 0, stream, p);
+    if (p.precision == 1) launch_ns<BM, BN, 2>(p, grid, stream);
+    else if (p.precision == 2) launch_ns<BM, BN, 3>(p, grid, stream);
+    else launch_ns<BM, BN, 0>(p, grid, stream);
 }
 }  // namespace
 
+thread_local int g_default_gemm_precision = 0;
+
 int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     GemmParams p = desc;
+    if (p.precision == 0) p.precision = g_default_gemm_precision;
     if (p.alpha == 0.f) p.alpha = 1.f;
     if (p.batch1 == 0) p.batch1 = 1;
     if (p.batch2 == 0) p.batch2 = 1;
@@ -293,7 +373,7 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     GNNLM_REQUIRE(((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0), "gemm: operands must be 16-byte aligned");
     GNNLM_REQUIRE(p.sA1 % 4 == 0 && p.sA2 % 4 == 0 && p.sW1 % 4 == 0 && p.sW2 % 4 == 0, "gemm: batch strides must be multiples of 4");
     GNNLM_REQUIRE(p.batch1 >= 1 && p.batch2 >= 1, "gemm: bad batch");
-    GNNLM_REQUIRE(p.precision == 0, "gemm: unknown precision");
+    GNNLM_REQUIRE(p.precision >= 0 && p.precision <= 2, "gemm: precision must be 0 (f32 MFMA), 1 (bf16x3) or 2 (bf16x6)");
     GNNLM_REQUIRE(!p.lse_part || p.batch1 * p.batch2 == 1, "gemm: the LSE epilogue does not support batches");
     GNNLM_REQUIRE(p.tile_order >= 0 && p.tile_order <= 66, "gemm: tile_order must be 0 (auto), 1 (n fastest), 2 (m fastest) or 2+GM (bands of GM m-tiles)");
     if (p.M == 0) return OK;

@@ -13,6 +13,13 @@ typedef gnnlm_chain_attn_t ChainAttnParams;
 typedef gnnlm_knn_interp_t KnnInterpParams;
 
 int gemm_nt(const GemmParams& p, hipStream_t stream);
+// precision used by gemm_nt for descriptors that leave `precision` at 0 (set by the orchestrators)
+extern thread_local int g_default_gemm_precision;
+struct GemmPrecisionScope {
+    int saved;
+    explicit GemmPrecisionScope(int prec) : saved(g_default_gemm_precision) { g_default_gemm_precision = prec; }
+    ~GemmPrecisionScope() { g_default_gemm_precision = saved; }
+};
 int lse_reduce(const float* part, int n_parts, int64_t rows, const int32_t* m_dev, float* lse, hipStream_t stream);
 int gather_decode(const GatherParams& p, hipStream_t stream);
 int pq_encode(const float* x, int64_t ldx, const float* cen, const float* norm2, int M, int dsub, int64_t n, uint8_t* codes,

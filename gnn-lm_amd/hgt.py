@@ -171,6 +171,7 @@ class HGT(nn.Module):
                                   for _ in range(n_layers)])
         self.adapt_ws = nn.ModuleList()
         self._prepared = None
+        self.gemm_precision = 0     # 0 exact f32 MFMA | 1 bf16x3 | 2 bf16x6 (opt-in split-bf16 emulation)
 
     def _load_from_state_dict(self, *a, **k):
         self._prepared = None
@@ -220,6 +221,7 @@ class HGT(nn.Module):
         prep = self.prepare(G.store, tgt.device)
         m = prep["model"]
         m.left, m.right, m.max_intra_context = G.left, G.right, G.max_intra_context
+        m.gemm_precision = self.gemm_precision
         io = _lib.gnnlm_hgt_io_t()
         io.n_blocks, io.T, io.kg = G.n_blocks, G.T, G.kg
         ids = G.ids.contiguous()

@@ -23,8 +23,11 @@ def _f32(t):
     return t
 
 
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+
+
 def gemm_nt(A, W, bias=None, residual=None, alpha=1.0, out=None, bias_mode=1, gate=None,
-            a_rows=None, m_dev=None):
+            a_rows=None, m_dev=None, precision=0):
     """C = alpha * A @ W.T (+ gate*bias) (+ residual).  A [M,K] (row stride may exceed K), W [N,K]."""
     _f32(A), _f32(W)
     _dev(A, W, bias, residual, gate, a_rows, m_dev, out)
@@ -50,6 +53,7 @@ def gemm_nt(A, W, bias=None, residual=None, alpha=1.0, out=None, bias_mode=1, ga
         g.m_dev = m_dev.data_ptr()
     g.alpha = alpha
     g.M, g.N, g.K = M, N, K
+    g.precision = PRECISIONS.get(precision, precision)
     call_desc("gnnlm_gemm_nt", g)
     return out
 

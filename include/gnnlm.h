@@ -63,7 +63,8 @@ typedef struct gnnlm_gemm {
     const int32_t* m_dev;      /* optional device-side row count (<= M): tiles beyond it exit */
     int32_t batch1, batch2;    /* 0 is read as 1; batch index (b1, b2) */
     int64_t sA1, sA2, sW1, sW2, sC1, sC2, sB1, sB2, sR1, sR2;   /* batch strides in elements */
-    int32_t precision;         /* 0: f32 MFMA */
+    int32_t precision;         /* 0: f32 MFMA (exact fmaf chain; or the enclosing orchestrator's setting);
+                                  1: bf16x3 split emulation (~2^-16 per product); 2: bf16x6 (~2^-24, f32-level) */
     int32_t tile_order;        /* 0: auto (consecutive tiles share the larger operand's panel), 1: n fastest, 2: m fastest */
     /* log-sum-exp epilogue (C may be NULL): instead of storing C, every (row, 64-column slab) writes a
      * (max, sum exp(x - max)) pair to lse_part[row][slab], slab count = 2*ceil(N/128); lse_picked[row] =
@@ -170,6 +171,7 @@ int gnnlm_row_lse_pick(const float* logits, int64_t ld, int64_t rows, const int3
 typedef struct gnnlm_adaptive_softmax {
     int32_t d, n_bands;
     int32_t cutoff[8];         /* cutoff[0..n_bands-1]; cutoff[n_bands-1] = vocab size */
+    int32_t gemm_precision;    /* precision of the GEMMs (see gnnlm_gemm_t.precision); 0 = exact f32 */
     const float* head_w;       /* [cutoff[0] + n_bands - 1, d]: rows of E_0 followed by class_proj */
     const float* proj_t[8];    /* band b>=1: [dim_b, d] (embeddings.b.1.weight TRANSPOSED) */
     const float* emb[8];       /* band b>=1: [cutoff[b]-cutoff[b-1], dim_b] */
@@ -231,6 +233,7 @@ typedef struct gnnlm_hgt {
     const uint8_t* codes;  const void* vals;  int32_t vals_itemsize;
     int64_t n_store, row0, n_local;
     const gnnlm_hgt_layer_t* layers;   /* HOST array [n_layers] */
+    int32_t gemm_precision;    /* precision of the GEMMs (see gnnlm_gemm_t.precision); 0 = exact f32 */
 } gnnlm_hgt_t;
 
 typedef struct gnnlm_hgt_io {

@@ -98,6 +98,39 @@ def test_gemm_lse_epilogue(ops, dev, M, N, K):
     assert torch.equal(lse2[: M // 2], lse[: M // 2])
 
 
+@pytest.mark.parametrize("precision,tol", [("f32", 5e-7), ("bf16x6", 5e-7), ("bf16x3", 4e-5)])
+@pytest.mark.parametrize("M,N,K", [(130, 257, 100), (512, 1024, 1024), (64, 20002, 64)])
+def test_gemm_split_precisions(ops, dev, precision, tol, M, N, K):
+    """Opt-in split-bf16 GEMM modes against float64: bf16x6 (three bf16 planes, six cross products) is at
+    f32 level; bf16x3 (two planes, three products) at ~2^-16 per product.  Error is measured relative to
+    sum |a||b| (the scale of the rounding errors of a length-K dot product)."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g) * torch.logspace(-2, 2, K)         # wide dynamic range along k
+    W = torch.randn(N, K, generator=g)
+    ref = A.double() @ W.double().t()
+    scale = A.abs().double() @ W.abs().double().t() + 1e-30
+    out = ops.gemm_nt(A.to(dev), W.to(dev), precision=precision).cpu().double()
+    err = ((out - ref).abs() / scale).max().item()
+    assert err < tol, (precision, err)
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x6", 2e-5), ("bf16x3", 2e-4)])
+def test_adaptive_softmax_split_precision(ops, dev, precision, tol):
+    """The opt-in modes through the whole adaptive-softmax entry point (LSE epilogue included)."""
+    from gnnlm_amd.adaptive_softmax import AdaptiveSoftmax
+    from gnnlm_amd.synthetic import make_asm_weights
+    rs = np.random.RandomState(5)
+    w = make_asm_weights(rs, 5000, 128, [500, 2000])
+    asm = AdaptiveSoftmax(w["cutoff"], w["emb"], w["proj"], w["class_proj"], dev)
+    x = torch.randn(300, 128, generator=torch.Generator().manual_seed(1)).to(dev)
+    tgt = torch.from_numpy(rs.randint(0, 5000, size=300)).to(dev)
+    ref = asm.target_log_prob(x, tgt).clone()
+    asm.gemm_precision = ops.PRECISIONS[precision]
+    got = asm.target_log_prob(x, tgt)
+    assert (got - ref).abs().max().item() < tol
+    assert not torch.equal(got, ref) or precision == "bf16x6"
+
+
 def test_gemm_errors(ops, dev):
     from gnnlm_amd._lib import GnnlmError
     A = torch.randn(4, 6, device=dev)

@@ -21,6 +21,7 @@ SHAPES = [  # name, M, N, K, batch1, batch2
     ("head8k 8192x20002x1024", 8192, 20002, 1024, 1, 1),
 ]
 ORDER = int(os.environ.get("TILE_ORDER", "0"))
+PREC = int(os.environ.get("PRECISION", "0"))
 sel = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, M, N, K, b1, b2 in [s_ for s_ in SHAPES if sel in s_[0]]:
     nb = b1 * b2
@@ -31,6 +32,7 @@ for name, M, N, K, b1, b2 in [s_ for s_ in SHAPES if sel in s_[0]]:
     g.A, g.lda, g.W, g.ldw, g.C, g.ldc = A.data_ptr(), K, W.data_ptr(), K, C.data_ptr(), N
     g.M, g.N, g.K, g.batch1, g.batch2 = M, N, K, b1, b2
     g.tile_order = ORDER
+    g.precision = PREC
     g.sA1, g.sA2, g.sW1, g.sW2, g.sC1, g.sC2 = b2 * M * K, M * K, b2 * N * K, N * K, b2 * M * N, M * N
     for _ in range(3):
         _lib.call_desc("gnnlm_gemm_nt", g)
