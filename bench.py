@@ -251,7 +251,7 @@ def main():
     for i in range(max(0, args.warmup - 2)):
         step(i + 2)
     dominant = max(kern, key=lambda k_: kern[k_]["total_ms"])
-    names = [_lib.lib().gnnlm_kernel_name(i).decode() for i in range(9)]
+    names = [_lib.lib().gnnlm_kernel_name(i).decode() for i in range(10)]
     # ---- timed region: exactly K steps, the dominant kernel bracketed by HIP events on its stream
     for a in accs:
         a.zero_()

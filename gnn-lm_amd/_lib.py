@@ -11,7 +11,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(ROOT, "include", "gnnlm.h")
-LIB_PATH = os.path.join(_HERE, "lib", "libgnnlm_hip.so")
+LIB_PATH = os.environ.get("GNNLM_LIB") or os.path.join(_HERE, "lib", "libgnnlm_hip.so")   # GNNLM_LIB: A/B builds
 
 _SCALARS = {
     "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,

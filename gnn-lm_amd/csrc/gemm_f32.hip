@@ -264,63 +264,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
 #undef GNNLM_LOAD_TILE
 #undef GNNLM_STORE_TILE
 
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if constexpr (EPI == EPI_STORE) {
-        float* C = p.C + b1 * p.sC1 + b2 * p.sC2;
-        const float* bias = p.bias ? p.bias + b1 * p.sB1 + b2 * p.sB2 : nullptr;
-        const float* R = p.R ? p.R + b1 * p.sR1 + b2 * p.sR2 : nullptr;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * (BN / 2) + j * 32 + l32;
-                if (col >= p.N) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row >= M) continue;
-                    const int64_t crow = p.c_rows ? (int64_t)p.c_rows[row] : (int64_t)row;
-                    float v = (p.a_rows && p.a_rows[row] < 0) ? 0.f : acc[i][j][r] * p.alpha;
-                    if (bias) v += (p.gate ? p.gate[row] : 1.f) * (p.bias_mode == 1 ? bias[col] : bias[row]);
-                    if (R) v += R[crow * p.ldr + col];
-                    C[crow * p.ldc + col] = v;
-                }
-            }
-    } else {
-        // per row: m = max over this wave's valid columns, s = sum exp(x - m); the 32 lanes of a half
-        // hold the 32 columns of one accumulator row.  The tile's pick columns are staged in LDS once
-        // (a global load per accumulator row inside the loop costs ~30 us per tile in exposed latency).
-        const int n_parts = 2 * tiles_n;
-        int* lpick = reinterpret_cast<int*>(lds);            // the k-loop's last barrier freed the buffer
-        if (tid < BM) lpick[tid] = (p.lse_pick && m0 + tid < M) ? p.lse_pick[m0 + tid] : -1;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v[TN];
-                float mx = -INFINITY;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + wn * (BN / 2) + j * 32 + l32;
-                    v[j] = col < p.N ? acc[i][j][r] * p.alpha : -INFINITY;
-                    mx = fmaxf(mx, v[j]);
-                    if (col < p.N && lpick[row - m0] == col) p.lse_picked[row] = v[j];
-                }
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) s += v[j] == -INFINITY ? 0.f : __expf(v[j] - mx);   // v_exp_f32: arg <= 0, rel. err ~1e-7
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                if (l32 == 0 && row < M) {
-                    float2* dst = reinterpret_cast<float2*>(p.lse_part) + (int64_t)row * n_parts + 2 * tn + wn;
-                    *dst = make_float2(mx, s);
-                }
-            }
-    }
+    constexpr int WROWS = BM / 2, WCOLS = BN / 2;
+#include "gemm_epilogue.inc"
     __syncthreads();          // the next tile's prologue overwrites LDS buffer 0
     }   // tile walk
 }
@@ -346,10 +291,13 @@ __global__ __launch_bounds__(256) void lse_reduce_kernel(const float2* part, int
 
 template <int BM, int BN, int NS>
 void launch_ns(const GemmParams& p, dim3 grid, hipStream_t stream) {
-    if (p.lse_part)
-        hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, EPI_LSE, NS>), grid, dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, EPI_STORE, NS>), grid, dim3(256), 0, stream, p);
+    if constexpr (BN == 128) {          // the LSE epilogue writes one part per 64 columns = one per wave column
+        if (p.lse_part) {
+            hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, EPI_LSE, NS>), grid, dim3(256), 0, stream, p);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<BM, BN, EPI_STORE, NS>), grid, dim3(256), 0, stream, p);
 }
 template <int BM, int BN>
 void launch(const GemmParams& p, dim3 grid, hipStream_t stream) {
@@ -377,6 +325,9 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     GNNLM_REQUIRE(!p.lse_part || p.batch1 * p.batch2 == 1, "gemm: the LSE epilogue does not support batches");
     GNNLM_REQUIRE(p.tile_order >= 0 && p.tile_order <= 66, "gemm: tile_order must be 0 (auto), 1 (n fastest), 2 (m fastest) or 2+GM (bands of GM m-tiles)");
     if (p.M == 0) return OK;
+    if (p.tile_order == 0)      // share the larger operand's panel between consecutive tiles
+        p.tile_order = (!p.m_dev && (double)p.M > (double)p.N) ? 1 : 2;
+    if (gemm_split_eligible(p)) return gemm_nt_split(p, stream);      // pre-split planes + LDS-DMA (gemm_split.hip)
     const int64_t nb = (int64_t)p.batch1 * p.batch2;
     // 128x128 tiles unless they would leave CUs without a workgroup (256 CUs)
     const int64_t tiles128 = cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
@@ -384,8 +335,6 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     const int BMN = small ? 64 : 128;
     const int64_t tiles = cdiv(p.M, BMN) * cdiv(p.N, BMN);
     GNNLM_REQUIRE(tiles < (1ll << 31) && nb < 65536, "gemm: grid too large");
-    if (p.tile_order == 0)      // share the larger operand's panel between consecutive tiles
-        p.tile_order = (!p.m_dev && (double)p.M > (double)p.N) ? 1 : 2;
     // device-side M: a pool of resident workgroups (256 CUs x 3 per CU) walks the real tiles
     dim3 grid((unsigned)(p.m_dev ? std::min<int64_t>(tiles, 768) : tiles), (unsigned)nb);
     const double work = 2.0 * p.M * (double)p.N * p.K * nb;

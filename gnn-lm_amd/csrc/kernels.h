@@ -13,6 +13,9 @@ typedef gnnlm_chain_attn_t ChainAttnParams;
 typedef gnnlm_knn_interp_t KnnInterpParams;
 
 int gemm_nt(const GemmParams& p, hipStream_t stream);
+// big-tile split-bf16 path (gemm_split.hip): taken by gemm_nt for precision != 0 when the problem fills the chip
+bool gemm_split_eligible(const GemmParams& p);
+int gemm_nt_split(const GemmParams& p, hipStream_t stream);
 // precision used by gemm_nt for descriptors that leave `precision` at 0 (set by the orchestrators)
 extern thread_local int g_default_gemm_precision;
 struct GemmPrecisionScope {

@@ -99,13 +99,15 @@ def test_gemm_lse_epilogue(ops, dev, M, N, K):
 
 
 @pytest.mark.parametrize("precision,tol", [("f32", 5e-7), ("bf16x6", 5e-7), ("bf16x3", 4e-5)])
-@pytest.mark.parametrize("M,N,K", [(130, 257, 100), (512, 1024, 1024), (64, 20002, 64)])
+@pytest.mark.parametrize("M,N,K", [(130, 257, 100), (512, 1024, 1024), (64, 20002, 64),
+                                   (1000, 5000, 264),      # pre-split planes + LDS-DMA kernel, 128x128 tiles
+                                   (4100, 8200, 272)])     # the same with 256x256 tiles
 def test_gemm_split_precisions(ops, dev, precision, tol, M, N, K):
     """Opt-in split-bf16 GEMM modes against float64: bf16x6 (three bf16 planes, six cross products) is at
     f32 level; bf16x3 (two planes, three products) at ~2^-16 per product.  Error is measured relative to
     sum |a||b| (the scale of the rounding errors of a length-K dot product)."""
     g = torch.Generator().manual_seed(M + K)
-    A = torch.randn(M, K, generator=g) * torch.logspace(-2, 2, K)         # wide dynamic range along k
+    A = torch.randn(M, K + 4, generator=g)[:, :K] * torch.logspace(-2, 2, K)   # wide dynamic range along k; lda != K
     W = torch.randn(N, K, generator=g)
     ref = A.double() @ W.double().t()
     scale = A.abs().double() @ W.abs().double().t() + 1e-30

@@ -45,4 +45,9 @@ for name, M, N, K, b1, b2 in [s_ for s_ in SHAPES if sel in s_[0]]:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
-    print(f"{name:28s} {us:9.1f} us  {2.0 * M * N * K * nb / us / 1e6:7.1f} TFLOP/s")
+    _lib.profile_begin()
+    _lib.call_desc("gnnlm_gemm_nt", g)
+    torch.cuda.synchronize()
+    pr = _lib.profile_end()
+    parts = "  ".join(f"{k_.split('_kernel')[0]} {v['total_ms'] * 1e3:.0f}us" for k_, v in pr.items())
+    print(f"{name:28s} {us:9.1f} us  {2.0 * M * N * K * nb / us / 1e6:7.1f} TFLOP/s   [{parts}]")
