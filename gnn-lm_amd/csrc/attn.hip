@@ -249,44 +249,57 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Chunk-swept star attention for the PQ source (layer 1): k_g <= 128, dsub in {4, 8}, D in {512, 1024},
-// <= 8 heads per launch.
+// Chunk-swept star attention for the PQ source (layer 1): k_g <= 128, dsub in {4, 8}, D % 32 == 0,
+// <= 8 heads per launch, one token per workgroup of 4 waves.
 //
 // The generic kernel above lets every lane own a fixed slice of the 1-MiB centroid table, so a wave's
 // gathers spray over the whole table: every 32-B row costs a 128-B line from L2 (measured 1.57 ms per
 // 8192 tokens; 50 % of the wave time is spent in s_waitcnt, TA stalled by the L2).  Here the four waves of
 // a workgroup sweep the feature dimension in 32-dim chunks together.  Per chunk the token's 128 x 32 slab
 // of decoded neighbour features is built ONCE in LDS by all 256 threads (4 independent 16-B gathers per
-// thread, all inside the chunk's 4 sub-tables = 32 KiB, which stay in the CU's L1), double-buffered so the
-// gathers of chunk c+1 fly under the math of chunk c; the math itself only reads LDS.
-//   pass 1: lane = (dq, ng) (float4 of the chunk, neighbour group); acc[it][h] += x . U[h]; the partial
-//           dot products are reduced over the 8 dq-lanes ONCE per token (96 DPP shuffles).
+// thread, all inside the chunk's 4 sub-tables = 32 KiB, which stay in the CU's L1); the math only reads LDS.
+// Everything the loop waits for is two chunks ahead of its use: the gathers of chunk c+2 and the query
+// slice U of chunk c+1 are in flight (in a second register set; the loop is unrolled by two so the sets
+// have static names) while chunk c is computed, and the slab of chunk c+1 is committed to the other LDS
+// buffer before the chunk's single barrier.
+//   pass 1 (f32 matrix cores): S[128 nb x 16 (8 real) heads] += X[128 x 32] . U^T per chunk as
+//           v_mfma_f32_16x16x4_f32; wave w owns neighbours 32w..32w+31 (two accumulator tiles, 16 MFMAs per
+//           chunk); the chunk's query rows U[h] ride in the slab as rows 128..135.  The scores come out of
+//           the accumulators whole: no cross-lane reduction (the VALU formulation spent 64 v_pk_fma + ~100
+//           VALU bookkeeping instructions per chunk per wave and 96 DPP shuffles per token here).
 //   softmax per head over the neighbours (LDS).
-//   pass 2: wave w owns heads 2w, 2w+1 for ALL neighbours; lane = (dq, head, neighbour group of 4); two
-//           xor-shuffle steps (fixed order, deterministic) finish a chunk, whose 128-B pieces of Z are
-//           stored straight away -- 4 accumulator registers, no cross-wave reduction.
-template <int DSUB, int CD, int KT>
-__global__ __launch_bounds__(256 * KT) void star_attn_sweep_kernel(StarAttnParams p, int h0) {
-    // KT tokens per workgroup (256 threads each) sweep the chunks in lockstep so that a chunk's sub-tables
-    // (CD/DSUB x 8 KiB) could serve all KT tokens from the CU's L1.  Measured: it does not pay (the wider
-    // barriers cost more than the L1 reuse saves), KT = 1 is the default; the template stays for re-tuning.
-    constexpr int KGM = 128;
-    constexpr int NDQ = CD / 4;                 // float4 per chunk row (4 or 8)
+//   pass 2 (f32 matrix cores): per chunk Z[16 (8 real) heads x 32 dims] = alpha^T [16 x 128] . X [128 x 32]
+//           as v_mfma_f32_16x16x4_f32.  Wave w owns column tile w & 1 and the neighbour half w >> 1
+//           (16 MFMAs per chunk); the A operand (alpha) lives in 16 registers for the whole sweep, the B
+//           operand is ONE ds_read_b32 per MFMA, so the slab is read exactly once (a VALU formulation with
+//           lanes = (dq, head, neighbour group) re-reads it once per head: 128 KiB of LDS reads per chunk).
+//           The two neighbour halves meet through a 2-KiB LDS buffer after the chunk's barrier.
+// Slab rows are 36 floats apart: 36 r mod 64 runs over the 16 multiples of 4, so the pass-1 operand read
+// (16 rows x 4 consecutive dims) touches 64 different banks; pass 2 groups the neighbours 4 apart into one
+// k-step (rows 4 apart = 16 banks apart: 4 rows x 16 consecutive dims, again 64 different banks).
+// Measured at T = 8192, WikiText-103 shape: generic 1.57 ms; swept, VALU pass 2, depth-1 prefetch 1.42 ms;
+// + MFMA pass 2 1.36 ms; + depth-2 prefetch of gathers and U: see DESIGN.md.
+#ifndef GNNLM_STAR_EXP
+#define GNNLM_STAR_EXP 0
+#endif
+template <int DSUB>
+__global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, int h0) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int KGM = 128, CD = 32;
+    constexpr int XS = CD + 4;                  // slab row stride (floats), see the bank notes above
+    constexpr int SLAB = (KGM + HB) * XS;       // 128 neighbour rows + the 8 query rows U[h] of the chunk
+    constexpr int NDQ = CD / 4;                 // float4 per chunk row
     constexpr int SCS = KGM + 4;                // score row stride: heads land on different banks
-    constexpr int NG1 = 64 / NDQ, ITS = 32 / NG1;          // pass 1: neighbour groups per wave, iterations
-    constexpr int NG2 = 32 / NDQ, JJ2 = KGM / NG2;         // pass 2: neighbour groups (2 heads per wave)
-    constexpr int NF = KGM * NDQ / 256;         // float4 decoded per thread per chunk (2 or 4)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = p.D, NCH = D / CD;
     const int kg = p.kg, M = p.M, H = p.H;
     const int MS = M + 4;                       // padded code row stride (bytes): conflict-free column reads
-    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    const size_t grp_floats = 2 * KGM * CD + HB * SCS + (size_t)(KGM * MS + 3) / 4;
-    float* xc = smem + grp * grp_floats;                            // [2][KGM][CD] decoded slabs
-    float* sc = xc + 2 * KGM * CD;                                  // [HB][SCS] scores -> alphas
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* xc = smem;                                               // [2][KGM + HB][XS] decoded slabs + query rows
+    float* sc = xc + 2 * SLAB;                                      // [HB][SCS] scores -> alphas
     uint8_t* lcodes = reinterpret_cast<uint8_t*>(sc + HB * SCS);    // [KGM][MS]
-    const int i = min(KT * (int)blockIdx.x + grp, p.T - 1);         // surplus groups redo the last token
-    const bool live = KT * (int)blockIdx.x + grp < p.T;
+    float* zpart = reinterpret_cast<float*>(lcodes + ((KGM * MS + 15) & ~15));     // [2][2 tiles][4][64]
+    const int i = blockIdx.x;
     const int64_t* ids = p.ids + (int64_t)i * kg;
 
     {   // stage the code rows (zeros for invalid neighbours): 16-B global pieces, coalesced
@@ -304,72 +317,70 @@ __global__ __launch_bounds__(256 * KT) void star_attn_sweep_kernel(StarAttnParam
     __syncthreads();
 
     const float* cen = p.centroids;
-    // slab builder: thread t decodes float4 `t % NDQ` of the neighbours (t / NDQ) + (256/NDQ) q.  For a fixed
-    // q consecutive lanes write consecutive 16-B pieces (conflict-free ds_write_b128) and lane pairs fetch
-    // the two halves of one 32-B centroid row.
+    // slab builder: thread t decodes float4 `t % 8` of the neighbours (t / 8) + 32 q, q = 0..3; lane pairs
+    // fetch the two halves of one 32-B centroid row.  Threads 0..63 also carry the chunk's query rows
+    // (pass 1): float4 `t % 8` of head t / 8.
     const int ddq = tid % NDQ, dj0 = tid / NDQ;
     const int dm_in = (4 * ddq) / DSUB, dwithin = (4 * ddq) % DSUB;
-    float4 xr0, xr1, xr2, xr3;
-    xr2 = xr3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* Uq = p.U + ((int64_t)i * H + h0 + min(dj0 & 7, H - 1 - h0)) * D + 4 * ddq;
+    float4 xrA0, xrA1, xrA2, xrA3, xrB0, xrB1, xrB2, xrB3, uqA, uqB;
+    uqA = uqB = make_float4(0.f, 0.f, 0.f, 0.f);
 #define GNNLM_FETCH1(XR, Q, m_)                                                                         \
     XR = *reinterpret_cast<const float4*>(                                                              \
-        cen + ((int64_t)((m_) * 256 + lcodes[(dj0 + (256 / NDQ) * (Q)) * MS + (m_)])) * DSUB + dwithin);
-#define GNNLM_FETCH(c)                                                                                  \
-    {                                                                                                   \
+        cen + ((int64_t)((m_) * 256 + (GNNLM_STAR_EXP == 3 ? 0 : lcodes[(dj0 + 32 * (Q)) * MS + (m_)]))) * DSUB + dwithin);
+#define GNNLM_FETCH(c, S, WITH_U)                                                                       \
+    if ((c) < NCH) {                                                                                    \
         const int m_ = (c) * (CD / DSUB) + dm_in;                                                       \
-        GNNLM_FETCH1(xr0, 0, m_) GNNLM_FETCH1(xr1, 1, m_)                                               \
-        if constexpr (NF > 2) { GNNLM_FETCH1(xr2, 2, m_) GNNLM_FETCH1(xr3, 3, m_) }                     \
+        GNNLM_FETCH1(xr##S##0, 0, m_) GNNLM_FETCH1(xr##S##1, 1, m_)                                     \
+        GNNLM_FETCH1(xr##S##2, 2, m_) GNNLM_FETCH1(xr##S##3, 3, m_)                                     \
+        if (WITH_U && tid < 64) uq##S = *reinterpret_cast<const float4*>(Uq + (c) * CD);                \
     }
-#define GNNLM_COMMIT(buf)                                                                               \
-    {                                                                                                   \
-        float* d_ = xc + ((buf) * KGM + dj0) * CD + 4 * ddq;                                            \
-        *reinterpret_cast<float4*>(d_) = xr0;                                                           \
-        *reinterpret_cast<float4*>(d_ + (256 / NDQ) * CD) = xr1;                                        \
-        if constexpr (NF > 2) {                                                                         \
-            *reinterpret_cast<float4*>(d_ + 2 * (256 / NDQ) * CD) = xr2;                                \
-            *reinterpret_cast<float4*>(d_ + 3 * (256 / NDQ) * CD) = xr3;                                \
-        }                                                                                               \
+#define GNNLM_COMMIT(buf, S, c, WITH_U)                                                                 \
+    if ((c) < NCH) {                                                                                    \
+        float* d_ = xc + (buf) * SLAB + dj0 * XS + 4 * ddq;                                             \
+        *reinterpret_cast<float4*>(d_) = xr##S##0;                                                      \
+        *reinterpret_cast<float4*>(d_ + 32 * XS) = xr##S##1;                                            \
+        *reinterpret_cast<float4*>(d_ + 64 * XS) = xr##S##2;                                            \
+        *reinterpret_cast<float4*>(d_ + 96 * XS) = xr##S##3;                                            \
+        if (WITH_U && tid < 64) *reinterpret_cast<float4*>(d_ + 128 * XS) = uq##S;                      \
     }
 
-    // ---------------- pass 1: lane = (dq, ng); acc[it][h] += x . U[h]
+    const int n16 = lane & 15, g = lane >> 4;
+    // ---------------- pass 1 on the f32 matrix cores: S[128 nb x 16 (8 real) heads] += X[128 x 32] . U^T
     {
-        const int dq = lane % NDQ, ng = lane / NDQ;
-        float acc[ITS][HB];
-#pragma unroll
-        for (int it = 0; it < ITS; ++it)
-#pragma unroll
-            for (int h = 0; h < HB; ++h) acc[it][h] = 0.f;
-        const float* Ui = p.U + ((int64_t)i * H + h0) * D + 4 * dq;
-        GNNLM_FETCH(0);
-        GNNLM_COMMIT(0);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* xa = xc + (32 * wave + n16) * XS + g;          // A: X[nb = 32 w + 16 rt + n16][4 ks + g]
+        const float* ub = xc + (KGM + (n16 & 7)) * XS + g;          // B: U[head n16][4 ks + g] (columns 8..15: unused copies)
+#define GNNLM_PASS1(buf)                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < (GNNLM_STAR_EXP == 1 ? 0 : 8); ++ks) {                      \
+        const float b_ = ub[(buf) * SLAB + 4 * ks];                                                     \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(buf) * SLAB + 4 * ks], b_, acc0, 0, 0, 0);      \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(buf) * SLAB + 16 * XS + 4 * ks], b_, acc1, 0, 0, 0); \
+    }
+        GNNLM_FETCH(0, A, true)
+        GNNLM_COMMIT(0, A, 0, true)
+        GNNLM_FETCH(1, B, true)
         __syncthreads();
-        for (int c = 0; c < NCH; ++c) {
-            float4 u[HB];
-#pragma unroll
-            for (int h = 0; h < HB; ++h)
-                u[h] = *reinterpret_cast<const float4*>(Ui + (int64_t)min(h, H - 1 - h0) * D + c * CD);
-            if (c + 1 < NCH) GNNLM_FETCH(c + 1);
-            const float* xb = xc + ((c & 1) * KGM + 32 * wave + ng) * CD + 4 * dq;
-#pragma unroll
-            for (int it = 0; it < ITS; ++it) {
-                const float4 x = *reinterpret_cast<const float4*>(xb + NG1 * it * CD);
-#pragma unroll
-                for (int h = 0; h < HB; ++h)
-                    acc[it][h] = fmaf(x.x, u[h].x, fmaf(x.y, u[h].y, fmaf(x.z, u[h].z, fmaf(x.w, u[h].w, acc[it][h]))));
-            }
-            if (c + 1 < NCH) GNNLM_COMMIT((c + 1) & 1);
+        for (int c = 0; c < NCH; c += 2) {
+            GNNLM_FETCH(c + 2, A, true)
+            GNNLM_PASS1(0)
+            GNNLM_COMMIT(1, B, c + 1, true)
             __syncthreads();
+            if (c + 1 < NCH) {
+                GNNLM_FETCH(c + 3, B, true)
+                GNNLM_PASS1(1)
+                GNNLM_COMMIT(0, A, c + 2, true)
+                __syncthreads();
+            }
         }
+#undef GNNLM_PASS1
+        // C layout: acc_rt[r] = S[nb = 32 w + 16 rt + 4 g + r][head n16]
+        if (n16 < HB) {
 #pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            const int j = 32 * wave + ng + NG1 * it;
-            const bool ok = j < kg && ids[j] >= 0;
-#pragma unroll
-            for (int h = 0; h < HB; ++h) {
-                float v = acc[it][h];
-#pragma unroll
-                for (int o = 1; o < NDQ; o <<= 1) v += __shfl_xor(v, o, 64);
-                if (dq == 0) sc[h * SCS + j] = ok ? v : -INFINITY;
+            for (int r = 0; r < 4; ++r) {
+                const int j0 = 32 * wave + 4 * g + r, j1 = j0 + 16;
+                sc[n16 * SCS + j0] = (j0 < kg && ids[j0] >= 0) ? acc0[r] : -INFINITY;
+                sc[n16 * SCS + j1] = (j1 < kg && ids[j1] >= 0) ? acc1[r] : -INFINITY;
             }
         }
     }
@@ -383,37 +394,57 @@ __global__ __launch_bounds__(256 * KT) void star_attn_sweep_kernel(StarAttnParam
         const float inv = sum > 0.f ? 1.f / sum : 0.f;
         sc[h * SCS + lane] = e0 * inv;
         sc[h * SCS + 64 + lane] = e1 * inv;
-        if (h == 0 && h0 == 0 && lane == 0 && p.has_nb && live) p.has_nb[i] = sum > 0.f ? 1.f : 0.f;
+        if (h == 0 && h0 == 0 && lane == 0 && p.has_nb) p.has_nb[i] = sum > 0.f ? 1.f : 0.f;
     }
-    // ---------------- pass 2: wave w owns heads 2w, 2w+1 over ALL neighbours; lane = (dq, hh, ng)
+    // ---------------- pass 2 on the f32 matrix cores: Z[16 (8 real) heads x 32 dims] = alpha^T . X per chunk
     {
-        const int dq = lane % NDQ, hh = (lane / NDQ) & 1, ng = lane / (2 * NDQ);
-        const int h = 2 * wave + hh;
-        const float* al = sc + h * SCS;
-        GNNLM_FETCH(0);
-        GNNLM_COMMIT(0);
+        const int tile = wave & 1, kh = wave >> 1;
+        GNNLM_FETCH(0, A, false)
+        GNNLM_COMMIT(0, A, 0, false)
+        GNNLM_FETCH(1, B, false)
         __syncthreads();                       // also orders the softmax writes before the alpha reads
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 1 < NCH) GNNLM_FETCH(c + 1);
-            const float* xb = xc + ((c & 1) * KGM + ng) * CD + 4 * dq;
-            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-            for (int jj = 0; jj < JJ2; ++jj) {
-                const float4 x = *reinterpret_cast<const float4*>(xb + NG2 * jj * CD);
-                const float a = al[ng + NG2 * jj];
-                z.x = fmaf(a, x.x, z.x); z.y = fmaf(a, x.y, z.y);
-                z.z = fmaf(a, x.z, z.z); z.w = fmaf(a, x.w, z.w);
-            }
+        // k-step ks, lane group g  <->  neighbour j = 64 kh + 16 (ks / 4) + (ks % 4) + 4 g: rows 4 apart are
+        // 16 banks apart at a 36-float stride
+        float a_reg[16];
 #pragma unroll
-            for (int o = 2 * NDQ; o < 64; o <<= 1) {        // reduce the neighbour groups (fixed order)
-                z.x += __shfl_xor(z.x, o, 64); z.y += __shfl_xor(z.y, o, 64);
-                z.z += __shfl_xor(z.z, o, 64); z.w += __shfl_xor(z.w, o, 64);
-            }
-            if (ng == 0 && h0 + h < H && live)
-                *reinterpret_cast<float4*>(p.Z + ((int64_t)i * H + h0 + h) * D + c * CD + 4 * dq) = z;
-            if (c + 1 < NCH) GNNLM_COMMIT((c + 1) & 1);
+        for (int ks = 0; ks < 16; ++ks)
+            a_reg[ks] = n16 < HB ? sc[n16 * SCS + 64 * kh + 16 * (ks >> 2) + (ks & 3) + 4 * g] : 0.f;
+        const float* xb0 = xc + (64 * kh + 4 * g) * XS + 16 * tile + n16;
+        float* zp0 = zpart + tile * 256 + lane;
+        float* zo0 = p.Z + ((int64_t)i * H + h0 + 4 * g) * D + 16 * tile + n16;
+        // C layout of the 16x16 tile: acc[r] = Z[head 4g + r][dim 16 tile + n16]
+#define GNNLM_PASS2(buf, c)                                                                             \
+    {                                                                                                   \
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < (GNNLM_STAR_EXP == 2 ? 0 : 16); ++ks)                   \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], xb0[(buf) * SLAB + (16 * (ks >> 2) + (ks & 3)) * XS], acc, 0, 0, 0); \
+        float* zp = zp0 + (buf) * 512;                                                                  \
+        if (kh == 1) { zp[0] = acc[0]; zp[64] = acc[1]; zp[128] = acc[2]; zp[192] = acc[3]; }           \
+        zacc = acc;                                                                                     \
+    }
+#define GNNLM_ZSTORE(buf, c)                                                                            \
+    if (kh == 0 && g < 2) {                                                                             \
+        const float* zp = zp0 + (buf) * 512;                                                            \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
+            if (h0 + 4 * g + r < H) zo0[(int64_t)r * D + (c) * CD] = zacc[r] + zp[64 * r];              \
+    }
+        f32x4 zacc;
+        for (int c = 0; c < NCH; c += 2) {
+            GNNLM_FETCH(c + 2, A, false)
+            GNNLM_PASS2(0, c)
+            GNNLM_COMMIT(1, B, c + 1, false)
             __syncthreads();
+            GNNLM_ZSTORE(0, c)
+            if (c + 1 < NCH) {
+                GNNLM_FETCH(c + 3, B, false)
+                GNNLM_PASS2(1, c + 1)
+                GNNLM_COMMIT(0, A, c + 2, false)
+                __syncthreads();
+                GNNLM_ZSTORE(1, c + 1)
+            }
         }
+#undef GNNLM_PASS2
+#undef GNNLM_ZSTORE
     }
 #undef GNNLM_FETCH
 #undef GNNLM_FETCH1
@@ -547,26 +578,12 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
     if (p.codes && p.kg <= 128 && (p.dsub == 4 || p.dsub == 8) && p.M % 16 == 0 && p.D % 32 == 0 &&
         (uintptr_t)p.codes % 16 == 0 && !getenv("GNNLM_STAR_GENERIC")) {
         ProfScope prof(K_STAR, stream, 4.0 * rows * p.H * p.D, rows * (8.0 + p.M) + 8.0 * p.T * p.H * p.D);
-        // tokens per workgroup: 1 measured fastest (T = 8192: KT=1 1.42 ms, KT=2 1.74 ms, KT=4 1.79 ms; generic 1.57 ms)
-        static const int kt = getenv("GNNLM_STAR_KT") ? atoi(getenv("GNNLM_STAR_KT")) : 1;
         const int MS = p.M + 4;
-        auto lds_bytes = [&](int cd, int k) {
-            return (size_t)k * 4 * (2 * 128 * cd + HB * 132 + (size_t)(128 * MS + 3) / 4);
-        };
+        const size_t lds_bytes = 4 * (size_t)(2 * (128 + HB) * 36 + HB * 132 + (128 * MS + 15) / 4 + 1024);
         for (int h0 = 0; h0 < p.H; h0 += HB) {
-            if (kt == 4) {
-                dim3 grid((p.T + 3) / 4), block(1024);
-                if (p.dsub == 8) hipLaunchKernelGGL((star_attn_sweep_kernel<8, 16, 4>), grid, block, lds_bytes(16, 4), stream, p, h0);
-                else hipLaunchKernelGGL((star_attn_sweep_kernel<4, 16, 4>), grid, block, lds_bytes(16, 4), stream, p, h0);
-            } else if (kt == 2) {
-                dim3 grid((p.T + 1) / 2), block(512);
-                if (p.dsub == 8) hipLaunchKernelGGL((star_attn_sweep_kernel<8, 32, 2>), grid, block, lds_bytes(32, 2), stream, p, h0);
-                else hipLaunchKernelGGL((star_attn_sweep_kernel<4, 32, 2>), grid, block, lds_bytes(32, 2), stream, p, h0);
-            } else {
-                dim3 grid(p.T), block(256);
-                if (p.dsub == 8) hipLaunchKernelGGL((star_attn_sweep_kernel<8, 32, 1>), grid, block, lds_bytes(32, 1), stream, p, h0);
-                else hipLaunchKernelGGL((star_attn_sweep_kernel<4, 32, 1>), grid, block, lds_bytes(32, 1), stream, p, h0);
-            }
+            dim3 grid(p.T), block(256);
+            if (p.dsub == 8) hipLaunchKernelGGL((star_attn_sweep_kernel<8>), grid, block, lds_bytes, stream, p, h0);
+            else hipLaunchKernelGGL((star_attn_sweep_kernel<4>), grid, block, lds_bytes, stream, p, h0);
         }
         GNNLM_LAUNCH_CHECK();
         return OK;
