@@ -60,15 +60,45 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + idx;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on the VALU (DPP + the gfx950 permlane swaps): no LDS round trips, unlike
+// __shfl_xor (ds_bpermute_b32).  Fixed combination order, every lane ends up with the result.
+//   row16_*: over the 16 lanes of a DPP row;  half32_*: over lanes 0..31 / 32..63;  wave_*: all 64.
+#define GNNLM_DPP(v_, ctrl_) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v_), __float_as_int(v_), ctrl_, 0xf, 0xf, false))
+__device__ __forceinline__ float row16_sum(float v) {
+    v += GNNLM_DPP(v, 0xB1);     // quad_perm [1,0,3,2]
+    v += GNNLM_DPP(v, 0x4E);     // quad_perm [2,3,0,1]
+    v += GNNLM_DPP(v, 0x141);    // row_half_mirror
+    v += GNNLM_DPP(v, 0x140);    // row_mirror
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, GNNLM_DPP(v, 0xB1));
+    v = fmaxf(v, GNNLM_DPP(v, 0x4E));
+    v = fmaxf(v, GNNLM_DPP(v, 0x141));
+    v = fmaxf(v, GNNLM_DPP(v, 0x140));
     return v;
+}
+#undef GNNLM_DPP
+typedef unsigned gnnlm_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float half32_sum(float v) {
+    v = row16_sum(v);
+    const gnnlm_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);          // (row 0, row 1) / (row 2, row 3)
+}
+__device__ __forceinline__ float half32_max(float v) {
+    v = row16_max(v);
+    const gnnlm_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = half32_sum(v);
+    const gnnlm_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = half32_max(v);
+    const gnnlm_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 
 }  // namespace gnnlm
