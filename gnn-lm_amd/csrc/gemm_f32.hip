@@ -71,63 +71,61 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
     int M = p.M;
     if (p.m_dev) M = min(M, *p.m_dev);
     const int tiles_n = (p.N + BN - 1) / BN;
-    // Tile walk.  Host-known M: one tile per workgroup (XCD-chunked list).  Device-side M: the grid
-    // is a fixed pool of workgroups striding over the REAL tiles only -- launching one workgroup per
-    // worst-case tile costs ~10 ns of dispatch each, 3x the useful work on the 207,744-word tail band.
+    // Tile walk: the grid is a pool of resident workgroups (gemm_nt sizes it to the chip) walking the list of
+    // REAL (batch, tile) pairs -- with a device-side row count a workgroup per worst-case tile would cost
+    // ~10 ns of dispatch each, 3x the useful work on the 207,744-word tail band.  Virtual index v -> list
+    // position through xcd_remap: every XCD (block b runs on XCD b % 8; the pool size is a multiple of 8)
+    // walks its own contiguous chunk of the list, so concurrently running tiles share operand panels in
+    // that XCD's L2.  The first k-tile of a workgroup's NEXT tile is loaded before the epilogue of the
+    // current one, so short-K problems (K = 64 tail band, K = 128 absorbed queries) do not expose a
+    // load latency per tile.
     const int tiles_m = ((p.m_dev ? M : p.M) + BM - 1) / BM;
     const unsigned n_tiles = (unsigned)(tiles_m * tiles_n);
-    const unsigned t_step = p.m_dev ? gridDim.x : n_tiles;
-    for (unsigned t = p.m_dev ? blockIdx.x : xcd_remap(blockIdx.x, n_tiles); t < n_tiles; t += t_step) {
-    int tm, tn;
-    if (p.tile_order == 1) { tm = t / tiles_n; tn = t % tiles_n; }      // n fastest
-    else if (p.tile_order == 2) { tn = t / tiles_m; tm = t % tiles_m; } // m fastest
-    else {
-        // grouped: bands of GM m-tiles; inside a band n is the slow index.  GM A-panels (GM x 512 KiB at
-        // K = 1024) stay in the XCD's 4-MiB L2 while the W panels stream through once per band.
-        const int GM = p.tile_order - 2;
-        const int band = t / (GM * tiles_n);
-        const int m_in = min(GM, tiles_m - band * GM);
-        const int r = t - band * GM * tiles_n;
-        tn = r / m_in;
-        tm = band * GM + r % m_in;
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const unsigned n_work = n_tiles * (unsigned)(p.batch1 * p.batch2);
+    unsigned v = blockIdx.x;
+    if (v >= n_work) return;
 
-    const int b1 = blockIdx.y / p.batch2, b2 = blockIdx.y % p.batch2;
-    const float* A = p.A + b1 * p.sA1 + b2 * p.sA2;
-    const float* W = p.W + b1 * p.sW1 + b2 * p.sW2;
-
-    // Staging rows: out-of-range rows / k are read from a clamped (valid) address and zeroed by a
-    // select, so the loads stay unconditional.
     const int kq = (tid & 7) * 4;
     const int srow = tid >> 3;
     const float* ap[LA];
     const float* wp[LW];
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        const int gr = m0 + srow + 32 * i;
-        int64_t ar = gr < M ? (p.a_rows ? (int64_t)p.a_rows[gr] : (int64_t)gr) : 0;
-        if (ar < 0) ar = 0;                      // negative gather index = zero row, applied in the epilogue
-        ap[i] = A + ar * p.lda;
-    }
-#pragma unroll
-    for (int i = 0; i < LW; ++i) {
-        const int gn = n0 + srow + 32 * i;
-        wp[i] = W + (int64_t)(gn < p.N ? gn : 0) * p.ldw;
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     float4 ra[LA], rw[LW];
     const int nk_full = p.K / BK;              // full k-tiles: loaded without any guard
     const bool k_tail = (p.K % BK) != 0;       // one partial tile, peeled after the main loop
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int m0x, n0x, b1x, b2x;                    // the tile whose first k-tile is in flight
+
+    // (batch, tile) of list position w_, then the staging row pointers: out-of-range rows read a clamped
+    // (valid) address, so the loads stay unconditional.
+#define GNNLM_TILE_SETUP(w_)                                                                 \
+    {                                                                                        \
+        const unsigned by_ = (w_) / n_tiles, t = (w_) - by_ * n_tiles;                       \
+        b1x = by_ / p.batch2; b2x = by_ % p.batch2;                                          \
+        int tm, tn;                                                                          \
+        if (p.tile_order == 1) { tm = t / tiles_n; tn = t % tiles_n; }                       \
+        else if (p.tile_order == 2) { tn = t / tiles_m; tm = t % tiles_m; }                  \
+        else {   /* bands of GM m-tiles; inside a band n is the slow index */                \
+            const int GM = p.tile_order - 2;                                                 \
+            const int band = t / (GM * tiles_n);                                             \
+            const int m_in = min(GM, tiles_m - band * GM);                                   \
+            const int r = t - band * GM * tiles_n;                                           \
+            tn = r / m_in;                                                                   \
+            tm = band * GM + r % m_in;                                                       \
+        }                                                                                    \
+        m0x = tm * BM; n0x = tn * BN;                                                        \
+        const float* A_ = p.A + b1x * p.sA1 + b2x * p.sA2;                                   \
+        const float* W_ = p.W + b1x * p.sW1 + b2x * p.sW2;                                   \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                     \
+            const int gr = m0x + srow + 32 * i;                                              \
+            int64_t ar = gr < M ? (p.a_rows ? (int64_t)p.a_rows[gr] : (int64_t)gr) : 0;      \
+            if (ar < 0) ar = 0;      /* negative gather index = zero row, applied in the epilogue */ \
+            ap[i] = A_ + ar * p.lda;                                                         \
+        }                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < LW; ++i) {                                     \
+            const int gn = n0x + srow + 32 * i;                                              \
+            wp[i] = W_ + (int64_t)(gn < p.N ? gn : 0) * p.ldw;                               \
+        }                                                                                    \
+    }
 
     // No select on the loaded data in the main loop: a select would need the value and so put an
     // s_waitcnt right behind every global load, serialising HBM latency with the 64 MFMAs of the
@@ -201,7 +199,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
 #define GNNLM_SPLIT_MFMA(PA, PB)                                                             \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                       \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][i], fb[PB][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = EPI == EPI_LSE ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][j], fa[PA][i], acc[i][j], 0, 0, 0)  \
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][i], fb[PB][j], acc[i][j], 0, 0, 0);
 #define GNNLM_COMPUTE(buf)                                                                   \
     if constexpr (NS != 0) {                                                                 \
         const char* base_ = reinterpret_cast<const char*>(lds);                              \
@@ -227,35 +226,73 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
                 b[j] = *reinterpret_cast<const float4*>(w_base + 32 * j * LDS_LD + 8 * s_);  \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                   \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j) {                             \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0); \
+                    /* LSE epilogue: operands swapped = transposed accumulator tile (gemm_epilogue.inc) */ \
+                    if constexpr (EPI == EPI_LSE) {                                          \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].x, a[i].x, acc[i][j], 0, 0, 0); \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].y, a[i].y, acc[i][j], 0, 0, 0); \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].z, a[i].z, acc[i][j], 0, 0, 0); \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].w, a[i].w, acc[i][j], 0, 0, 0); \
+                    } else {                                                                 \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0); \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0); \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0); \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0); \
+                    }                                                                        \
                 }                                                                            \
         }                                                                                    \
     }
 
-    if (nk_full > 0) {
-        GNNLM_LOAD_TILE(0);
+#define GNNLM_LOAD_FIRST()                                                                   \
+    if (nk_full > 0) GNNLM_LOAD_TILE(0) else GNNLM_LOAD_TILE_GUARDED(0)
+
+    GNNLM_TILE_SETUP(xcd_remap(v, n_work))
+    GNNLM_LOAD_FIRST()
+    for (;;) {
+        const int m0 = m0x, n0 = n0x, b1 = b1x, b2 = b2x;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
         GNNLM_STORE_TILE(0);
         __syncthreads();
-        for (int kt = 0; kt < nk_full; ++kt) {
-            constexpr bool ONE_BUF = NBUF == 1 || NS != 0;
-            const int buf = ONE_BUF ? 0 : (kt & 1);
-            if (kt + 1 < nk_full) GNNLM_LOAD_TILE(kt + 1);
-            GNNLM_COMPUTE(buf);
-            if (ONE_BUF) __syncthreads();
-            if (kt + 1 < nk_full) { GNNLM_STORE_TILE(ONE_BUF ? 0 : (buf ^ 1)); }
+        if (nk_full > 0) {
+            for (int kt = 0; kt < nk_full; ++kt) {
+                constexpr bool ONE_BUF = NBUF == 1 || NS != 0;
+                const int buf = ONE_BUF ? 0 : (kt & 1);
+                if (kt + 1 < nk_full) GNNLM_LOAD_TILE(kt + 1);
+                GNNLM_COMPUTE(buf);
+                if (ONE_BUF) __syncthreads();
+                if (kt + 1 < nk_full) { GNNLM_STORE_TILE(ONE_BUF ? 0 : (buf ^ 1)); }
+                __syncthreads();
+            }
+            if (k_tail) {
+                GNNLM_LOAD_TILE_GUARDED(nk_full);
+                GNNLM_STORE_TILE(0);
+                __syncthreads();
+                GNNLM_COMPUTE(0);
+                __syncthreads();
+            }
+        } else {            // K < BK: the single guarded tile is the one loaded ahead
+            GNNLM_COMPUTE(0);
             __syncthreads();
         }
+        v += gridDim.x;
+        const bool has_next = v < n_work;
+        if (has_next) {
+            GNNLM_TILE_SETUP(xcd_remap(v, n_work))
+            GNNLM_LOAD_FIRST()
+        }
+        constexpr int WROWS = BM / 2, WCOLS = BN / 2;
+#include "gemm_epilogue.inc"
+        __syncthreads();          // the next tile's first k-tile overwrites LDS buffer 0
+        if (!has_next) break;
     }
-    if (k_tail) {
-        GNNLM_LOAD_TILE_GUARDED(nk_full);
-        GNNLM_STORE_TILE(0);
-        __syncthreads();
-        GNNLM_COMPUTE(0);
-        __syncthreads();
-    }
+#undef GNNLM_LOAD_FIRST
+#undef GNNLM_TILE_SETUP
 #undef GNNLM_LOAD_TILE_GUARDED
 #undef GNNLM_COMPUTE
 #undef GNNLM_SPLIT_MFMA
@@ -263,11 +300,6 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
 #undef GNNLM_PK_TRUNC
 #undef GNNLM_LOAD_TILE
 #undef GNNLM_STORE_TILE
-
-    constexpr int WROWS = BM / 2, WCOLS = BN / 2;
-#include "gemm_epilogue.inc"
-    __syncthreads();          // the next tile's prologue overwrites LDS buffer 0
-    }   // tile walk
 }
 
 // lse[row] = log sum exp over the row's partial (max, sum) pairs
@@ -333,10 +365,11 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     const int64_t tiles128 = cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
     const bool small = !p.lse_part && tiles128 < 256;
     const int BMN = small ? 64 : 128;
-    const int64_t tiles = cdiv(p.M, BMN) * cdiv(p.N, BMN);
-    GNNLM_REQUIRE(tiles < (1ll << 31) && nb < 65536, "gemm: grid too large");
-    // device-side M: a pool of resident workgroups (256 CUs x 3 per CU) walks the real tiles
-    dim3 grid((unsigned)(p.m_dev ? std::min<int64_t>(tiles, 768) : tiles), (unsigned)nb);
+    const int64_t tiles = cdiv(p.M, BMN) * cdiv(p.N, BMN) * nb;
+    GNNLM_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
+    // pool of resident workgroups: 256 CUs x the kernel variant's workgroups per CU (a multiple of 8 = XCDs)
+    const int64_t pool = 256 * (small ? 4 : (p.precision == 2 ? 2 : 3));
+    dim3 grid((unsigned)std::min<int64_t>(tiles, pool));
     const double work = 2.0 * p.M * (double)p.N * p.K * nb;
     ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N) * nb,
                    p.m_dev, (double)p.M);

@@ -168,7 +168,8 @@ void gemm_planes_kernel(const GemmParams p, const uint4* __restrict__ Ap, const 
 #define GNNLM_SPLIT_MFMA(PA, PB)                                                             \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                       \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][i], fb[PB][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = EPI == EPI_LSE ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][j], fa[PA][i], acc[i][j], 0, 0, 0)  \
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][i], fb[PB][j], acc[i][j], 0, 0, 0);
 
     f32x16 acc[TM][TN];
 #pragma unroll

@@ -191,6 +191,73 @@ __global__ __launch_bounds__(256) void knn_interp_kernel(KnnInterpParams p, floa
     }
 }
 
+// k <= 64 * JMAX: every lane keeps its JMAX (id, sim) pairs in registers and has all its label gathers
+// (random 4-B reads of the 413-MB table, the kernel's cost) in flight at once; one pass.  Same summation
+// order as the generic kernel above.
+template <int JMAX>
+__global__ __launch_bounds__(256) void knn_interp_regs_kernel(KnnInterpParams p, float log_1ml, float log_l) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.n) return;
+    const float* sims = p.sims + i * p.k;
+    const int64_t* ids = p.ids + i * p.k;
+    int64_t id[JMAX];
+    float sv[JMAX];
+    int64_t val[JMAX];
+#pragma unroll
+    for (int t = 0; t < JMAX; ++t) {
+        const int j = lane + 64 * t;
+        id[t] = j < p.k ? ids[j] : -1;
+        sv[t] = j < p.k ? sims[j] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < JMAX; ++t) {
+        const int j = lane + 64 * t;
+        val[t] = -1;
+        if (j < p.k) {
+            if (p.knn_vals) {
+                val[t] = p.knn_vals[i * p.k + j];
+            } else {
+                const int64_t row = (id[t] < 0 ? id[t] + p.n_store : id[t]) - p.row0;
+                val[t] = p.vals_itemsize == 2 ? (int64_t) reinterpret_cast<const int16_t*>(p.vals)[row]
+                                              : (int64_t) reinterpret_cast<const int32_t*>(p.vals)[row];
+            }
+        }
+    }
+    const int64_t tgt = p.targets[i];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < JMAX; ++t) {
+        sv[t] = (id[t] == -1 ? -1e10f : sv[t]) / p.temperature;
+        if (lane + 64 * t < p.k) mx = fmaxf(mx, sv[t]);
+    }
+    mx = wave_max(mx);
+    float den = 0.f, num = 0.f;
+    int rec = 0;
+#pragma unroll
+    for (int t = 0; t < JMAX; ++t) {
+        if (lane + 64 * t < p.k) {
+            const float e = expf(sv[t] - mx);
+            const bool hit = val[t] == tgt;
+            den += e;
+            num += hit ? e : 0.f;
+            rec += hit;
+        }
+    }
+    den = wave_sum(den);
+    num = wave_sum(num);
+    rec = (int)wave_sum((float)rec);
+    if (lane == 0) {
+        const float pk = num / den;
+        if (p.out_pknn) p.out_pknn[i] = pk;
+        if (p.out_recall) p.out_recall[i] = rec;
+        const float a = p.lm_logp[i] + log_1ml;
+        const float b = logf(pk + 1e-10f) + log_l;
+        const float m = fmaxf(a, b);
+        p.out_logp[i] = m + logf(expf(a - m) + expf(b - m));
+    }
+}
+
 __global__ __launch_bounds__(256) void masked_sum_f64_kernel(const float* x, const uint8_t* mask, int64_t n, double* out) {
     __shared__ double red[256];
     double s = 0.0;
@@ -277,7 +344,10 @@ int knn_interp(const KnnInterpParams& p, hipStream_t stream) {
     // coefficients are float32 roundings of the float64 logs, as in coeffs[0] = np.log(1 - coeff)
     ProfScope prof(K_KNN, stream, 0.0, (double)p.n * p.k * (12.0 + (p.knn_vals ? 4.0 : p.vals_itemsize)) + 16.0 * p.n);
     const float log_1ml = (float)log(1.0 - p.lmbda), log_l = (float)log(p.lmbda);
-    hipLaunchKernelGGL(knn_interp_kernel, dim3((unsigned)cdiv(p.n, 4)), dim3(256), 0, stream, p, log_1ml, log_l);
+    const dim3 grid((unsigned)cdiv(p.n, 4)), block(256);
+    if (p.k <= 256) hipLaunchKernelGGL(knn_interp_regs_kernel<4>, grid, block, 0, stream, p, log_1ml, log_l);
+    else if (p.k <= 1024) hipLaunchKernelGGL(knn_interp_regs_kernel<16>, grid, block, 0, stream, p, log_1ml, log_l);
+    else hipLaunchKernelGGL(knn_interp_kernel, grid, block, 0, stream, p, log_1ml, log_l);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

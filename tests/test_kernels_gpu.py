@@ -328,9 +328,10 @@ def test_knn_interp_golden(ops, dev, golden, metric_type, t):
         np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-6)
 
 
-def test_knn_interp_full_size(ops, dev):
+@pytest.mark.parametrize("k", [1024, 200, 1500, 70])       # register-resident paths (k <= 256, <= 1024) and the generic loop
+def test_knn_interp_full_size(ops, dev, k):
     rs = np.random.RandomState(8)
-    n, k, N, V = 256, 1024, 200000, 267744
+    n, N, V = 256, 200000, 267744
     vals = rs.randint(0, V, size=N).astype(np.int32)
     ids = rs.randint(0, N, size=(n, k)).astype(np.int64)
     ids[::5, -3:] = -1
