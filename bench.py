@@ -156,6 +156,22 @@ def cpu_baseline(args, cpu_model):
                       f"{n_host}-row host table, torch-CPU fp32, {dt:.1f} s"}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, written by
+    tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same
+    command; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read
+    from inside the timed run, so this is the launch-weighted average over the kernel's instantiations of
+    the last profiled build, or None when no profile is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None
+    rows = [v for k, v in t.items() if k.startswith(kernel)]
+    n = sum(v["launches"] for v in rows)
+    return round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n) if n else None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -288,7 +304,7 @@ def main():
 
     if rank == 0:
         r = roof(dominant, prof)
-        r["traffic"] = None
+        r["traffic"] = pmc_traffic(dominant)
         r["launches_per_step"] = prof["launches"] / args.steps
         res = {
             "metric": "eval tokens/sec on WikiText-103 (k=1024, GNN+KNN); test ppl match",
