@@ -1,0 +1,191 @@
+// f32 "NT" GEMM on the f32 matrix cores with LDS-DMA staging (global_load_lds_dwordx4): the variant of
+// gemm_f32.hip's kernel taken for K % BK == 0 problems on 128x128 tiles.  Same contract, same epilogues
+// (gemm_epilogue.inc), same numerics (v_mfma_f32_32x32x2_f32 fmaf chains; the k order inside a stage is
+// permuted, which the MFMA sums over).
+//
+// What changes against the register-staged kernel: the operand tiles go global -> LDS directly (no staging
+// VGPRs, no ds_write pass, no second barrier per k-tile) and the LDS image is double-buffered with ONE barrier
+// per stage.
+//
+// Measured (tools/gemm_bench.py, TFLOP/s; GNNLM_DMA_EXP ablations built with tools/build_variant.sh):
+//   register-staged kernel      head 8192x20002x1024 124.7   4096^3 129.5   163840x1024x1024 127.7
+//   this kernel, BK = 16 (4 WG/CU)                   124.0          126.8                    127.1
+//   this kernel, BK = 32 (2 WG/CU, the default)      124.5          136.3                    123.4   (step: -1.7 %)
+//   BK = 16 without the DMA in the main loop         139.8          147.4      <- LDS reads + MFMA + barrier alone
+//   BK = 16, DMA re-reading one L1-resident stage    127.5          130.9      <- the cost is the load issue itself,
+//                                                                                 not the L2 / fabric latency
+//   register-only MFMA loop (tools/probes/mfma_peak.hip) 155.2 sustained.
+// I.e. getting 16 KiB per stage into LDS costs ~10 % of the matrix pipe whichever way it is staged; the next
+// lever is fewer load instructions per MFMA (256-wide tiles), not deeper prefetch.
+//
+// LDS image of a stage: [256 rows (A 128 + W 128)][BK floats], rows unpadded (a DMA instruction writes
+// wave-uniform base + lane x 16 B: 64 / (BK/4) consecutive rows).  Bank conflicts are avoided by swizzling on the
+// SOURCE side: slot s (16 B) of row r holds the global k-chunk s ^ f(r); a lane's per-lane global address makes
+// that free, and the fragment read applies the same involution.  f(r) = (r >> 2) & 3 for 64-B rows (BK = 16):
+// the 16 lanes of a ds_read_b128 group (16 consecutive rows, one chunk) then cover all 16 slots of a 256-B
+// bank window.
+#include "kernels.h"
+
+namespace gnnlm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+namespace {
+enum { EPI_STORE = 0, EPI_LSE = 1 };
+
+#ifndef GNNLM_DMA_EXP
+#define GNNLM_DMA_EXP 0      // ablations (timing only, wrong results): 1 no DMA after the prologue, 2 + no LDS reads, 3 + no barriers
+#endif
+template <int EPI, int BK>
+__global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_nt_f32_dma_kernel(const GemmParams p) {
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WROWS = 64, WCOLS = 64;
+    constexpr int CH = BK / 4;                     // 16-B chunks per row
+    constexpr int RPI = 64 / CH;                   // rows per DMA instruction
+    constexpr int NI = 256 / RPI / 4;              // DMA instructions per wave per stage
+    constexpr int STAGE = 256 * BK;                // floats
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
+
+    int M = p.M;
+    if (p.m_dev) M = min(M, *p.m_dev);
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = ((p.m_dev ? M : p.M) + BM - 1) / BM;
+    const unsigned n_tiles = (unsigned)(tiles_m * tiles_n);
+    const unsigned n_work = n_tiles * (unsigned)(p.batch1 * p.batch2);
+    const int nk = p.K / BK;
+
+    // DMA lane roles: instruction q of this wave stages rows (NI * wave + q) * RPI + lane / CH of the 256-row
+    // image, LDS slot lane % CH; the global chunk is slot ^ f(row)
+    const int d_slot = lane % CH, d_rsub = lane / CH;
+    // fragment reads: lane (l32, half) of k-step group s reads chunk c = 2 s + half of row l32 (+ 32 i)
+#define GNNLM_SWZ(row_) (BK == 16 ? (((row_) >> 2) & 3) : (((row_) >> 1) & 7))
+
+    for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x) {
+        const unsigned w_ = xcd_remap(v, n_work);
+        const unsigned by = w_ / n_tiles, t = w_ - by * n_tiles;
+        const int b1 = by / p.batch2, b2 = by % p.batch2;
+        int tm, tn;
+        if (p.tile_order == 1) { tm = t / tiles_n; tn = t % tiles_n; }
+        else if (p.tile_order == 2) { tn = t / tiles_m; tm = t % tiles_m; }
+        else {
+            const int GM = p.tile_order - 2;
+            const int band = t / (GM * tiles_n);
+            const int m_in = min(GM, tiles_m - band * GM);
+            const int r = t - band * GM * tiles_n;
+            tn = r / m_in;
+            tm = band * GM + r % m_in;
+        }
+        const int m0 = tm * BM, n0 = tn * BN;
+        const float* A = p.A + b1 * p.sA1 + b2 * p.sA2;
+        const float* W = p.W + b1 * p.sW1 + b2 * p.sW2;
+
+        const float* src[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int irow = (NI * wave + q) * RPI + d_rsub;          // 0..255 of the stage image
+            const int chunk = d_slot ^ GNNLM_SWZ(irow);
+            if (irow < BM) {
+                const int gr = m0 + irow;
+                int64_t ar = gr < M ? (p.a_rows ? (int64_t)p.a_rows[gr] : (int64_t)gr) : 0;
+                if (ar < 0) ar = 0;                                    // zero row, applied in the epilogue
+                src[q] = A + ar * p.lda + 4 * chunk;
+            } else {
+                const int gn = n0 + irow - BM;
+                src[q] = W + (int64_t)(gn < p.N ? gn : 0) * p.ldw + 4 * chunk;
+            }
+        }
+#define GNNLM_ISSUE(ks_, buf_)                                                               \
+    _Pragma("unroll") for (int q = 0; q < NI; ++q)                                           \
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src[q] + (ks_) * BK),                 \
+            (lds_void_t*)(lds + (buf_) * STAGE + (NI * wave + q) * RPI * BK), 16, 0, 0);
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        GNNLM_ISSUE(0, 0)
+        __syncthreads();
+        const int arow = wm * WROWS + l32, wrow = BM + wn * WCOLS + l32;
+        for (int ks = 0; ks < nk; ++ks) {
+            const float* sb = lds + (((GNNLM_DMA_EXP == 2 || GNNLM_DMA_EXP == 3) ? 0 : ks) & 1) * STAGE;
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) {
+                float4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = arow + 32 * i;
+                    a[i] = *reinterpret_cast<const float4*>(sb + r * BK + 4 * ((2 * s + half) ^ GNNLM_SWZ(r)));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int r = wrow + 32 * j;
+                    b[j] = *reinterpret_cast<const float4*>(sb + r * BK + 4 * ((2 * s + half) ^ GNNLM_SWZ(r)));
+                }
+                if (s == 0 && ks + 1 < nk && (GNNLM_DMA_EXP == 0 || GNNLM_DMA_EXP >= 4)) GNNLM_ISSUE((GNNLM_DMA_EXP == 4 ? 0 : GNNLM_DMA_EXP == 5 ? (ks & 7) : ks + 1), (ks + 1) & 1)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (EPI == EPI_LSE) {     // transposed accumulators (gemm_epilogue.inc)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].x, a[i].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].y, a[i].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].z, a[i].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].w, a[i].w, acc[i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                        }
+                    }
+            }
+            if (GNNLM_DMA_EXP != 3) __syncthreads();            // stage ks+1 landed (the barrier carries the DMA's vmcnt(0)); buffer ks&1 is free
+        }
+#undef GNNLM_ISSUE
+
+#include "gemm_epilogue.inc"
+        __syncthreads();
+    }
+#undef GNNLM_SWZ
+}
+}  // namespace
+
+#ifndef GNNLM_DMA_BK
+#define GNNLM_DMA_BK 32
+#endif
+
+bool gemm_dma_eligible(const GemmParams& p) {
+#ifdef GNNLM_NO_DMA_GEMM
+    return false;
+#endif
+    return p.precision == 0 && p.K % GNNLM_DMA_BK == 0 && p.K >= 4 * GNNLM_DMA_BK;
+}
+
+// p is normalised by gemm_nt; 128x128 tiles only (the caller checked the problem fills the chip)
+int gemm_nt_dma(const GemmParams& p, hipStream_t stream) {
+    constexpr int BK = GNNLM_DMA_BK;
+    const int64_t nb = (int64_t)p.batch1 * p.batch2;
+    const int64_t tiles = cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
+    GNNLM_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
+    const int64_t pool = 256 * (BK == 16 ? 4 : 2);
+    dim3 grid((unsigned)std::min<int64_t>(tiles, pool));
+    const double work = 2.0 * p.M * (double)p.N * p.K * nb;
+    ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N) * nb,
+                   p.m_dev, (double)p.M);
+    if (p.lse_part) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<EPI_LSE, BK>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<EPI_STORE, BK>), grid, dim3(256), 0, stream, p);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // namespace gnnlm

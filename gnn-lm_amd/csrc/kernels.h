@@ -16,6 +16,9 @@ int gemm_nt(const GemmParams& p, hipStream_t stream);
 // big-tile split-bf16 path (gemm_split.hip): taken by gemm_nt for precision != 0 when the problem fills the chip
 bool gemm_split_eligible(const GemmParams& p);
 int gemm_nt_split(const GemmParams& p, hipStream_t stream);
+// f32 MFMA kernel with LDS-DMA staging (gemm_f32_dma.hip): taken by gemm_nt for 128x128-tile problems with K % 16 == 0
+bool gemm_dma_eligible(const GemmParams& p);
+int gemm_nt_dma(const GemmParams& p, hipStream_t stream);
 // precision used by gemm_nt for descriptors that leave `precision` at 0 (set by the orchestrators)
 extern thread_local int g_default_gemm_precision;
 struct GemmPrecisionScope {
