@@ -27,10 +27,12 @@ PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
 
 
 def gemm_nt(A, W, bias=None, residual=None, alpha=1.0, out=None, bias_mode=1, gate=None,
-            a_rows=None, m_dev=None, precision=0):
-    """C = alpha * A @ W.T (+ gate*bias) (+ residual).  A [M,K] (row stride may exceed K), W [N,K]."""
+            a_rows=None, m_dev=None, precision=0, c_rows=None):
+    """C = alpha * A @ W.T (+ gate*bias) (+ residual).  A [M,K] (row stride may exceed K), W [N,K].
+    a_rows: logical row r reads A[a_rows[r]] (< 0: zero row); c_rows: row r is stored to (and its residual
+    read from) row c_rows[r] of ``out`` (which must then be given)."""
     _f32(A), _f32(W)
-    _dev(A, W, bias, residual, gate, a_rows, m_dev, out)
+    _dev(A, W, bias, residual, gate, a_rows, m_dev, out, c_rows)
     M, K = A.shape
     N = W.shape[0]
     if a_rows is not None:
@@ -43,6 +45,9 @@ def gemm_nt(A, W, bias=None, residual=None, alpha=1.0, out=None, bias_mode=1, ga
     g.C, g.ldc = out.data_ptr(), out.stride(0)
     if a_rows is not None:
         g.a_rows = a_rows.data_ptr()
+    if c_rows is not None:
+        assert c_rows.dtype == torch.int32 and c_rows.shape[0] == M
+        g.c_rows = c_rows.data_ptr()
     if bias is not None:
         g.bias, g.bias_mode = bias.data_ptr(), bias_mode
     if gate is not None:
@@ -58,7 +63,7 @@ def gemm_nt(A, W, bias=None, residual=None, alpha=1.0, out=None, bias_mode=1, ga
     return out
 
 
-def gemm_lse(A, W, pick=None, alpha=1.0, m_dev=None):
+def gemm_lse(A, W, pick=None, alpha=1.0, m_dev=None, precision=0):
     """lse[r] = logsumexp_n(alpha * A[r] . W[n]) and picked[r] = alpha * A[r] . W[pick[r]], without
     materialising the [M, N] logits (LSE epilogue of the GEMM + gnnlm_lse_reduce)."""
     _f32(A), _f32(W)
@@ -79,6 +84,7 @@ def gemm_lse(A, W, pick=None, alpha=1.0, m_dev=None):
         g.m_dev = m_dev.data_ptr()
     g.alpha = alpha
     g.M, g.N, g.K = M, N, K
+    g.precision = PRECISIONS.get(precision, precision)
     call_desc("gnnlm_gemm_nt", g)
     call("gnnlm_lse_reduce", ptr(part), n_parts, M, ptr(m_dev), ptr(lse), stream())
     return lse, picked

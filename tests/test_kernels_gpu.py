@@ -83,6 +83,85 @@ def test_gemm_options(ops, dev):
     assert (out.double() - big.cpu().double()[:, :64] @ W.cpu().double().t()).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("bf16x6", 2e-5), ("bf16x3", 3e-4)])
+@pytest.mark.parametrize("M,N,K", [(2100, 20002, 256),    # 256x256 plane tiles for the bf16 modes, LDS-DMA kernel for f32
+                                   (1000, 5000, 288)])    # 128x128 plane tiles
+def test_gemm_lse_large(ops, dev, precision, tol, M, N, K):
+    """LSE epilogue (transposed accumulators) of every large-problem kernel, ragged last n-tile, device-side M."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    pick = torch.randint(0, N, (M,), generator=g, dtype=torch.int32)
+    pick[:8] = torch.tensor([0, N - 1, N - 2, 63, 64, 127, 128, N - 65])
+    logits = 0.05 * (A.double() @ W.double().t())
+    m = M - 130
+    lse, picked = ops.gemm_lse(A.to(dev), W.to(dev), pick.to(dev), alpha=0.05, precision=precision,
+                               m_dev=torch.tensor([m], dtype=torch.int32, device=dev))
+    assert (lse.cpu().double()[:m] - torch.logsumexp(logits, 1)[:m]).abs().max() < tol
+    assert (picked.cpu().double()[:m] - logits.gather(1, pick.long()[:, None])[:m, 0]).abs().max() < tol
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 5e-7), ("bf16x6", 5e-7), ("bf16x3", 4e-5)])
+@pytest.mark.parametrize("M,N,K", [(2100, 2050, 96),     # 128x128 tiles, register-staged kernel (K < 128)
+                                   (2100, 2050, 160),    # 128x128 tiles, LDS-DMA kernel (f32) / in-kernel split
+                                   (2100, 2050, 288),    # + the pre-split plane kernel for the bf16 modes
+                                   (700, 300, 100)])     # 64x64 tiles
+def test_gemm_full_contract(ops, dev, precision, tol, M, N, K):
+    """Every epilogue option at once on each kernel variant: row gather with zero rows, scattered store +
+    residual through c_rows, gated per-column bias, alpha, device-side row count, untouched rows beyond it."""
+    g = torch.Generator().manual_seed(M + N + K)
+    n_src = M + 37
+    A = torch.randn(n_src, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    a_rows = torch.randint(0, n_src, (M,), generator=g, dtype=torch.int32)
+    a_rows[::11] = -1
+    c_rows = torch.randperm(M + 5, generator=g)[:M].to(torch.int32)
+    bias = torch.randn(N, generator=g)
+    gate = (torch.rand(M, generator=g) < 0.7).float() * 1.5
+    R = torch.randn(M + 5, N, generator=g)
+    m = M - 77
+    prod = A.double()[a_rows.clamp(min=0).long()] @ W.double().t()
+    prod[a_rows < 0] = 0
+    ref = torch.full((M + 5, N), 3.25, dtype=torch.float64)
+    val = 0.75 * prod + gate.double()[:, None] * bias.double()[None, :] + R.double()[c_rows.long()]
+    ref[c_rows[:m].long()] = val[:m]
+    scale = torch.ones(M + 5, N, dtype=torch.float64)
+    scale[c_rows.long()] = A.abs().double()[a_rows.clamp(min=0).long()] @ W.abs().double().t() + 1.0
+    out = torch.full((M + 5, N), 3.25, device=dev)
+    ops.gemm_nt(A.to(dev), W.to(dev), bias=bias.to(dev), gate=gate.to(dev), residual=R.to(dev), alpha=0.75, out=out,
+                a_rows=a_rows.to(dev), c_rows=c_rows.to(dev), m_dev=torch.tensor([m], dtype=torch.int32, device=dev),
+                precision=precision)
+    err = ((out.cpu().double() - ref).abs() / scale).max().item()
+    assert err < tol, (precision, err)
+    untouched = torch.ones(M + 5, dtype=torch.bool)
+    untouched[c_rows[:m].long()] = False
+    assert torch.all(out.cpu()[untouched] == 3.25)
+
+
+def test_gemm_batched_strides(ops, dev):
+    """batch1 x batch2 with independent strides for every operand (the causal scores / P.V / absorbed-query calls),
+    many tiles per batch so the flattened (batch, tile) walk of the resident pool is exercised."""
+    from gnnlm_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    b1, b2, M, N, K = 3, 2, 520, 390, 64
+    A = torch.randn(b1, b2, M, K + 4, generator=g).to(dev)
+    W = torch.randn(b2, b1, N, K, generator=g).to(dev)
+    C = torch.zeros(b1, M, b2, N + 4, device=dev)
+    bias = torch.randn(b1, b2, N, generator=g).to(dev)
+    d = _lib.gnnlm_gemm_t()
+    d.A, d.lda, d.W, d.ldw, d.C, d.ldc = A.data_ptr(), K + 4, W.data_ptr(), K, C.data_ptr(), b2 * (N + 4)
+    d.bias, d.bias_mode = bias.data_ptr(), 1
+    d.M, d.N, d.K, d.batch1, d.batch2 = M, N, K, b1, b2
+    d.sA1, d.sA2 = A.stride(0), A.stride(1)
+    d.sW1, d.sW2 = W.stride(1), W.stride(0)
+    d.sC1, d.sC2 = C.stride(0), C.stride(2)
+    d.sB1, d.sB2 = bias.stride(0), bias.stride(1)
+    _lib.call_desc("gnnlm_gemm_nt", d)
+    ref = torch.einsum("abmk,bank->ambn", A.cpu().double()[..., :K], W.cpu().double()) + bias.cpu().double()[:, None]
+    assert (C.cpu().double()[..., :N] - ref).abs().max() < 2e-4
+    assert torch.all(C[..., N:] == 0)
+
+
 @pytest.mark.parametrize("M,N,K", [(5, 7, 8), (300, 20002, 64), (129, 1000, 256), (64, 128, 32)])
 def test_gemm_lse_epilogue(ops, dev, M, N, K):
     g = torch.Generator().manual_seed(M + N)
