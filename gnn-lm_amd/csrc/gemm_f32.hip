@@ -14,19 +14,23 @@
 // 36-float row stride: every lane fetches its operands with ds_read_b128 (16-lane groups land on 16
 // distinct 16-B slots: 9*i mod 16 is a bijection).  The k index is permuted between the two 32-lane
 // halves (half h of a float4 read covers k = 8s+4h..+3); the MFMA sums over k, so A and W only have
-// to agree on the permutation.  Global->LDS staging goes through registers (the padded image is not
-// lane-linear, so LDS-DMA cannot write it) with the next tile's loads in flight under the current
-// tile's MFMAs; one barrier per k-tile, two LDS buffers.
+// to agree on the permutation.  Global->LDS staging goes through registers with the next k-tile's loads
+// in flight under the current tile's MFMAs; ONE LDS buffer and two barriers per k-tile at 3 waves per SIMD
+// measured faster than two buffers at 2 waves per SIMD.  (Problems with K % 32 == 0 on 128x128 tiles
+// take gemm_f32_dma.hip instead: same tile, LDS-DMA staging; this kernel keeps the ragged-K, short-K and
+// 64x64 cases and the in-kernel split-bf16 modes.)
 //
-// blockIdx -> tile mapping: every XCD (block b runs on XCD b % 8, speed only) gets a contiguous chunk
-// of the tile list, and the list is ordered so that consecutive tiles share the panel of the LARGER
-// operand (m-fastest when W is the big one, n-fastest when A is), which is then read from HBM once
-// and served from that XCD's L2.  With a device-side row count the real tiles are the m-prefix, so
-// m-fastest order also spreads them over all XCDs.
+// Work list: the grid is a pool of resident workgroups walking the list of (batch, tile) pairs; list
+// position -> pool slot through xcd_remap, so every XCD (block b runs on XCD b % 8, speed only) walks a
+// contiguous chunk of the list, ordered so that consecutive tiles share the panel of the LARGER operand
+// (m-fastest when W is the big one, n-fastest when A is), which then comes from that XCD's L2.  With a
+// device-side row count only the real tiles are on the list.  The first k-tile of a workgroup's next
+// tile is loaded under the epilogue of the current one.
 //
-// LSE epilogue (adaptive softmax): a wave reduces its 64 (or 32) rows over its columns to
-// (max, sum exp) pairs and writes them to part[row][2*tile_n + wn]; the logits matrix
-// (164 MB per 2048-token step for the WikiText-103 head) is never materialised.
+// LSE epilogue (adaptive softmax): the MFMA operands are swapped, so the accumulators hold the transposed
+// tile and a token's 64 logits of a wave's slab sit in registers of two lanes; (max, sum exp) per
+// (row, 64-column slab) goes to part[row][slab] -- the logits matrix (164 MB per 2048-token step for the
+// WikiText-103 head) is never materialised.  Details in gemm_epilogue.inc.
 #include "kernels.h"
 
 namespace gnnlm {

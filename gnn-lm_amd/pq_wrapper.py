@@ -97,28 +97,19 @@ class TorchPQCodec(torch.nn.Module):
         return ops.gemm_nt(x, At, bias=nba)
 
     def encode(self, x):
-        """x [n, d_in] -> codes uint8 [n, M]   (pq_wrapper.py:131-167).  Device tensors: OPQ rotation on the
-        f32 MFMA GEMM + the HIP argmin kernel (gnnlm_pq_encode); host tensors: the plain torch expression
-        (offline tool in the reference, not on the eval path)."""
-        if x.is_cuda:
-            from . import ops
-            x = x.to(torch.float32).contiguous()
-            if self.pre_torch:
-                x = ops.gemm_nt(x, self.A.contiguous(), bias=self.b if self.b.numel() > 0 else None)
-            M, ksub, dsub = self.centroids_torch.shape
-            codes = torch.empty(x.shape[0], M, dtype=torch.uint8, device=x.device)
-            _lib.call("gnnlm_pq_encode", _lib.ptr(x), x.stride(0), _lib.ptr(self.centroids_torch.contiguous()),
-                      _lib.ptr(self.norm2_centroids_torch.contiguous()), M, dsub, x.shape[0], _lib.ptr(codes), _lib.stream())
-            return codes
+        """x [n, d_in] (device) -> codes uint8 [n, M]   (pq_wrapper.py:131-167): OPQ rotation on the f32 MFMA
+        GEMM + the HIP argmin kernel (gnnlm_pq_encode).  Offline tool in the reference, a "next" row here."""
+        if not x.is_cuda:
+            raise _lib.GnnlmError("TorchPQCodec.encode runs on the GPU (MFMA GEMM + HIP argmin); no CPU fallback")
+        from . import ops
+        x = x.to(torch.float32).contiguous()
         if self.pre_torch:
-            x = x @ self.A.t()
-            if self.b.numel() > 0:
-                x = x + self.b
-        n = x.shape[0]
-        cen = self.centroids_torch
-        M, ksub, dsub = cen.shape
-        dot = torch.matmul(x.view(n, M, 1, dsub), cen.transpose(1, 2).unsqueeze(0)).squeeze(-2)
-        return (self.norm2_centroids_torch.unsqueeze(0) - 2 * dot).argmin(dim=2).to(torch.uint8)
+            x = ops.gemm_nt(x, self.A.contiguous(), bias=self.b if self.b.numel() > 0 else None)
+        M, ksub, dsub = self.centroids_torch.shape
+        codes = torch.empty(x.shape[0], M, dtype=torch.uint8, device=x.device)
+        _lib.call("gnnlm_pq_encode", _lib.ptr(x), x.stride(0), _lib.ptr(self.centroids_torch.contiguous()),
+                  _lib.ptr(self.norm2_centroids_torch.contiguous()), M, dsub, x.shape[0], _lib.ptr(codes), _lib.stream())
+        return codes
 
     def compute_sim(self, src, tgt):
         """sim[n, m] = sum_M sdc[M, src[n,M], tgt[m,M]]   (pq_wrapper.py:104-129).  Offline tool."""
