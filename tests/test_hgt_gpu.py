@@ -126,3 +126,31 @@ def test_hgt_wikitext103_shape_prefix(dev):
         err = np.abs(out["tgt"][:P] - ref).max()
         assert err < 1e-4, (L, err)
         assert np.isfinite(out["tgt"]).all()
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_step_is_graph_capturable(dev, precision):
+    """The whole step (gather -> HGT -> adaptive softmax -> kNN interpolation) is stream-ordered with device-side
+    row counts and no host round trip, so it can be captured in a HIP graph and replayed (bench.py --graph):
+    the replay must reproduce the eager results bit for bit, also after the inputs changed in place."""
+    from gnnlm_amd.synthetic import build_engine, make_problem, to_batch
+    prob = make_problem(n_store=3000, d=64, n_heads=4, M=16, dsub=4, vocab=600, cutoff=[100, 300], T=16, kg=8,
+                        left=2, right=2, n_layers=2, k=32, seed=3)
+    eng = build_engine(prob, dev)
+    eng.hgt.gemm_precision = eng.asm.gemm_precision = precision
+    batch = to_batch(prob["block"], dev)
+    eager = {k: v.clone() for k, v in eng.score(batch, 0.25, 1.0).items()}
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = eng.score(batch, 0.25, 1.0)
+    g.replay()
+    torch.cuda.synchronize()
+    for k in ("logp", "lm_logp", "gcn_feat"):
+        assert torch.equal(out[k], eager[k]), k
+    tgt0 = batch.targets.clone()
+    batch.targets.copy_(torch.roll(tgt0, 1))                       # same buffers, new contents
+    g.replay()
+    torch.cuda.synchronize()
+    ref = eng.score(batch, 0.25, 1.0)
+    assert torch.equal(out["logp"], ref["logp"]) and not torch.equal(out["logp"], eager["logp"])
