@@ -171,7 +171,8 @@ def pmc_traffic(kernel):
             t = json.load(f)
     except OSError:
         return None
-    rows = [v for k, v in t.items() if k.startswith(kernel)]
+    family = kernel[:-len("_kernel")] if kernel.endswith("_kernel") else kernel     # gemm_nt_f32_kernel + gemm_nt_f32_dma_kernel
+    rows = [v for k, v in t.items() if k.startswith(family)]
     n = sum(v["launches"] for v in rows)
     return round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n) if n else None
 

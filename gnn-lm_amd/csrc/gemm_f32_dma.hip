@@ -163,19 +163,20 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_nt_f32_dma_kernel(
 #ifndef GNNLM_DMA_BK
 #define GNNLM_DMA_BK 32
 #endif
-#ifndef GNNLM_DMA_MIN_TILES
-#define GNNLM_DMA_MIN_TILES 0
-#endif
 
 bool gemm_dma_eligible(const GemmParams& p) {
 #ifdef GNNLM_NO_DMA_GEMM
     return false;
 #endif
-    // GNNLM_DMA_MIN_TILES: A/B knob.  Isolated, the 512-tile projections are faster on the register-staged kernel
-    // (146 vs 160 us) and the 20002-column head here, but whole steps measured 5.79 / 5.79 / 5.83 ms for thresholds
-    // 0 / 4097 / 1024 -- within noise, so every eligible problem takes this kernel.
-    const int64_t tiles = cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch1 * p.batch2;
-    return p.precision == 0 && p.K % GNNLM_DMA_BK == 0 && p.K >= 4 * GNNLM_DMA_BK && tiles >= GNNLM_DMA_MIN_TILES;
+    // Where it pays, measured per launch inside the step (rocprofv3 trace, us; register-staged -> this kernel):
+    // LSE head 8192x20002x1024 2689 -> 2571, tail band 1 147 -> 147; store epilogue: projections 146 -> 145,
+    // absorbed queries (K = 128) 191 -> 209, 163840x1024x1024 of the 3-layer path 127.7 -> 123.4 TFLOP/s.  So the
+    // LSE problems take this kernel and the store-epilogue problems stay on the register-staged one
+    // (GNNLM_DMA_STORE=1 at build time sends them here too, for A/B runs).
+#ifndef GNNLM_DMA_STORE
+    if (!p.lse_part) return false;
+#endif
+    return p.precision == 0 && p.K % GNNLM_DMA_BK == 0 && p.K >= 4 * GNNLM_DMA_BK;
 }
 
 // p is normalised by gemm_nt; 128x128 tiles only (the caller checked the problem fills the chip)
