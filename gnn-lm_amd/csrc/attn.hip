@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
 // (16 rows x 4 consecutive dims) touches 64 different banks; pass 2 groups the neighbours 4 apart into one
 // k-step (rows 4 apart = 16 banks apart: 4 rows x 16 consecutive dims, again 64 different banks).
 // Measured at T = 8192, WikiText-103 shape: generic 1.57 ms; swept, VALU pass 2, depth-1 prefetch 1.42 ms;
-// + MFMA pass 2 1.36 ms; + depth-2 prefetch of gathers and U: see DESIGN.md.
+// + MFMA pass 2 1.36 ms; + depth-2 prefetch 1.39 ms (no gain: not latency-bound); + MFMA pass 1 1.17-1.19 ms.
+// A timing-only variant without the 17-KiB code staging (3 workgroups per CU instead of 2) ran 1.01 ms, but
+// feeding it needs the codes transposed per (token, chunk) by a pre-pass that moves 2 x 134 MB -- no net gain.
 #ifndef GNNLM_STAR_EXP
 #define GNNLM_STAR_EXP 0
 #endif
