@@ -48,10 +48,13 @@ void prof_start(int kid, hipStream_t s) {
     g_pending_start[kid] = take_event();
     (void)hipEventRecord(g_pending_start[kid], s);
 }
-void prof_stop(int kid, hipStream_t s, double flops, double bytes, const int32_t* scale_dev, double den) {
+int32_t* prof_take_slot() { return take_pinned(); }
+void prof_stop(int kid, hipStream_t s, double flops, double bytes, const int32_t* scale_dev, double den, int32_t* host_slot) {
     ProfRec r{kid, g_pending_start[kid], take_event(), flops, bytes, nullptr, den};
     (void)hipEventRecord(r.b, s);
-    if (scale_dev) {
+    if (host_slot) {
+        r.host_scale = host_slot;                       // written by the kernel itself
+    } else if (scale_dev) {
         r.host_scale = take_pinned();
         (void)hipMemcpyAsync(r.host_scale, scale_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     }

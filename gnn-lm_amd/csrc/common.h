@@ -36,14 +36,21 @@ extern unsigned g_prof_mask;
 void prof_start(int kid, hipStream_t s);
 // flops / bytes: algorithmic work of the launch; if scale_dev != null the work is multiplied by
 // (*scale_dev / scale_den) read back stream-ordered (device-side row counts)
-void prof_stop(int kid, hipStream_t s, double flops, double bytes, const int32_t* scale_dev, double scale_den);
+void prof_stop(int kid, hipStream_t s, double flops, double bytes, const int32_t* scale_dev, double scale_den,
+               int32_t* host_slot);
+int32_t* prof_take_slot();      // pinned, device-visible int32 for a kernel to store its device-side row count in
 struct ProfScope {
     int kid; hipStream_t s; double flops, bytes; const int32_t* sd; double den; bool on;
-    ProfScope(int kid_, hipStream_t s_, double flops_, double bytes_, const int32_t* sd_ = nullptr, double den_ = 1.0)
+    int32_t* slot = nullptr;    // kernels_write_count: the launch stores the count here itself (no D2H copy afterwards)
+    ProfScope(int kid_, hipStream_t s_, double flops_, double bytes_, const int32_t* sd_ = nullptr, double den_ = 1.0,
+              bool kernel_writes_count = false)
         : kid(kid_), s(s_), flops(flops_), bytes(bytes_), sd(sd_), den(den_), on((g_prof_mask >> kid_) & 1u) {
-        if (on) prof_start(kid, s);
+        if (on) {
+            if (sd && kernel_writes_count) slot = prof_take_slot();
+            prof_start(kid, s);
+        }
     }
-    ~ProfScope() { if (on) prof_stop(kid, s, flops, bytes, sd, den); }
+    ~ProfScope() { if (on) prof_stop(kid, s, flops, bytes, sd, den, slot); }
 };
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
 
     int M = p.M;
     if (p.m_dev) M = min(M, *p.m_dev);
+    if (p.m_out && blockIdx.x == 0 && threadIdx.x == 0) *p.m_out = M;
     const int tiles_n = (p.N + BN - 1) / BN;
     // Tile walk: the grid is a pool of resident workgroups (gemm_nt sizes it to the chip) walking the list of
     // REAL (batch, tile) pairs -- with a device-side row count a workgroup per worst-case tile would cost
@@ -306,23 +307,38 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_kernel(const GemmParams p)
 #undef GNNLM_STORE_TILE
 }
 
-// lse[row] = log sum exp over the row's partial (max, sum) pairs
+// lse[row] = log sum exp over the row's partial (max, sum) pairs.  WPR waves per row: one for short rows
+// (4 rows per workgroup), four for long ones (the 207,744-word tail band has 3,248 pairs per row and only
+// ~1000 live rows: a wave per row leaves most of the chip idle).
+template <int WPR>
 __global__ __launch_bounds__(256) void lse_reduce_kernel(const float2* part, int n_parts, int64_t rows,
                                                          const int32_t* m_dev, float* lse) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows || (m_dev && row >= *m_dev)) return;
+    __shared__ float2 red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = WPR == 1 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+    if (row >= rows || (m_dev && row >= *m_dev)) return;        // uniform per workgroup when WPR == 4
     const float2* pr = part + row * n_parts;
+    const int i0 = WPR == 1 ? lane : threadIdx.x, step = 64 * WPR;
     float m = -INFINITY;
-    for (int i = lane; i < n_parts; i += 64) m = fmaxf(m, pr[i].x);
+    for (int i = i0; i < n_parts; i += step) m = fmaxf(m, pr[i].x);
     m = wave_max(m);
+    if (WPR == 4) {
+        if (lane == 0) red[wave].x = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0].x, red[1].x), fmaxf(red[2].x, red[3].x));
+    }
     float s = 0.f;
-    for (int i = lane; i < n_parts; i += 64) {
+    for (int i = i0; i < n_parts; i += step) {
         const float2 v = pr[i];
         s += v.x == -INFINITY ? 0.f : v.y * expf(v.x - m);
     }
     s = wave_sum(s);
-    if (lane == 0) lse[row] = m + logf(s);
+    if (WPR == 4) {
+        if (lane == 0) red[wave].y = s;
+        __syncthreads();
+        s = (red[0].y + red[1].y) + (red[2].y + red[3].y);
+    }
+    if (threadIdx.x == (WPR == 1 ? 64 * wave : 0)) lse[row] = m + logf(s);
 }
 
 template <int BM, int BN, int NS>
@@ -377,7 +393,8 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     dim3 grid((unsigned)std::min<int64_t>(tiles, pool));
     const double work = 2.0 * p.M * (double)p.N * p.K * nb;
     ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N) * nb,
-                   p.m_dev, (double)p.M);
+                   p.m_dev, (double)p.M, true);
+    if (prof.slot) p.m_out = prof.slot;
     if (small) launch<64, 64>(p, grid, stream);
     else launch<128, 128>(p, grid, stream);
     GNNLM_LAUNCH_CHECK();
@@ -388,8 +405,12 @@ int lse_reduce(const float* part, int n_parts, int64_t rows, const int32_t* m_de
     GNNLM_REQUIRE(part && lse && n_parts > 0, "lse_reduce: bad arguments");
     if (rows == 0) return OK;
     ProfScope prof(K_LSE, stream, 0.0, 8.0 * rows * n_parts, m_dev, (double)rows);
-    hipLaunchKernelGGL(lse_reduce_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream,
-                       reinterpret_cast<const float2*>(part), n_parts, rows, m_dev, lse);
+    if (n_parts >= 1024)
+        hipLaunchKernelGGL(lse_reduce_kernel<4>, dim3((unsigned)rows), dim3(256), 0, stream,
+                           reinterpret_cast<const float2*>(part), n_parts, rows, m_dev, lse);
+    else
+        hipLaunchKernelGGL(lse_reduce_kernel<1>, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream,
+                           reinterpret_cast<const float2*>(part), n_parts, rows, m_dev, lse);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

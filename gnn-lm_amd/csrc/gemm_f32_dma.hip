@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_nt_f32_dma_kernel(
 
     int M = p.M;
     if (p.m_dev) M = min(M, *p.m_dev);
+    if (p.m_out && blockIdx.x == 0 && threadIdx.x == 0) *p.m_out = M;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = ((p.m_dev ? M : p.M) + BM - 1) / BM;
     const unsigned n_tiles = (unsigned)(tiles_m * tiles_n);
@@ -180,7 +181,8 @@ bool gemm_dma_eligible(const GemmParams& p) {
 }
 
 // p is normalised by gemm_nt; 128x128 tiles only (the caller checked the problem fills the chip)
-int gemm_nt_dma(const GemmParams& p, hipStream_t stream) {
+int gemm_nt_dma(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
     constexpr int BK = GNNLM_DMA_BK;
     const int64_t nb = (int64_t)p.batch1 * p.batch2;
     const int64_t tiles = cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
@@ -189,7 +191,8 @@ int gemm_nt_dma(const GemmParams& p, hipStream_t stream) {
     dim3 grid((unsigned)std::min<int64_t>(tiles, pool));
     const double work = 2.0 * p.M * (double)p.N * p.K * nb;
     ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N) * nb,
-                   p.m_dev, (double)p.M);
+                   p.m_dev, (double)p.M, true);
+    if (prof.slot) p.m_out = prof.slot;
     if (p.lse_part) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<EPI_LSE, BK>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<EPI_STORE, BK>), grid, dim3(256), 0, stream, p);
     GNNLM_LAUNCH_CHECK();

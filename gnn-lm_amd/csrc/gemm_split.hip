@@ -116,6 +116,7 @@ void gemm_planes_kernel(const GemmParams p, const uint4* __restrict__ Ap, const 
 
     int M = p.M;
     if (p.m_dev) M = min(M, *p.m_dev);
+    if (p.m_out && blockIdx.x == 0 && threadIdx.x == 0) *p.m_out = M;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = ((p.m_dev ? M : p.M) + BM - 1) / BM;
     const unsigned n_tiles = (unsigned)(tiles_m * tiles_n);
@@ -300,7 +301,8 @@ int gemm_nt_split(const GemmParams& p_in, hipStream_t stream) {
     GNNLM_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
     dim3 grid((unsigned)(p.m_dev ? std::min<int64_t>(tiles, 512) : tiles));
     const double work = 2.0 * p.M * (double)p.N * p.K;
-    ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), p.m_dev, (double)p.M);
+    ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), p.m_dev, (double)p.M, true);
+    if (prof.slot) p.m_out = prof.slot;
     if (big) { if (NS == 2) launch_planes<256, 2>(p, Ap, Wp, KS, grid, stream); else launch_planes<256, 3>(p, Ap, Wp, KS, grid, stream); }
     else     { if (NS == 2) launch_planes<128, 2>(p, Ap, Wp, KS, grid, stream); else launch_planes<128, 3>(p, Ap, Wp, KS, grid, stream); }
     GNNLM_LAUNCH_CHECK();

@@ -80,13 +80,14 @@ __global__ __launch_bounds__(256) void row_lse_pick_kernel(const float* logits, 
     }
 }
 
-// one workgroup: stable compaction of the rows whose target falls into each tail band.  Rows are taken
-// in chunks of 256; per band a ballot per wave + a 4-entry LDS prefix gives every row its slot.
-__global__ __launch_bounds__(256) void band_split_kernel(BandSplitParams p) {
-    __shared__ int wcnt[8][4];
+// one workgroup of 16 waves: stable compaction of the rows whose target falls into each tail band.  Rows are
+// taken in chunks of 1024; per band a ballot per wave + a 16-entry LDS prefix gives every row its slot.
+constexpr int BS_WAVES = 16;
+__global__ __launch_bounds__(64 * BS_WAVES) void band_split_kernel(BandSplitParams p) {
+    __shared__ int wcnt[8][BS_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int count[8] = {0};
-    for (int64_t base = 0; base < p.n; base += 256) {
+    for (int64_t base = 0; base < p.n; base += 64 * BS_WAVES) {
         const int64_t r = base + tid;
         const bool in = r < p.n;
         const int64_t t = in ? p.target[r] : 0;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void band_split_kernel(BandSplitParams p) {
             if (b >= p.n_bands) break;
             int before = 0, total = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < BS_WAVES; ++w) {
                 before += w < wave ? wcnt[b][w] : 0;
                 total += wcnt[b][w];
             }
@@ -258,13 +259,13 @@ __global__ __launch_bounds__(256) void knn_interp_regs_kernel(KnnInterpParams p,
     }
 }
 
-__global__ __launch_bounds__(256) void masked_sum_f64_kernel(const float* x, const uint8_t* mask, int64_t n, double* out) {
-    __shared__ double red[256];
+__global__ __launch_bounds__(1024) void masked_sum_f64_kernel(const float* x, const uint8_t* mask, int64_t n, double* out) {
+    __shared__ double red[1024];
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += (!mask || mask[i]) ? (double)x[i] : 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (!mask || mask[i]) ? (double)x[i] : 0.0;
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
@@ -314,7 +315,7 @@ int row_lse_pick(const float* logits, int64_t ld, int64_t rows, const int32_t* m
 int band_split(const BandSplitParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(p.target && p.head_pick && p.n_bands >= 1 && p.n_bands <= 8, "band_split: bad arguments");
     GNNLM_REQUIRE(p.n_bands == 1 || (p.band_rows && p.band_pick && p.band_count), "band_split: null band outputs");
-    hipLaunchKernelGGL(band_split_kernel, dim3(1), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(band_split_kernel, dim3(1), dim3(64 * BS_WAVES), 0, stream, p);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }
@@ -354,7 +355,7 @@ int knn_interp(const KnnInterpParams& p, hipStream_t stream) {
 
 int masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, hipStream_t stream) {
     GNNLM_REQUIRE(x && out, "masked_sum_f64: null");
-    hipLaunchKernelGGL(masked_sum_f64_kernel, dim3(1), dim3(256), 0, stream, x, mask, n, out);
+    hipLaunchKernelGGL(masked_sum_f64_kernel, dim3(1), dim3(1024), 0, stream, x, mask, n, out);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

@@ -61,6 +61,7 @@ typedef struct gnnlm_gemm {
     float alpha;               /* 0 is read as 1 */
     int32_t M, N, K;           /* K % 4 == 0 */
     const int32_t* m_dev;      /* optional device-side row count (<= M): tiles beyond it exit */
+    int32_t* m_out;            /* optional: receives min(M, *m_dev) (device or host-mapped memory; used by the profiler) */
     int32_t batch1, batch2;    /* 0 is read as 1; batch index (b1, b2) */
     int64_t sA1, sA2, sW1, sW2, sC1, sC2, sB1, sB2, sR1, sR2;   /* batch strides in elements */
     int32_t precision;         /* 0: f32 MFMA (exact fmaf chain; or the enclosing orchestrator's setting);
