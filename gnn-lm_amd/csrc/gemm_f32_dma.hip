@@ -38,18 +38,21 @@ enum { EPI_STORE = 0, EPI_LSE = 1 };
 #ifndef GNNLM_DMA_EXP
 #define GNNLM_DMA_EXP 0      // ablations (timing only, wrong results): 1 no DMA after the prologue, 2 + no LDS reads, 3 + no barriers
 #endif
-template <int EPI, int BK>
-__global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_nt_f32_dma_kernel(const GemmParams p) {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WROWS = 64, WCOLS = 64;
+// BT = 128: 128x128 tile, 4 waves (2x2) of 64x64.  BT = 256: 256x256 tile, 8 waves (2x4) of 128x64 -- half the
+// load instructions and 3/4 of the LDS reads per MFMA, one workgroup (2 waves per SIMD) per CU, 128 KiB of LDS.
+template <int EPI, int BK, int BT>
+__global__ __launch_bounds__(BT == 256 ? 512 : 256, BT == 256 ? 1 : (BK == 16 ? 4 : 2)) void gemm_nt_f32_dma_kernel(const GemmParams p) {
+    constexpr int BM = BT, BN = BT, WAVES_N = BT / 64, NWAVES = 2 * WAVES_N;
+    constexpr int WROWS = BM / 2, WCOLS = 64, TM = WROWS / 32, TN = 2;
     constexpr int CH = BK / 4;                     // 16-B chunks per row
     constexpr int RPI = 64 / CH;                   // rows per DMA instruction
-    constexpr int NI = 256 / RPI / 4;              // DMA instructions per wave per stage
-    constexpr int STAGE = 256 * BK;                // floats
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    constexpr int NI = 2 * BT / RPI / NWAVES;      // DMA instructions per wave per stage
+    constexpr int STAGE = 2 * BT * BK;             // floats
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][2 BT rows][BK]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int half = lane >> 5, l32 = lane & 31;
 
     int M = p.M;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_nt_f32_dma_kernel(
         const float* src[NI];
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
-            const int irow = (NI * wave + q) * RPI + d_rsub;          // 0..255 of the stage image
+            const int irow = (NI * wave + q) * RPI + d_rsub;          // row of the 2 BT-row stage image
             const int chunk = d_slot ^ GNNLM_SWZ(irow);
             if (irow < BM) {
                 const int gr = m0 + irow;
@@ -180,21 +183,42 @@ bool gemm_dma_eligible(const GemmParams& p) {
     return p.precision == 0 && p.K % GNNLM_DMA_BK == 0 && p.K >= 4 * GNNLM_DMA_BK;
 }
 
-// p is normalised by gemm_nt; 128x128 tiles only (the caller checked the problem fills the chip)
+// p is normalised by gemm_nt (the caller checked the problem fills the chip with 128x128 tiles)
+template <int EPI, int BK, int BT>
+int launch_dma(const GemmParams& p, dim3 grid, hipStream_t stream) {
+    constexpr size_t lds_bytes = 2 * (size_t)(2 * BT * BK) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {      // > 64 KiB of dynamic LDS has to be allowed once per kernel
+        GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_dma_kernel<EPI, BK, BT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<EPI, BK, BT>), grid, dim3(BT == 256 ? 512 : 256), lds_bytes, stream, p);
+    return OK;
+}
+
+#ifndef GNNLM_DMA_BIG_TILES
+#define GNNLM_DMA_BIG_TILES 2048     // 256x256 tiles from this many of them on (8 per CU); 1 << 30 disables
+#endif
+
 int gemm_nt_dma(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     constexpr int BK = GNNLM_DMA_BK;
     const int64_t nb = (int64_t)p.batch1 * p.batch2;
-    const int64_t tiles = cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
+    const bool big = !p.m_dev && cdiv(p.M, 256) * cdiv(p.N, 256) * nb >= GNNLM_DMA_BIG_TILES;
+    const int BT = big ? 256 : 128;
+    const int64_t tiles = cdiv(p.M, BT) * cdiv(p.N, BT) * nb;
     GNNLM_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
-    const int64_t pool = 256 * (BK == 16 ? 4 : 2);
+    const int64_t pool = 256 * (big ? 1 : (BK == 16 ? 4 : 2));
     dim3 grid((unsigned)std::min<int64_t>(tiles, pool));
     const double work = 2.0 * p.M * (double)p.N * p.K * nb;
     ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N) * nb,
                    p.m_dev, (double)p.M, true);
     if (prof.slot) p.m_out = prof.slot;
-    if (p.lse_part) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<EPI_LSE, BK>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<EPI_STORE, BK>), grid, dim3(256), 0, stream, p);
+    int rc;
+    if (big) rc = p.lse_part ? launch_dma<EPI_LSE, BK, 256>(p, grid, stream) : launch_dma<EPI_STORE, BK, 256>(p, grid, stream);
+    else rc = p.lse_part ? launch_dma<EPI_LSE, BK, 128>(p, grid, stream) : launch_dma<EPI_STORE, BK, 128>(p, grid, stream);
+    if (rc != OK) return rc;
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

@@ -101,6 +101,24 @@ def test_gemm_lse_large(ops, dev, precision, tol, M, N, K):
     assert (picked.cpu().double()[:m] - logits.gather(1, pick.long()[:, None])[:m, 0]).abs().max() < tol
 
 
+def test_gemm_lse_head_sized(ops, dev):
+    """The softmax-head regime (>= 2048 tiles of 256x256: LDS-DMA kernel with 256x256 tiles, 8 waves) against a
+    float64 log-sum-exp evaluated in row blocks; ragged last tiles in both directions."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 4000, 33000, 128
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    pick = torch.randint(0, N, (M,), generator=g, dtype=torch.int32)
+    pick[:4] = torch.tensor([0, N - 1, 255, 256])
+    lse, picked = ops.gemm_lse(A.to(dev), W.to(dev), pick.to(dev), alpha=0.07)
+    lse, picked = lse.cpu().double(), picked.cpu().double()
+    Wd = W.double().t().contiguous()
+    for r0 in range(0, M, 500):
+        logits = 0.07 * (A[r0:r0 + 500].double() @ Wd)
+        assert (lse[r0:r0 + 500] - torch.logsumexp(logits, 1)).abs().max() < 2e-5
+        assert (picked[r0:r0 + 500] - logits.gather(1, pick[r0:r0 + 500].long()[:, None])[:, 0]).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize("precision,tol", [("f32", 5e-7), ("bf16x6", 5e-7), ("bf16x3", 4e-5)])
 @pytest.mark.parametrize("M,N,K", [(2100, 2050, 96),     # 128x128 tiles, register-staged kernel (K < 128)
                                    (2100, 2050, 160),    # 128x128 tiles, LDS-DMA kernel (f32) / in-kernel split
