@@ -31,7 +31,7 @@ import torch
 
 PEAK = {"mfma_f32_tflops": 157.3, "mfma_bf16_tflops": 2500.0, "hbm_gbs": 8000.0}   # MI355X_MICROARCH.md chip table
 SPLIT_PRODUCTS = {"f32": 1, "bf16x3": 3, "bf16x6": 6}            # bf16 MFMA products issued per f32 multiply-add
-KERNEL_BOUND = {"gemm_nt_f32_kernel": "mfma"}                    # everything else on this path: hbm
+KERNEL_BOUND = {"gemm_nt_f32_kernel": "mfma", "causal_attn_kernel": "mfma"}     # everything else on this path: hbm
 
 
 def parse():

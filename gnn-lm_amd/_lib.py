@@ -98,6 +98,7 @@ def lib():
         L.gnnlm_store_vals.restype = ctypes.c_void_p
         vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
         L.gnnlm_causal_softmax.argtypes = [vp, i64, i32, i64, i32, vp]
+        L.gnnlm_causal_attn.argtypes = [vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]
         L.gnnlm_layernorm.argtypes = [vp, i64, vp, vp, vp, i64, i64, i32, f32, vp, vp]
         L.gnnlm_half_to_float.argtypes = [vp, vp, i64, vp]
         L.gnnlm_row_lse_pick.argtypes = [vp, i64, i64, vp, i32, vp, vp, vp, vp]

@@ -189,8 +189,8 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         valid = b.valid;
         if (io.out_valid) GNNLM_HIP(hipMemcpyAsync(io.out_valid, b.valid, (size_t)S, hipMemcpyDeviceToDevice, s));
     }
-    // V^T buffer: its padding columns (t >= T) are read by the P.V GEMM against zero probabilities
-    GNNLM_HIP(hipMemsetAsync(b.vt, 0, sizeof(float) * (size_t)nb * d * Tp, s));
+    // V^T buffer of the GEMM path: its padding columns (t >= T) are read by the P.V GEMM against zero probabilities
+    if (!causal_attn_fused_ok(T, dk)) GNNLM_HIP(hipMemsetAsync(b.vt, 0, sizeof(float) * (size_t)nb * d * Tp, s));
 
     const float* ht_in = io.tgt_feats;
     for (int l = 0; l < m.n_layers; ++l) {
@@ -204,31 +204,37 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         // ---- tgt projections (hgt.py:315-322 with the 'intra' relation folded into K and V)
         TRY(linear(ht_in, d, w.wq_t, w.bq_t, b.q, Tt, d, d, nullptr, 1.f, s));
         TRY(linear(ht_in, d, w.wk_t, w.bk_t, b.k, Tt, d, d, nullptr, 1.f, s));
-        {   // V'^T[blk][n][t] = sum_k Wv'[n,k] h[blk*T + t, k] + bv'[n]
-            GemmParams g{};
-            g.A = w.wv_t; g.lda = d; g.W = ht_in; g.ldw = d; g.C = b.vt; g.ldc = Tp;
-            g.bias = w.bv_t; g.bias_mode = 2;
-            g.M = d; g.N = T; g.K = d; g.batch1 = nb;
-            g.sW1 = (int64_t)T * d; g.sC1 = (int64_t)d * Tp;
-            TRY(gemm_nt(g, s));
-        }
-        {   // causal scores S[blk,h] = Q_h K'_h^T   (scale folded into K')
-            GemmParams g{};
-            g.A = b.q; g.lda = d; g.W = b.k; g.ldw = d; g.C = b.scores; g.ldc = Tp;
-            g.M = T; g.N = T; g.K = dk; g.batch1 = nb; g.batch2 = H;
-            g.sA1 = (int64_t)T * d; g.sA2 = dk; g.sW1 = (int64_t)T * d; g.sW2 = dk;
-            g.sC1 = (int64_t)H * T * Tp; g.sC2 = (int64_t)T * Tp;
-            TRY(gemm_nt(g, s));
-        }
-        TRY(causal_softmax(b.scores, (int64_t)nb * H, T, Tp, m.max_intra_context, s));
-        {   // m_causal[blk, :, h] = P[blk,h] V'_h
-            GemmParams g{};
-            g.A = b.scores; g.lda = Tp; g.W = b.vt; g.ldw = Tp; g.C = b.mc; g.ldc = d;
-            g.M = T; g.N = dk; g.K = (int)Tp; g.batch1 = nb; g.batch2 = H;
-            g.sA1 = (int64_t)H * T * Tp; g.sA2 = (int64_t)T * Tp;
-            g.sW1 = (int64_t)d * Tp; g.sW2 = (int64_t)dk * Tp;
-            g.sC1 = (int64_t)T * d; g.sC2 = dk;
-            TRY(gemm_nt(g, s));
+        if (causal_attn_fused_ok(T, dk)) {
+            // recipe shape: V' row-major, then scores + masked softmax + P.V in one kernel (attn.hip)
+            TRY(linear(ht_in, d, w.wv_t, w.bv_t, b.vt, Tt, d, d, nullptr, 1.f, s));
+            TRY(causal_attn_fused(b.q, b.k, b.vt, d, b.mc, d, nb, T, H, dk, m.max_intra_context, s));
+        } else {
+            {   // V'^T[blk][n][t] = sum_k Wv'[n,k] h[blk*T + t, k] + bv'[n]
+                GemmParams g{};
+                g.A = w.wv_t; g.lda = d; g.W = ht_in; g.ldw = d; g.C = b.vt; g.ldc = Tp;
+                g.bias = w.bv_t; g.bias_mode = 2;
+                g.M = d; g.N = T; g.K = d; g.batch1 = nb;
+                g.sW1 = (int64_t)T * d; g.sC1 = (int64_t)d * Tp;
+                TRY(gemm_nt(g, s));
+            }
+            {   // causal scores S[blk,h] = Q_h K'_h^T   (scale folded into K')
+                GemmParams g{};
+                g.A = b.q; g.lda = d; g.W = b.k; g.ldw = d; g.C = b.scores; g.ldc = Tp;
+                g.M = T; g.N = T; g.K = dk; g.batch1 = nb; g.batch2 = H;
+                g.sA1 = (int64_t)T * d; g.sA2 = dk; g.sW1 = (int64_t)T * d; g.sW2 = dk;
+                g.sC1 = (int64_t)H * T * Tp; g.sC2 = (int64_t)T * Tp;
+                TRY(gemm_nt(g, s));
+            }
+            TRY(causal_softmax(b.scores, (int64_t)nb * H, T, Tp, m.max_intra_context, s));
+            {   // m_causal[blk, :, h] = P[blk,h] V'_h
+                GemmParams g{};
+                g.A = b.scores; g.lda = Tp; g.W = b.vt; g.ldw = Tp; g.C = b.mc; g.ldc = d;
+                g.M = T; g.N = dk; g.K = (int)Tp; g.batch1 = nb; g.batch2 = H;
+                g.sA1 = (int64_t)H * T * Tp; g.sA2 = (int64_t)T * Tp;
+                g.sW1 = (int64_t)d * Tp; g.sW2 = (int64_t)dk * Tp;
+                g.sC1 = (int64_t)T * d; g.sC2 = dk;
+                TRY(gemm_nt(g, s));
+            }
         }
         {   // absorbed star queries U[i,h,:] = Wku_h q[i,h,:]
             GemmParams g{};
@@ -414,6 +420,10 @@ int gnnlm_chain_attn(const gnnlm_chain_attn_t* d, void* stream) { GNNLM_DESC(d);
 int gnnlm_causal_softmax(float* S, int64_t n_mats, int32_t T, int64_t ld, int32_t max_ctx, void* stream) {
     return causal_softmax(S, n_mats, T, ld, max_ctx, (hipStream_t)stream);
 }
+int gnnlm_causal_attn(const float* Q, const float* K, const float* V, int64_t ld, float* out, int64_t ldo,
+                      int32_t n_blocks, int32_t T, int32_t H, int32_t dk, int32_t max_ctx, void* stream) {
+    return causal_attn_fused(Q, K, V, ld, out, ldo, n_blocks, T, H, dk, max_ctx, (hipStream_t)stream);
+}
 int gnnlm_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo,
                     int64_t rows, int32_t d, float eps, const uint8_t* valid, void* stream) {
     return layernorm(x, ldx, gamma, beta, out, ldo, rows, d, eps, valid, (hipStream_t)stream);
@@ -457,7 +467,7 @@ int gnnlm_hgt_forward(const gnnlm_hgt_t* m, const gnnlm_hgt_io_t* io, void* work
 }
 
 static const char* kKernelNames[K_COUNT] = {"gemm_nt_f32_kernel", "gather_decode_kernel", "star_attn_kernel",
-                                            "chain_attn_kernel", "causal_softmax_kernel", "layernorm_kernel",
+                                            "chain_attn_kernel", "causal_attn_kernel", "layernorm_kernel",
                                             "row_lse_pick_kernel", "knn_interp_kernel", "misc", "split_planes_kernel"};
 const char* gnnlm_kernel_name(int32_t kernel_id) {
     return kernel_id >= 0 && kernel_id < K_COUNT ? kKernelNames[kernel_id] : nullptr;

@@ -556,6 +556,164 @@ __global__ __launch_bounds__(256) void causal_softmax_kernel(float* S, int64_t n
     for (int u = lane; u < (int)ld; u += 64) r[u] = (u >= lo && u <= w) ? expf(r[u] - mx) * inv : 0.f;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Fused causal ('tgt','intra','tgt') attention for the recipe shape T = 256, d_k = 128: one workgroup of 8
+// waves per (block, head); scores, masked softmax and P.V without the [T, T] score matrix ever leaving the
+// registers (the GEMM + softmax + GEMM formulation writes and re-reads 67 MB of scores per 8192 tokens).
+//
+// Wave w owns 32 queries.  Pass 1 computes S^T = K' Q^T with v_mfma_f32_32x32x2_f32 -- accumulator rows are
+// KEYS, columns (lane & 31) are queries -- so a query's 256 scores are registers of two lanes and the masked
+// softmax is in-lane plus one v_permlane32_swap.  In that layout accumulator register r of key tile t in lane
+// (query, half) is exactly the A operand of the 32x32x2 MFMA whose k pair is (key(t,r,0), key(t,r,1)): pass 2
+// feeds the probabilities to P.V straight from the accumulators, B = two rows of V from LDS.  K' and V stream
+// through LDS in blocks of 64 keys (double-buffered); key tiles above the diagonal are skipped, and the
+// query tiles are dealt to the waves so that the two waves of a SIMD carry equal work (tiles w and 7 - w).
+// The score scale and the relation prior are folded into K' by prepare_hgt_weights, as in the GEMM path.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct CausalAttnParams {
+    const float* Q; const float* K; const float* V; float* out;    // [n_blocks * T, ld] rows; head h at column h * dk
+    int64_t ld, ldo;
+    int n_blocks, H, max_ctx;
+};
+
+__global__ __launch_bounds__(512, 1) void causal_attn_256x128_kernel(CausalAttnParams p) {
+    constexpr int T = 256, DK = 128, KB = 64;
+    constexpr int KS = DK + 4;                    // K' block row stride: conflict-free ds_read_b128 of 16 rows
+    constexpr int VS = DK + 8;                    // V block row stride: rows 4 apart are 32 banks apart
+    constexpr int BUF = KB * VS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];    // [2][KB][VS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int blk = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int qt = wave < 4 ? wave : 11 - wave;   // waves w and w + 4 share a SIMD: tiles (0,7) (1,6) (2,5) (3,4)
+    const int q0 = 32 * qt, query = q0 + l32;
+    const int64_t row0 = (int64_t)blk * T;
+    const float* Qb = p.Q + row0 * p.ld + h * DK;
+    const float* Kb = p.K + row0 * p.ld + h * DK;
+    const float* Vb = p.V + row0 * p.ld + h * DK;
+
+    // B operand of pass 1: Q[query][8 s + 4 half + e], e = 0..3, s = 0..15 (the k permutation of the staged K')
+    float4 qreg[16];
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_)
+        qreg[s_] = *reinterpret_cast<const float4*>(Qb + (int64_t)query * p.ld + 8 * s_ + 4 * half);
+
+    f32x16 sc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+
+    // staging: 512 threads x 4 float4 = one 64 x 128 block
+    const int srow = tid >> 5, scol = (tid & 31) * 4;           // rows srow + 16 u, u = 0..3
+    float4 stg[4];
+#define GNNLM_CA_LOAD(src, kb)                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                       \
+        stg[u] = *reinterpret_cast<const float4*>((src) + (int64_t)((kb) * KB + srow + 16 * u) * p.ld + scol);
+#define GNNLM_CA_STORE(buf, stride)                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                       \
+        *reinterpret_cast<float4*>(smem + (buf) * BUF + (srow + 16 * u) * (stride) + scol) = stg[u];
+
+    // ---------------- pass 1: S^T tiles (keys x queries)
+    GNNLM_CA_LOAD(Kb, 0)
+    GNNLM_CA_STORE(0, KS)
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < T / KB; ++kb) {
+        if (kb + 1 < T / KB) GNNLM_CA_LOAD(Kb, kb + 1)
+        const float* kl = smem + (kb & 1) * BUF;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * kb + tt;
+            if (t <= qt) {
+                const float* kr = kl + (32 * tt + l32) * KS + 4 * half;
+#pragma unroll
+                for (int s_ = 0; s_ < 16; ++s_) {
+                    const float4 a = *reinterpret_cast<const float4*>(kr + 8 * s_);
+                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[s_].x, sc[t], 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[s_].y, sc[t], 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[s_].z, sc[t], 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[s_].w, sc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (kb + 1 < T / KB) GNNLM_CA_STORE((kb + 1) & 1, KS)
+        __syncthreads();
+    }
+    // ---------------- masked softmax over the keys of each query (edge_softmax by destination, hgt.py:356)
+    GNNLM_CA_LOAD(Vb, 0)                              // V block 0 flies under the softmax
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool ok = t <= qt && key <= query && (p.max_ctx <= 0 || query - key < p.max_ctx);
+            sc[t][r] = ok ? sc[t][r] : -INFINITY;
+            mx = fmaxf(mx, sc[t][r]);
+        }
+    {
+        const gnnlm_u32x2 x = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(x.x), __uint_as_float(x.y));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = sc[t][r] == -INFINITY ? 0.f : expf(sc[t][r] - mx);
+            sc[t][r] = e;
+            sum += e;
+        }
+    {
+        const gnnlm_u32x2 x = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+        sum = __uint_as_float(x.x) + __uint_as_float(x.y);
+    }
+    const float inv = 1.f / sum;                      // the diagonal key is always valid: sum >= 1
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[t][r] *= inv;
+
+    // ---------------- pass 2: out[query][:] = sum_key P[query][key] V[key][:]
+    f32x16 oc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oc[c][r] = 0.f;
+    GNNLM_CA_STORE(0, VS)
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < T / KB; ++kb) {
+        if (kb + 1 < T / KB) GNNLM_CA_LOAD(Vb, kb + 1)
+        const float* vl = smem + (kb & 1) * BUF + l32;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * kb + tt;
+            if (t <= qt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* vr = vl + (32 * tt + (r & 3) + 8 * (r >> 2) + 4 * half) * VS;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        oc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[t][r], vr[32 * c], oc[c], 0, 0, 0);
+                }
+            }
+        }
+        if (kb + 1 < T / KB) GNNLM_CA_STORE((kb + 1) & 1, VS)
+        __syncthreads();
+    }
+#undef GNNLM_CA_LOAD
+#undef GNNLM_CA_STORE
+    float* ob = p.out + (row0 + q0) * p.ldo + h * DK + l32;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ob[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.ldo + 32 * c] = oc[c][r];
+}
+
 }  // namespace
 
 int star_attn(const StarAttnParams& p, hipStream_t stream) {
@@ -623,6 +781,31 @@ int causal_softmax(float* S, int64_t n_mats, int T, int64_t ld, int max_ctx, hip
     if (rows == 0) return OK;
     ProfScope prof(K_CAUSAL, stream, 0.0, 8.0 * rows * ld);
     hipLaunchKernelGGL(causal_softmax_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, S, rows, T, ld, max_ctx);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+bool causal_attn_fused_ok(int T, int dk) { return T == 256 && dk == 128; }
+
+int causal_attn_fused(const float* Q, const float* K, const float* V, int64_t ld, float* out, int64_t ldo,
+                      int n_blocks, int T, int H, int dk, int max_ctx, hipStream_t stream) {
+    GNNLM_REQUIRE(Q && K && V && out, "causal_attn: null operand");
+    GNNLM_REQUIRE(causal_attn_fused_ok(T, dk), "causal_attn: the fused kernel is built for T = 256, d_k = 128");
+    GNNLM_REQUIRE(ld % 4 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0),
+                  "causal_attn: operands must be 16-byte aligned with ld % 4 == 0");
+    if (n_blocks == 0) return OK;
+    constexpr size_t lds_bytes = 2 * 64 * (128 + 8) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&causal_attn_256x128_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    CausalAttnParams p{Q, K, V, out, ld, ldo, n_blocks, H, max_ctx};
+    const double pairs = (double)n_blocks * H;
+    // algorithmic: the causal half of 2 * (T * T * dk) * 2 flops per (block, head)
+    ProfScope prof(K_CAUSAL, stream, pairs * 2.0 * T * (T + 1) * dk, pairs * 4.0 * T * dk * 4.0);
+    hipLaunchKernelGGL(causal_attn_256x128_kernel, dim3((unsigned)(n_blocks * H)), dim3(512), lds_bytes, stream, p);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

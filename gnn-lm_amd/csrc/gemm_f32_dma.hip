@@ -167,6 +167,9 @@ __global__ __launch_bounds__(BT == 256 ? 512 : 256, BT == 256 ? 1 : (BK == 16 ? 
 #ifndef GNNLM_DMA_BK
 #define GNNLM_DMA_BK 32
 #endif
+#ifndef GNNLM_DMA_MIN_K
+#define GNNLM_DMA_MIN_K 128
+#endif
 
 bool gemm_dma_eligible(const GemmParams& p) {
 #ifdef GNNLM_NO_DMA_GEMM
@@ -180,7 +183,7 @@ bool gemm_dma_eligible(const GemmParams& p) {
 #ifndef GNNLM_DMA_STORE
     if (!p.lse_part) return false;
 #endif
-    return p.precision == 0 && p.K % GNNLM_DMA_BK == 0 && p.K >= 4 * GNNLM_DMA_BK;
+    return p.precision == 0 && p.K % GNNLM_DMA_BK == 0 && p.K >= GNNLM_DMA_MIN_K;
 }
 
 // p is normalised by gemm_nt (the caller checked the problem fills the chip with 128x128 tiles)

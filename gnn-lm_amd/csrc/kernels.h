@@ -37,6 +37,11 @@ int chain_attn(const ChainAttnParams& p, hipStream_t stream);
 
 // rows of S[b, h, w, :T] -> causal softmax (u <= w, and w-u < max_ctx if max_ctx > 0), in place
 int causal_softmax(float* S, int64_t n_mats, int T, int64_t ld, int max_ctx, hipStream_t stream);
+// fused scores + masked softmax + P.V for T = 256, d_k = 128 (attn.hip); Q, K', V are [n_blocks * T, ld] with head h at
+// column h * dk
+bool causal_attn_fused_ok(int T, int dk);
+int causal_attn_fused(const float* Q, const float* K, const float* V, int64_t ld, float* out, int64_t ldo,
+                      int n_blocks, int T, int H, int dk, int max_ctx, hipStream_t stream);
 
 // out[r,:] = LayerNorm(x[r,:]) * gamma + beta ; optional row validity (invalid rows -> 0)
 int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,

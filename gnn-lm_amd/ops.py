@@ -182,6 +182,17 @@ def chain_attn(Q, K, V, valid, left, right, H, scale=None):
     return out
 
 
+def causal_attn(Q, K, V, n_blocks, T, H, max_ctx=0):
+    """Fused causal attention (T = 256, d_k = 128): Q, K', V' [n_blocks*T, H*dk] -> [n_blocks*T, H*dk]."""
+    _f32(Q), _f32(K), _f32(V)
+    _dev(Q, K, V)
+    d = Q.shape[1]
+    out = torch.empty_like(Q)
+    call("gnnlm_causal_attn", ptr(Q), ptr(K), ptr(V), Q.stride(0), ptr(out), out.stride(0), n_blocks, T, H, d // H,
+         max_ctx, stream())
+    return out
+
+
 def causal_softmax_(S, T, max_ctx=0):
     """In place over S [n_mats, T, ld]."""
     n_mats, T_, ld = S.shape

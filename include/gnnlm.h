@@ -153,6 +153,12 @@ int gnnlm_chain_attn(const gnnlm_chain_attn_t* desc, void* stream);
  * fairseq/data/token_block_dataset.py:586-594; edge_softmax fairseq/models/hgt.py:356).
  * S holds n_mats matrices of T rows, row stride ld; columns >= T are zeroed. */
 int gnnlm_causal_softmax(float* S, int64_t n_mats, int32_t T, int64_t ld, int32_t max_ctx, void* stream);
+/* The three steps above in one kernel for the recipe shape T = 256, d_k = 128 (other shapes: -EINVAL, use the GEMM +
+ * gnnlm_causal_softmax + GEMM sequence): Q, K', V' are [n_blocks*T, ld] f32 with head h at columns [h*dk, (h+1)*dk);
+ * out[blk*T + w, h*dk + :] = sum_{u <= w, w-u < max_ctx} softmax_u(Q_w . K'_u) V'_u.  The score matrix stays in
+ * registers.  Replaces fn.v_dot_u + edge_softmax + u_mul_e/sum on ('tgt','intra','tgt') (hgt.py:354-356,383-385). */
+int gnnlm_causal_attn(const float* Q, const float* K, const float* V, int64_t ld, float* out, int64_t ldo,
+                      int32_t n_blocks, int32_t T, int32_t H, int32_t dk, int32_t max_ctx, void* stream);
 
 /* LayerNorm epilogue of HGTLayer (fairseq/models/hgt.py:404-405).  valid (optional): rows with 0 -> zeros */
 int gnnlm_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,

@@ -474,3 +474,34 @@ def test_masked_sum_and_half(ops, dev):
     assert abs(acc.item() - (x.double()[m.bool()].sum() + x.double().sum()).item()) < 1e-9
     h = torch.randn(1000, generator=g).half()
     assert torch.equal(ops.half_to_float(h.to(dev)).cpu(), h.float())
+
+
+# ------------------------------------------------------------------------------------------ fused causal attention
+@pytest.mark.parametrize("max_ctx", [0, 1, 37, 256])
+def test_causal_attn_fused(ops, dev, max_ctx):
+    """scores + masked softmax + P.V in one kernel (T = 256, d_k = 128) against float64: softmax over the keys
+    u <= w (and w - u < max_ctx) of every query w (DGL edge_softmax by destination on the causal edges,
+    token_block_dataset.py:586-594, hgt.py:354-356,383-385)."""
+    g = torch.Generator().manual_seed(max_ctx)
+    nb, T, H, dk = 3, 256, 2, 128
+    Q = torch.randn(nb * T, H * dk, generator=g) * 0.3
+    K = torch.randn(nb * T, H * dk, generator=g) * 0.3
+    V = torch.randn(nb * T, H * dk, generator=g)
+    out = ops.causal_attn(Q.to(dev), K.to(dev), V.to(dev), nb, T, H, max_ctx).cpu().double()
+    q = Q.double().view(nb, T, H, dk).permute(0, 2, 1, 3)
+    k = K.double().view(nb, T, H, dk).permute(0, 2, 1, 3)
+    v = V.double().view(nb, T, H, dk).permute(0, 2, 1, 3)
+    sc = q @ k.transpose(-1, -2)
+    w = torch.arange(T)[:, None]
+    u = torch.arange(T)[None, :]
+    keep = (u <= w) & ((w - u < max_ctx) if max_ctx > 0 else torch.ones_like(u <= w))
+    sc = sc.masked_fill(~keep, float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(nb * T, H * dk)
+    assert (out - ref).abs().max() < 2e-5
+
+
+def test_causal_attn_other_shapes_refused(ops, dev):
+    from gnnlm_amd._lib import GnnlmError
+    x = torch.randn(64, 64, device=dev)
+    with pytest.raises(GnnlmError):
+        ops.causal_attn(x, x, x, 1, 64, 2)
