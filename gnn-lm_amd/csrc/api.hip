@@ -266,9 +266,9 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             TRY(gemm_nt(g, s));
         }
         // a_linear on the cross-type mean (0.5 folded into alpha) + residual, then LayerNorm (hgt.py:397-405)
-        TRY(linear(b.ms, d, w.wa_t, w.ba_t, b.aout, Tt, d, d, ht_in, 0.5f, s));
+        TRY(linear(b.ms, d, w.wa_t, w.ba_t, b.aout, Tt, d, d, nullptr, 0.5f, s));
         float* ht_out = last ? io.out_tgt : b.ht[l & 1];
-        TRY(layernorm(b.aout, d, w.ln_g_t, w.ln_b_t, ht_out, d, Tt, d, m.ln_eps, nullptr, s));
+        TRY(layernorm(b.aout, d, w.ln_g_t, w.ln_b_t, ht_out, d, Tt, d, m.ln_eps, nullptr, s, ht_in, d));    // + h (hgt.py:403)
 
         // ---- ntgt update (only when a later layer -- or the caller -- consumes it)
         if (ntgt && (!last || io.out_ntgt)) {
@@ -281,9 +281,9 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
             ca.out = b.nq; ca.ldo = d;      // in place over Q: a (group, head) task loads before it stores
             TRY(chain_attn(ca, s));
-            TRY(linear(b.nq, d, w.wa_n, w.ba_n, b.nk, S, d, d, hn_cur, 1.f, s));
+            TRY(linear(b.nq, d, w.wa_n, w.ba_n, b.nk, S, d, d, nullptr, 1.f, s));
             float* hn_out = (last && io.out_ntgt) ? io.out_ntgt : (hn_cur == b.hn[0] ? b.hn[1] : b.hn[0]);
-            TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, S, d, m.ln_eps, valid, s));
+            TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, S, d, m.ln_eps, valid, s, hn_cur, d));
             hn_cur = hn_out;
         }
         ht_in = ht_out;

@@ -44,8 +44,9 @@ int causal_attn_fused(const float* Q, const float* K, const float* V, int64_t ld
                       int n_blocks, int T, int H, int dk, int max_ctx, hipStream_t stream);
 
 // out[r,:] = LayerNorm(x[r,:]) * gamma + beta ; optional row validity (invalid rows -> 0)
-int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,
-              int64_t ldo, int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream);
+int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo,
+              int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream,
+              const float* residual = nullptr, int64_t ldr = 0);     // out = LN(x + residual)
 
 // out = 0.5 * (a + b)
 int mean2(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);

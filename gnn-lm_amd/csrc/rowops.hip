@@ -8,28 +8,72 @@
 namespace gnnlm {
 namespace {
 
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t ldx, const float* gamma,
-                                                        const float* beta, float* out, int64_t ldo,
+// One wave per row.  out = LayerNorm(x (+ residual)) * gamma + beta.  The optional residual is the `+ h` of
+// `trans_out + h` (hgt.py:403): added here, in the same (alpha * acc + bias) + residual order the GEMM epilogue
+// would use, it is a streaming read instead of 16 scattered loads per accumulator tile behind the GEMM's stores.
+// REGS: the row lives in registers (d <= 1024, d % 4 == 0, 16-byte aligned rows): one pass over memory.
+template <bool REGS>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t ldx, const float* residual, int64_t ldr,
+                                                        const float* gamma, const float* beta, float* out, int64_t ldo,
                                                         int64_t rows, int d, float eps, const uint8_t* valid) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * ldx;
+    const float* rr = residual ? residual + row * ldr : nullptr;
     float* orow = out + row * ldo;
     if (valid && !valid[row]) {
         for (int e = lane; e < d; e += 64) orow[e] = 0.f;
         return;
     }
-    float s = 0.f;
-    for (int e = lane; e < d; e += 64) s += xr[e];
-    const float mean = wave_sum(s) / d;
-    float v = 0.f;
-    for (int e = lane; e < d; e += 64) {
-        const float c = xr[e] - mean;
-        v = fmaf(c, c, v);
+    if constexpr (REGS) {
+        float4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = 4 * (lane + 64 * t);
+            v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < d) {
+                v[t] = *reinterpret_cast<const float4*>(xr + e);
+                if (rr) {
+                    const float4 r = *reinterpret_cast<const float4*>(rr + e);
+                    v[t].x += r.x; v[t].y += r.y; v[t].z += r.z; v[t].w += r.w;
+                }
+                s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+            }
+        }
+        const float mean = wave_sum(s) / d;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * (lane + 64 * t) < d) {
+                const float a = v[t].x - mean, b = v[t].y - mean, c = v[t].z - mean, e_ = v[t].w - mean;
+                q = fmaf(a, a, fmaf(b, b, fmaf(c, c, fmaf(e_, e_, q))));
+            }
+        const float rstd = rsqrtf(wave_sum(q) / d + eps);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = 4 * (lane + 64 * t);
+            if (e < d) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + e), bt = *reinterpret_cast<const float4*>(beta + e);
+                float4 o;
+                o.x = (v[t].x - mean) * rstd * g.x + bt.x; o.y = (v[t].y - mean) * rstd * g.y + bt.y;
+                o.z = (v[t].z - mean) * rstd * g.z + bt.z; o.w = (v[t].w - mean) * rstd * g.w + bt.w;
+                *reinterpret_cast<float4*>(orow + e) = o;
+            }
+        }
+    } else {
+        float s = 0.f;
+        for (int e = lane; e < d; e += 64) s += xr[e] + (rr ? rr[e] : 0.f);
+        const float mean = wave_sum(s) / d;
+        float v = 0.f;
+        for (int e = lane; e < d; e += 64) {
+            const float c = xr[e] + (rr ? rr[e] : 0.f) - mean;
+            v = fmaf(c, c, v);
+        }
+        const float rstd = rsqrtf(wave_sum(v) / d + eps);
+        for (int e = lane; e < d; e += 64) orow[e] = (xr[e] + (rr ? rr[e] : 0.f) - mean) * rstd * gamma[e] + beta[e];
     }
-    const float rstd = rsqrtf(wave_sum(v) / d + eps);
-    for (int e = lane; e < d; e += 64) orow[e] = (xr[e] - mean) * rstd * gamma[e] + beta[e];
 }
 
 __global__ void mean2_kernel(const float* a, const float* b, float* out, int64_t n) {
@@ -275,12 +319,15 @@ __global__ __launch_bounds__(1024) void masked_sum_f64_kernel(const float* x, co
 }  // namespace
 
 int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo,
-              int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream) {
+              int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream, const float* residual, int64_t ldr) {
     GNNLM_REQUIRE(x && gamma && beta && out && d > 0, "layernorm: bad arguments");
     if (rows == 0) return OK;
-    ProfScope prof(K_LAYERNORM, stream, 0.0, 8.0 * rows * d);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, x, ldx, gamma, beta,
-                       out, ldo, rows, d, eps, valid);
+    ProfScope prof(K_LAYERNORM, stream, 0.0, (residual ? 12.0 : 8.0) * rows * d);
+    const bool a16 = ((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)residual) % 16 == 0;
+    const bool regs = d <= 1024 && d % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (!residual || ldr % 4 == 0) && a16;
+    const dim3 grid((unsigned)cdiv(rows, 4)), block(256);
+    if (regs) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, stream, x, ldx, residual, ldr, gamma, beta, out, ldo, rows, d, eps, valid);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, stream, x, ldx, residual, ldr, gamma, beta, out, ldo, rows, d, eps, valid);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }
