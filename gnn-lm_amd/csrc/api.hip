@@ -206,8 +206,8 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         TRY(linear(ht_in, d, w.wk_t, w.bk_t, b.k, Tt, d, d, nullptr, 1.f, s));
         if (causal_attn_fused_ok(T, dk)) {
             // recipe shape: V' row-major, then scores + masked softmax + P.V in one kernel (attn.hip)
+            // (the kernel itself runs after the star branch and adds its result into the message sum, see below)
             TRY(linear(ht_in, d, w.wv_t, w.bv_t, b.vt, Tt, d, d, nullptr, 1.f, s));
-            TRY(causal_attn_fused(b.q, b.k, b.vt, d, b.mc, d, nb, T, H, dk, m.max_intra_context, s));
         } else {
             {   // V'^T[blk][n][t] = sum_k Wv'[n,k] h[blk*T + t, k] + bv'[n]
                 GemmParams g{};
@@ -260,10 +260,15 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         {   // 2*agg = Z Wvz + has_nb * bvz + m_causal
             GemmParams g{};
             g.A = b.Z; g.lda = (int64_t)H * din; g.W = w.wvz_t; g.ldw = din; g.C = b.ms; g.ldc = d;
-            g.bias = w.bvz; g.bias_mode = 1; g.gate = b.has_nb; g.R = b.mc; g.ldr = d;
+            g.bias = w.bvz; g.bias_mode = 1; g.gate = b.has_nb;
+            const bool fused = causal_attn_fused_ok(T, dk);
+            if (!fused) { g.R = b.mc; g.ldr = d; }
             g.M = (int)Tt; g.N = dk; g.K = din; g.batch1 = H;
             g.sA1 = din; g.sW1 = (int64_t)dk * din; g.sC1 = dk; g.sB1 = dk; g.sR1 = dk;
             TRY(gemm_nt(g, s));
+            // recipe shape: the causal branch adds itself into the sum with coalesced row accesses -- cheaper than
+            // the residual loads of the GEMM epilogue (same value: star + causal, fp32 addition commutes)
+            if (fused) TRY(causal_attn_fused(b.q, b.k, b.vt, d, b.ms, d, nb, T, H, dk, m.max_intra_context, s, true));
         }
         // a_linear on the cross-type mean (0.5 folded into alpha) + residual, then LayerNorm (hgt.py:397-405)
         TRY(linear(b.ms, d, w.wa_t, w.ba_t, b.aout, Tt, d, d, nullptr, 0.5f, s));

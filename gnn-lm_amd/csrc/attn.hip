@@ -575,6 +575,7 @@ struct CausalAttnParams {
     const float* Q; const float* K; const float* V; float* out;    // [n_blocks * T, ld] rows; head h at column h * dk
     int64_t ld, ldo;
     int n_blocks, H, max_ctx;
+    int accumulate;               // 1: out += result (the cross-edge-type sum of the HGT layer lands in one buffer)
 };
 
 __global__ __launch_bounds__(512, 1) void causal_attn_256x128_kernel(CausalAttnParams p) {
@@ -711,7 +712,8 @@ __global__ __launch_bounds__(512, 1) void causal_attn_256x128_kernel(CausalAttnP
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            ob[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.ldo + 32 * c] = oc[c][r];
+            if (p.accumulate) ob[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.ldo + 32 * c] += oc[c][r];
+            else ob[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.ldo + 32 * c] = oc[c][r];
 }
 
 }  // namespace
@@ -788,7 +790,7 @@ int causal_softmax(float* S, int64_t n_mats, int T, int64_t ld, int max_ctx, hip
 bool causal_attn_fused_ok(int T, int dk) { return T == 256 && dk == 128; }
 
 int causal_attn_fused(const float* Q, const float* K, const float* V, int64_t ld, float* out, int64_t ldo,
-                      int n_blocks, int T, int H, int dk, int max_ctx, hipStream_t stream) {
+                      int n_blocks, int T, int H, int dk, int max_ctx, hipStream_t stream, bool accumulate) {
     GNNLM_REQUIRE(Q && K && V && out, "causal_attn: null operand");
     GNNLM_REQUIRE(causal_attn_fused_ok(T, dk), "causal_attn: the fused kernel is built for T = 256, d_k = 128");
     GNNLM_REQUIRE(ld % 4 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0) && ((uintptr_t)V % 16 == 0),
@@ -801,7 +803,7 @@ int causal_attn_fused(const float* Q, const float* K, const float* V, int64_t ld
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    CausalAttnParams p{Q, K, V, out, ld, ldo, n_blocks, H, max_ctx};
+    CausalAttnParams p{Q, K, V, out, ld, ldo, n_blocks, H, max_ctx, accumulate ? 1 : 0};
     const double pairs = (double)n_blocks * H;
     // algorithmic: the causal half of 2 * (T * T * dk) * 2 flops per (block, head)
     ProfScope prof(K_CAUSAL, stream, pairs * 2.0 * T * (T + 1) * dk, pairs * 4.0 * T * dk * 4.0);

@@ -41,7 +41,7 @@ int causal_softmax(float* S, int64_t n_mats, int T, int64_t ld, int max_ctx, hip
 // column h * dk
 bool causal_attn_fused_ok(int T, int dk);
 int causal_attn_fused(const float* Q, const float* K, const float* V, int64_t ld, float* out, int64_t ldo,
-                      int n_blocks, int T, int H, int dk, int max_ctx, hipStream_t stream);
+                      int n_blocks, int T, int H, int dk, int max_ctx, hipStream_t stream, bool accumulate = false);
 
 // out[r,:] = LayerNorm(x[r,:]) * gamma + beta ; optional row validity (invalid rows -> 0)
 int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo,
