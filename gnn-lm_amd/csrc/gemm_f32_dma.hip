@@ -15,8 +15,13 @@
 //   BK = 16, DMA re-reading one L1-resident stage    127.5          130.9      <- the cost is the load issue itself,
 //                                                                                 not the L2 / fabric latency
 //   register-only MFMA loop (tools/probes/mfma_peak.hip) 155.2 sustained.
-// I.e. getting 16 KiB per stage into LDS costs ~10 % of the matrix pipe whichever way it is staged; the next
-// lever is fewer load instructions per MFMA (256-wide tiles), not deeper prefetch.
+// I.e. getting 16 KiB per stage into LDS costs ~10 % of the matrix pipe whichever way it is staged (spreading the
+// DMA instructions over the stage's k-step groups instead of issuing them together: no gain either); what helped
+// is fewer load instructions per MFMA (256-wide tiles).  Reference point: the vendor library's f32 GEMM
+// (tools/vendor_gemm_bench.py) does 131 / 134 / 143 / 149 TFLOP/s on 8192x20002x1024 / 8192x1024x1024 /
+// 163840x1024x1024 / 4096^3 -- hand-scheduled assembly hides the loads completely; this HIP kernel gives 5-15 %
+// away on the plain shapes and wins where the fused epilogue matters (the head with its log-sum-exp: 2.52 ms here
+// against 2.56 ms for the vendor GEMM alone, before any softmax over its 655 MB of logits).
 //
 // LDS image of a stage: [256 rows (A 128 + W 128)][BK floats], rows unpadded (a DMA instruction writes
 // wave-uniform base + lane x 16 B: 64 / (BK/4) consecutive rows).  Bank conflicts are avoided by swizzling on the
