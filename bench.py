@@ -208,6 +208,13 @@ def main():
     # Sharded store: the all-to-all row fetch of step i+1 runs on its own stream under the math of step i
     # (the inputs of every step are known up front); RCCL orders itself after the stream it is issued on.
     fetch_stream = torch.cuda.Stream(device=dev) if fetcher is not None else None
+    # the math runs on a high-priority stream when there is an exchange to overlap: the exchange's kernels (bucketing,
+    # owner-side gather, RCCL copies) then fill the tails of the compute kernels instead of time-slicing with them
+    prio = int(os.environ.get("GNNLM_COMPUTE_PRIORITY", "-1"))
+    compute_stream = torch.cuda.Stream(device=dev, priority=prio) if fetcher is not None and prio != 0 else None
+    if compute_stream is not None:
+        compute_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(compute_stream)
     pending = {}
 
     def issue_fetch(bi):
