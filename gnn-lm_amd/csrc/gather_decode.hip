@@ -77,23 +77,41 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherParams p) {
     const int per_row = p.M >> 4;                                   // 16-B pieces per row
     const int64_t n = p.n_groups;
     const int64_t total = n * per_row;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t s = e / per_row;
-        const int part = (int)(e - s * per_row);
-        const int64_t row = p.ids[s];
-        const int64_t lrow = row - p.row0;
-        const bool local = row >= 0 && row < p.n_store && lrow >= 0 && lrow < p.n_local;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (local) v = *reinterpret_cast<const uint4*>(p.codes + lrow * p.M + 16 * part);
-        *reinterpret_cast<uint4*>(p.out_codes + s * p.M + 16 * part) = v;
-        if (part == 0) {
-            if (p.out_valid) p.out_valid[s] = local ? 1 : 0;
-            if (p.out_labels) {
-                int32_t lab = -1;
-                if (local && p.vals)
-                    lab = p.vals_itemsize == 2 ? (int32_t) reinterpret_cast<const int16_t*>(p.vals)[lrow]
-                                               : reinterpret_cast<const int32_t*>(p.vals)[lrow];
-                p.out_labels[s] = lab;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    // four independent (id -> row piece) chains per thread per trip: the kernel is bound by the latency of the
+    // dependent pair of loads, not by bytes
+    for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += 4 * stride) {
+        int64_t s[4], lrow[4];
+        int part[4];
+        bool local[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t e = e0 + u * stride;
+            s[u] = e < total ? e / per_row : -1;
+            part[u] = (int)(e - s[u] * per_row);
+            const int64_t row = s[u] >= 0 ? p.ids[s[u]] : -1;
+            lrow[u] = row - p.row0;
+            local[u] = s[u] >= 0 && row >= 0 && row < p.n_store && lrow[u] >= 0 && lrow[u] < p.n_local;
+        }
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (local[u]) v[u] = *reinterpret_cast<const uint4*>(p.codes + lrow[u] * p.M + 16 * part[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (s[u] < 0) continue;
+            *reinterpret_cast<uint4*>(p.out_codes + s[u] * p.M + 16 * part[u]) = v[u];
+            if (part[u] == 0) {
+                if (p.out_valid) p.out_valid[s[u]] = local[u] ? 1 : 0;
+                if (p.out_labels) {
+                    int32_t lab = -1;
+                    if (local[u] && p.vals)
+                        lab = p.vals_itemsize == 2 ? (int32_t) reinterpret_cast<const int16_t*>(p.vals)[lrow[u]]
+                                                   : reinterpret_cast<const int32_t*>(p.vals)[lrow[u]];
+                    p.out_labels[s[u]] = lab;
+                }
             }
         }
     }
