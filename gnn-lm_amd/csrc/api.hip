@@ -38,9 +38,15 @@ hipEvent_t take_event() {
     return e;
 }
 int32_t* take_pinned() {
-    if (!g_pinned_pool.empty()) { int32_t* p = g_pinned_pool.back(); g_pinned_pool.pop_back(); return p; }
-    int32_t* p = nullptr;
-    (void)hipHostMalloc((void**)&p, sizeof(int32_t), hipHostMallocDefault);
+    // slots come from slabs of 1024 pinned ints: hipHostMalloc is a heavy, device-synchronising call that must not
+    // happen per launch inside a timed region
+    if (g_pinned_pool.empty()) {
+        int32_t* slab = nullptr;
+        (void)hipHostMalloc((void**)&slab, 1024 * sizeof(int32_t), hipHostMallocDefault);
+        for (int i = 0; i < 1024; ++i) g_pinned_pool.push_back(slab + i);
+    }
+    int32_t* p = g_pinned_pool.back();
+    g_pinned_pool.pop_back();
     return p;
 }
 }  // namespace
