@@ -1,0 +1,51 @@
+"""bench.py contract on the GPU box: one JSON line with the fields the driver reads, in every store / launch mode
+(tiny shapes; the numbers mean nothing here)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def run_bench(*extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--blocks", "2", "--steps", "3", "--warmup", "2",
+           "--n-store", "30000", "--gcn-k", "16", "--k", "32", "--tokens-per-sample", "32", *extra]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [(), ("--force-exchange",), ("--force-exchange", "--shard-vals", "--layers", "2"),
+                                   ("--graph", "--no-cpu-baseline"), ("--precision", "bf16x6", "--no-cpu-baseline")])
+def test_bench_contract(extra):
+    r = run_bench(*extra)
+    for k in REQUIRED:
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 2 and r["higher_is_better"] is True
+    assert r["unit"] == "tokens/s" and r["value"] > 0 and r["vs_baseline"] is None and r["scaling"] == "weak"
+    assert "workload" in r["config"]
+    roof = r["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] in ("hbm", "mfma") and 0 <= roof["frac"] <= 1.0
+    if "--no-cpu-baseline" not in extra:
+        cb = r["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "tokens/s" and cb["sample"]
+
+
+def test_bench_modes_agree():
+    """The sharded-store exchange and the HIP-graph replay reproduce the direct path's score sum."""
+    a = run_bench("--no-cpu-baseline")
+    b = run_bench("--no-cpu-baseline", "--force-exchange")
+    c = run_bench("--no-cpu-baseline", "--graph")
+    assert a["config"]["synthetic_ppl"] == b["config"]["synthetic_ppl"] == c["config"]["synthetic_ppl"]
