@@ -281,6 +281,9 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
 // + MFMA pass 2 1.36 ms; + depth-2 prefetch 1.39 ms (no gain: not latency-bound); + MFMA pass 1 1.17-1.19 ms.
 // A timing-only variant without the 17-KiB code staging (3 workgroups per CU instead of 2) ran 1.01 ms, but
 // feeding it needs the codes transposed per (token, chunk) by a pre-pass that moves 2 x 134 MB -- no net gain.
+// Mapping one gather instruction to ONE sub-table (32 neighbours x the two halves of a row, so that rows sharing
+// a 128-B line coalesce: ~25 instead of 32 lines per instruction) measured 1.19-1.22 ms against 1.17: the look-up
+// rate does not improve with intra-instruction line sharing.
 #ifndef GNNLM_STAR_EXP
 #define GNNLM_STAR_EXP 0
 #endif
