@@ -335,8 +335,14 @@ def main():
             a, p, unit = e["flops"] / sec / 1e12, PEAK["mfma_f32_tflops"], "TFLOP/s"
         else:
             a, p, unit = e["bytes"] / sec / 1e9, PEAK["hbm_gbs"], "GB/s"
-        return {"kernel": name, "bound": bound, "achieved": round(a, 2), "peak": p, "unit": unit,
-                "frac": round(a / p, 4), "launches": e["launches"], "avg_us": round(e["total_ms"] * 1e3 / e["launches"], 2)}
+        out = {"kernel": name, "bound": bound, "achieved": round(a, 2), "peak": p, "unit": unit,
+               "frac": round(a / p, 4), "launches": e["launches"], "avg_us": round(e["total_ms"] * 1e3 / e["launches"], 2)}
+        # both rates for the kernels that gather AND contract (star attention: code-row gather + f32-MFMA attention)
+        if e["flops"] > 0 and e["bytes"] > 0:
+            out["algorithmic_GBps"] = round(e["bytes"] / sec / 1e9, 1)
+            out["algorithmic_TFLOPs"] = round(e["flops"] / sec / 1e12, 2)
+            out["mfma_f32_frac"] = round(e["flops"] / sec / 1e12 / PEAK["mfma_f32_tflops"], 4)
+        return out
 
     if rank == 0:
         r = roof(dominant, prof)
