@@ -375,6 +375,7 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     GNNLM_REQUIRE(p.batch1 >= 1 && p.batch2 >= 1, "gemm: bad batch");
     GNNLM_REQUIRE(p.precision >= 0 && p.precision <= 2, "gemm: precision must be 0 (f32 MFMA), 1 (bf16x3) or 2 (bf16x6)");
     GNNLM_REQUIRE(!p.lse_part || p.batch1 * p.batch2 == 1, "gemm: the LSE epilogue does not support batches");
+    GNNLM_REQUIRE(!p.lse_part || p.alpha > 0.f, "gemm: the LSE epilogue needs alpha > 0");
     GNNLM_REQUIRE(p.tile_order >= 0 && p.tile_order <= 66, "gemm: tile_order must be 0 (auto), 1 (n fastest), 2 (m fastest) or 2+GM (bands of GM m-tiles)");
     if (p.M == 0) return OK;
     if (p.tile_order == 0)      // share the larger operand's panel between consecutive tiles

@@ -167,6 +167,106 @@ __global__ __launch_bounds__(BT == 256 ? 512 : 256, BT == 256 ? 1 : (BK == 16 ? 
     }
 #undef GNNLM_SWZ
 }
+
+// A-stationary variant for short-K log-sum-exp problems (the 207,744-word tail band: K = 64, ~1000 live rows).
+// At K = 64 a 128x128 tile is 2 MFLOP for 64 KiB of operands: the generic kernels are bound by the L2 -> LDS
+// path, not by the matrix cores (measured 292 us = 57 % of the f32 MFMA peak).  Here a workgroup keeps ONE m-tile
+// for its whole life -- its A operand (128 rows x K) lives in 64 registers per lane -- and walks the n-tiles, so
+// only the W tile (32 KiB) moves per 2 MFLOP and only W is read back from LDS.  W tiles arrive by LDS-DMA, double-
+// buffered, rows of 256 B swizzled on the source side (slot s of row r holds k-chunk s ^ (r & 15)).
+template <int K>
+__global__ __launch_bounds__(256, 3) void gemm_lse_astationary_kernel(const GemmParams p) {
+    constexpr int EPI = EPI_LSE;
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WROWS = 64, WCOLS = 64;
+    constexpr int CH = K / 4, RPI = 64 / CH, NI = BN / RPI / 4, TILE = BN * K;
+    static_assert(K == 64, "row swizzle below is written for 256-byte rows");
+    extern __shared__ __attribute__((aligned(16))) float dyn[];          // [BN][K] W tile, then BM ints
+    float* wt = dyn;
+    float* lds = dyn + TILE;                                              // the epilogue's pick staging
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int b1 = 0, b2 = 0;
+
+    int M = p.M;
+    if (p.m_dev) M = min(M, *p.m_dev);
+    if (p.m_out && blockIdx.x == 0 && threadIdx.x == 0) *p.m_out = M;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    if (tiles_m == 0) return;
+    const int nslots = (int)gridDim.x / tiles_m;                          // workgroups per m-tile
+    if ((int)blockIdx.x >= nslots * tiles_m) return;
+    const int tm = blockIdx.x % tiles_m, slot = blockIdx.x / tiles_m;
+    const int m0 = tm * BM;
+
+    // the stationary operand: A[row][8 s + 4 half + e] for this lane's two rows
+    float4 areg[TM][K / 8];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int gr = m0 + wm * WROWS + 32 * i + l32;
+        int64_t ar = gr < M ? (p.a_rows ? (int64_t)p.a_rows[gr] : (int64_t)gr) : 0;
+        if (ar < 0) ar = 0;
+        const float* arow = p.A + ar * p.lda + 4 * half;
+#pragma unroll
+        for (int s = 0; s < K / 8; ++s) areg[i][s] = *reinterpret_cast<const float4*>(arow + 8 * s);
+    }
+
+    const int d_slot = lane % CH, d_rsub = lane / CH;
+#define GNNLM_ISSUE_W(nt_)                                                                   \
+    _Pragma("unroll") for (int q = 0; q < NI; ++q) {                                         \
+        const int irow = (NI * wave + q) * RPI + d_rsub;                                     \
+        const int gn = (nt_) * BN + irow;                                                    \
+        const float* src_ = p.W + (int64_t)(gn < p.N ? gn : 0) * p.ldw + 4 * (d_slot ^ (irow & 15)); \
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src_,                                  \
+            (lds_void_t*)(wt + (NI * wave + q) * RPI * K), 16, 0, 0);                        \
+    }
+
+    int nt = slot;
+    if (nt >= tiles_n) return;
+    GNNLM_ISSUE_W(nt)
+    if (tid < BM) reinterpret_cast<int*>(lds)[tid] = (p.lse_pick && m0 + tid < M) ? p.lse_pick[m0 + tid] : -1;   // once: the m-tile is fixed
+    __syncthreads();
+    // One W buffer: the next tile's DMA is issued when this tile's MFMAs have read it and lands under the
+    // log-sum-exp epilogue (~1 us of VALU work), so a second buffer would buy nothing -- and 33 KiB of LDS per
+    // workgroup lets three of them share a CU, which is what hides the epilogue behind other waves' MFMAs.
+    for (; nt < tiles_n; nt += nslots) {
+        const int n0 = nt * BN;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const float* sb = wt;
+#pragma unroll
+        for (int s = 0; s < K / 8; ++s) {
+            float4 b[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * WCOLS + 32 * j + l32;
+                b[j] = *reinterpret_cast<const float4*>(sb + r * K + 4 * ((2 * s + half) ^ (r & 15)));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {      // operands swapped: transposed accumulators (gemm_epilogue.inc)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].x, areg[i][s].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].y, areg[i][s].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].z, areg[i][s].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].w, areg[i][s].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();            // every wave has read the tile
+        if (nt + nslots < tiles_n) GNNLM_ISSUE_W(nt + nslots)
+#define GNNLM_LSE_PICK_STAGED
+#include "gemm_epilogue.inc"
+#undef GNNLM_LSE_PICK_STAGED
+        __syncthreads();            // the next W tile landed (the barrier carries the DMA's vmcnt(0))
+    }
+#undef GNNLM_ISSUE_W
+}
 }  // namespace
 
 #ifndef GNNLM_DMA_BK
@@ -188,6 +288,7 @@ bool gemm_dma_eligible(const GemmParams& p) {
 #ifndef GNNLM_DMA_STORE
     if (!p.lse_part) return false;
 #endif
+    if (p.precision == 0 && p.K == 64 && p.lse_part && p.batch1 * p.batch2 == 1 && p.M <= 128 * 768) return true;   // A-stationary kernel
     return p.precision == 0 && p.K % GNNLM_DMA_BK == 0 && p.K >= GNNLM_DMA_MIN_K;
 }
 
@@ -212,6 +313,22 @@ int launch_dma(const GemmParams& p, dim3 grid, hipStream_t stream) {
 int gemm_nt_dma(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     constexpr int BK = GNNLM_DMA_BK;
+    if (p.K == 64 && p.lse_part) {      // short-K log-sum-exp: A stays in registers, workgroups walk the n-tiles
+        constexpr size_t lds_bytes = (128 * 64 + 128) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lse_astationary_kernel<64>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_set = true;
+        }
+        const double work = 2.0 * p.M * (double)p.N * p.K;
+        ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N),
+                       p.m_dev, (double)p.M, true);
+        if (prof.slot) p.m_out = prof.slot;
+        hipLaunchKernelGGL((gemm_lse_astationary_kernel<64>), dim3(768), dim3(256), lds_bytes, stream, p);
+        GNNLM_LAUNCH_CHECK();
+        return OK;
+    }
     const int64_t nb = (int64_t)p.batch1 * p.batch2;
     const bool big = !p.m_dev && cdiv(p.M, 256) * cdiv(p.N, 256) * nb >= GNNLM_DMA_BIG_TILES;
     const int BT = big ? 256 : 128;
