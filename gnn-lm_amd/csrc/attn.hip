@@ -279,6 +279,8 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
 // k-step (rows 4 apart = 16 banks apart: 4 rows x 16 consecutive dims, again 64 different banks).
 // Measured at T = 8192, WikiText-103 shape: generic 1.57 ms; swept, VALU pass 2, depth-1 prefetch 1.42 ms;
 // + MFMA pass 2 1.36 ms; + depth-2 prefetch 1.39 ms (no gain: not latency-bound); + MFMA pass 1 1.17-1.19 ms.
+// + producer / consumer wave roles 1.16 ms: the iteration is as long as the decode chain alone -- the kernel is bound
+// by the rate at which the L1 serves 16-B gathers (~0.37 lines per cycle per CU measured here), not by latency.
 // A timing-only variant without the 17-KiB code staging (3 workgroups per CU instead of 2) ran 1.01 ms, but
 // feeding it needs the codes transposed per (token, chunk) by a pre-pass that moves 2 x 134 MB -- no net gain.
 // Mapping one gather instruction to ONE sub-table (32 neighbours x the two halves of a row, so that rows sharing
@@ -288,7 +290,13 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
 #define GNNLM_STAR_EXP 0
 #endif
 template <int DSUB>
-__global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, int h0) {
+__global__ __launch_bounds__(512, 2) void star_attn_sweep_kernel(StarAttnParams p, int h0) {
+    // Wave specialisation: waves 0..3 are CONSUMERS (the two MFMA passes and the softmax), waves 4..7 PRODUCERS
+    // (the decode: code look-up, centroid gathers, slab commits).  The two halves meet only at the chunk barrier,
+    // so an iteration costs max(decode chain, MFMA chain) instead of their sum.  With every wave running both
+    // chains back to back, waves spent ~45 % of their time in s_waitcnt (SQ_WAIT_ANY) while neither the L1 tag
+    // pipeline (~37 % busy) nor the matrix cores (~40 %) were saturated: 1.17 ms per 8192 tokens.  The roles are
+    // separate code paths (same number of barriers on both), so a wave's registers hold one role's state only.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int KGM = 128, CD = 32;
     constexpr int XS = CD + 4;                  // slab row stride (floats), see the bank notes above
@@ -299,7 +307,8 @@ __global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, 
     const int D = p.D, NCH = D / CD;
     const int kg = p.kg, M = p.M, H = p.H;
     const int MS = M + 4;                       // padded code row stride (bytes): conflict-free column reads
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = threadIdx.x >= 256;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // index inside the role
     float* xc = smem;                                               // [2][KGM + HB][XS] decoded slabs + query rows
     float* sc = xc + 2 * SLAB;                                      // [HB][SCS] scores -> alphas
     uint8_t* lcodes = reinterpret_cast<uint8_t*>(sc + HB * SCS);    // [KGM][MS]
@@ -307,9 +316,9 @@ __global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, 
     const int i = blockIdx.x;
     const int64_t* ids = p.ids + (int64_t)i * kg;
 
-    {   // stage the code rows (zeros for invalid neighbours): 16-B global pieces, coalesced
+    {   // stage the code rows (zeros for invalid neighbours): 16-B global pieces, coalesced; all 512 threads
         const int per_row = M >> 4;
-        for (int e = tid; e < KGM * per_row; e += 256) {
+        for (int e = threadIdx.x; e < KGM * per_row; e += 512) {
             const int j = e / per_row, part = e - j * per_row;
             const int64_t id = j < kg ? ids[j] : -1;
             const int64_t lrow = p.codes_direct ? (p.codes_index ? (int64_t)p.codes_index[((int64_t)i * kg + j) * p.codes_direct] : ((int64_t)i * kg + j) * p.codes_direct) : id - p.row0;
@@ -321,15 +330,17 @@ __global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, 
     }
     __syncthreads();
 
-    const float* cen = p.centroids;
-    // slab builder: thread t decodes float4 `t % 8` of the neighbours (t / 8) + 32 q, q = 0..3; lane pairs
-    // fetch the two halves of one 32-B centroid row.  Threads 0..63 also carry the chunk's query rows
-    // (pass 1): float4 `t % 8` of head t / 8.
-    const int ddq = tid % NDQ, dj0 = tid / NDQ;
-    const int dm_in = (4 * ddq) / DSUB, dwithin = (4 * ddq) % DSUB;
-    const float* Uq = p.U + ((int64_t)i * H + h0 + min(dj0 & 7, H - 1 - h0)) * D + 4 * ddq;
-    float4 xrA0, xrA1, xrA2, xrA3, xrB0, xrB1, xrB2, xrB3, uqA, uqB;
-    uqA = uqB = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (producer) {
+        // ================================================================ PRODUCERS: build the slabs
+        // thread t decodes float4 `t % 8` of the neighbours (t / 8) + 32 q, q = 0..3; lane pairs fetch the two halves
+        // of one 32-B centroid row.  Threads 0..63 also carry the chunk's query rows (pass 1): float4 `t % 8` of
+        // head t / 8.  Gathers are two chunks ahead of their commit (two register sets, loop unrolled by two).
+        const float* cen = p.centroids;
+        const int ddq = tid % NDQ, dj0 = tid / NDQ;
+        const int dm_in = (4 * ddq) / DSUB, dwithin = (4 * ddq) % DSUB;
+        const float* Uq = p.U + ((int64_t)i * H + h0 + min(dj0 & 7, H - 1 - h0)) * D + 4 * ddq;
+        float4 xrA0, xrA1, xrA2, xrA3, xrB0, xrB1, xrB2, xrB3, uqA, uqB;
+        uqA = uqB = make_float4(0.f, 0.f, 0.f, 0.f);
 #define GNNLM_FETCH1(XR, Q, m_)                                                                         \
     XR = *reinterpret_cast<const float4*>(                                                              \
         cen + ((int64_t)((m_) * 256 + (GNNLM_STAR_EXP == 3 ? 0 : lcodes[(dj0 + 32 * (Q)) * MS + (m_)]))) * DSUB + dwithin);
@@ -349,9 +360,34 @@ __global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, 
         *reinterpret_cast<float4*>(d_ + 96 * XS) = xr##S##3;                                            \
         if (WITH_U && tid < 64) *reinterpret_cast<float4*>(d_ + 128 * XS) = uq##S;                      \
     }
+#define GNNLM_PRODUCE_SWEEP(WITH_U)                                                                     \
+    GNNLM_FETCH(0, A, WITH_U)                                                                           \
+    GNNLM_COMMIT(0, A, 0, WITH_U)                                                                       \
+    GNNLM_FETCH(1, B, WITH_U)                                                                           \
+    __syncthreads();                                                                                    \
+    for (int c = 0; c < NCH; c += 2) {                                                                  \
+        GNNLM_FETCH(c + 2, A, WITH_U)                                                                   \
+        GNNLM_COMMIT(1, B, c + 1, WITH_U)                                                               \
+        __syncthreads();                                                                                \
+        if (c + 1 < NCH) {                                                                              \
+            GNNLM_FETCH(c + 3, B, WITH_U)                                                               \
+            GNNLM_COMMIT(0, A, c + 2, WITH_U)                                                           \
+            __syncthreads();                                                                            \
+        }                                                                                               \
+    }
+        GNNLM_PRODUCE_SWEEP(true)               // pass 1 (query rows ride along)
+        __syncthreads();                        // scores written (consumers)
+        GNNLM_PRODUCE_SWEEP(false)              // pass 2: its first slabs are built under the consumers' softmax
+#undef GNNLM_PRODUCE_SWEEP
+#undef GNNLM_FETCH
+#undef GNNLM_FETCH1
+#undef GNNLM_COMMIT
+        return;
+    }
 
+    // ==================================================================== CONSUMERS: the two MFMA passes
     const int n16 = lane & 15, g = lane >> 4;
-    // ---------------- pass 1 on the f32 matrix cores: S[128 nb x 16 (8 real) heads] += X[128 x 32] . U^T
+    // ---------------- pass 1: S[128 nb x 16 (8 real) heads] += X[128 x 32] . U^T
     {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const float* xa = xc + (32 * wave + n16) * XS + g;          // A: X[nb = 32 w + 16 rt + n16][4 ks + g]
@@ -362,19 +398,12 @@ __global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, 
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(buf) * SLAB + 4 * ks], b_, acc0, 0, 0, 0);      \
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(buf) * SLAB + 16 * XS + 4 * ks], b_, acc1, 0, 0, 0); \
     }
-        GNNLM_FETCH(0, A, true)
-        GNNLM_COMMIT(0, A, 0, true)
-        GNNLM_FETCH(1, B, true)
-        __syncthreads();
+        __syncthreads();                        // slab 0 built
         for (int c = 0; c < NCH; c += 2) {
-            GNNLM_FETCH(c + 2, A, true)
             GNNLM_PASS1(0)
-            GNNLM_COMMIT(1, B, c + 1, true)
             __syncthreads();
             if (c + 1 < NCH) {
-                GNNLM_FETCH(c + 3, B, true)
                 GNNLM_PASS1(1)
-                GNNLM_COMMIT(0, A, c + 2, true)
                 __syncthreads();
             }
         }
@@ -390,7 +419,7 @@ __global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, 
         }
     }
     __syncthreads();
-    // ---------------- softmax over j per head (wave w: heads w, w+4)
+    // ---------------- softmax over j per head (wave w: heads w, w+4) while the producers build pass 2's first slab
     for (int h = wave; h < HB; h += 4) {
         const float v0 = sc[h * SCS + lane], v1 = sc[h * SCS + 64 + lane];
         const float mx = wave_max(fmaxf(v0, v1));
@@ -401,13 +430,10 @@ __global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, 
         sc[h * SCS + 64 + lane] = e1 * inv;
         if (h == 0 && h0 == 0 && lane == 0 && p.has_nb) p.has_nb[i] = sum > 0.f ? 1.f : 0.f;
     }
-    // ---------------- pass 2 on the f32 matrix cores: Z[16 (8 real) heads x 32 dims] = alpha^T . X per chunk
+    // ---------------- pass 2: Z[16 (8 real) heads x 32 dims] = alpha^T . X per chunk
     {
         const int tile = wave & 1, kh = wave >> 1;
-        GNNLM_FETCH(0, A, false)
-        GNNLM_COMMIT(0, A, 0, false)
-        GNNLM_FETCH(1, B, false)
-        __syncthreads();                       // also orders the softmax writes before the alpha reads
+        __syncthreads();                       // slab 0 of pass 2 built; also orders the softmax writes before the alpha reads
         // k-step ks, lane group g  <->  neighbour j = 64 kh + 16 (ks / 4) + (ks % 4) + 4 g: rows 4 apart are
         // 16 banks apart at a 36-float stride
         float a_reg[16];
@@ -435,15 +461,11 @@ __global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, 
     }
         f32x4 zacc;
         for (int c = 0; c < NCH; c += 2) {
-            GNNLM_FETCH(c + 2, A, false)
             GNNLM_PASS2(0, c)
-            GNNLM_COMMIT(1, B, c + 1, false)
             __syncthreads();
             GNNLM_ZSTORE(0, c)
             if (c + 1 < NCH) {
-                GNNLM_FETCH(c + 3, B, false)
                 GNNLM_PASS2(1, c + 1)
-                GNNLM_COMMIT(0, A, c + 2, false)
                 __syncthreads();
                 GNNLM_ZSTORE(1, c + 1)
             }
@@ -451,9 +473,6 @@ __global__ __launch_bounds__(256) void star_attn_sweep_kernel(StarAttnParams p, 
 #undef GNNLM_PASS2
 #undef GNNLM_ZSTORE
     }
-#undef GNNLM_FETCH
-#undef GNNLM_FETCH1
-#undef GNNLM_COMMIT
 }
 
 constexpr int MAX_NG = 8;
@@ -746,7 +765,7 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
         const int MS = p.M + 4;
         const size_t lds_bytes = 4 * (size_t)(2 * (128 + HB) * 36 + HB * 132 + (128 * MS + 15) / 4 + 1024);
         for (int h0 = 0; h0 < p.H; h0 += HB) {
-            dim3 grid(p.T), block(256);
+            dim3 grid(p.T), block(512);
             if (p.dsub == 8) hipLaunchKernelGGL((star_attn_sweep_kernel<8>), grid, block, lds_bytes, stream, p, h0);
             else hipLaunchKernelGGL((star_attn_sweep_kernel<4>), grid, block, lds_bytes, stream, p, h0);
         }
