@@ -272,6 +272,9 @@ __global__ __launch_bounds__(256, 3) void gemm_lse_astationary_kernel(const Gemm
 #ifndef GNNLM_DMA_BK
 #define GNNLM_DMA_BK 32
 #endif
+#ifndef GNNLM_DMA_BIG_TILES
+#define GNNLM_DMA_BIG_TILES 2048     // 256x256 tiles from this many of them on (8 per CU); 1 << 30 disables
+#endif
 #ifndef GNNLM_DMA_MIN_K
 #define GNNLM_DMA_MIN_K 128
 #endif
@@ -286,7 +289,8 @@ bool gemm_dma_eligible(const GemmParams& p) {
     // LSE problems take this kernel and the store-epilogue problems stay on the register-staged one
     // (GNNLM_DMA_STORE=1 at build time sends them here too, for A/B runs).
 #ifndef GNNLM_DMA_STORE
-    if (!p.lse_part) return false;
+    // ... except the head-sized ones, which get the 256x256 tiles: 655360x1024x1024 (3-layer path) 123 -> 128 TFLOP/s
+    if (!p.lse_part && (p.m_dev || cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch1 * p.batch2 < GNNLM_DMA_BIG_TILES)) return false;
 #endif
     if (p.precision == 0 && p.K == 64 && p.lse_part && p.batch1 * p.batch2 == 1 && p.M <= 128 * 768) return true;   // A-stationary kernel
     return p.precision == 0 && p.K % GNNLM_DMA_BK == 0 && p.K >= GNNLM_DMA_MIN_K;
@@ -305,10 +309,6 @@ int launch_dma(const GemmParams& p, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<EPI, BK, BT>), grid, dim3(BT == 256 ? 512 : 256), lds_bytes, stream, p);
     return OK;
 }
-
-#ifndef GNNLM_DMA_BIG_TILES
-#define GNNLM_DMA_BIG_TILES 2048     // 256x256 tiles from this many of them on (8 per CU); 1 << 30 disables
-#endif
 
 int gemm_nt_dma(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;

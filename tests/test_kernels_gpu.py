@@ -101,6 +101,26 @@ def test_gemm_lse_large(ops, dev, precision, tol, M, N, K):
     assert (picked.cpu().double()[:m] - logits.gather(1, pick.long()[:, None])[:m, 0]).abs().max() < tol
 
 
+def test_gemm_store_head_sized(ops, dev):
+    """>= 2048 tiles of 256x256 with the store epilogue (LDS-DMA kernel, 8 waves): bias, gate, residual, alpha, ragged
+    last tiles in both directions, checked against float64 in row blocks."""
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 20000, 6700, 128
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    gate = (torch.rand(M, generator=g) < 0.5).float() * 2.0
+    R = torch.randn(M, N, generator=g)
+    out = ops.gemm_nt(A.to(dev), W.to(dev), bias=bias.to(dev), gate=gate.to(dev), residual=R.to(dev), alpha=0.3).cpu()
+    Wd = W.double().t().contiguous()
+    Wa = W.abs().double().t().contiguous()
+    for r0 in range(0, M, 2000):
+        sl = slice(r0, r0 + 2000)
+        ref = 0.3 * (A[sl].double() @ Wd) + gate[sl].double()[:, None] * bias.double()[None, :] + R[sl].double()
+        scale = A[sl].abs().double() @ Wa + 1.0
+        assert ((out[sl].double() - ref).abs() / scale).max() < 5e-7
+
+
 def test_gemm_lse_head_sized(ops, dev):
     """The softmax-head regime (>= 2048 tiles of 256x256: LDS-DMA kernel with 256x256 tiles, 8 waves) against a
     float64 log-sum-exp evaluated in row blocks; ragged last tiles in both directions."""
