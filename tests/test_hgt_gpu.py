@@ -72,7 +72,8 @@ def oracle_hgt(sd, L, H, tgt, nb, codes, cen, A, b, n_store, l, r, dtype=torch.f
 @pytest.mark.parametrize("L", [1, 2, 3])
 @pytest.mark.parametrize("cfg", [dict(d=128, H=8, M=16, dsub=8, opq=True, T=24, kg=6, l=2, r=2),
                                  dict(d=64, H=2, M=8, dsub=4, opq=True, T=9, kg=5, l=1, r=0),     # rectangular OPQ
-                                 dict(d=64, H=4, M=16, dsub=4, opq=False, T=17, kg=3, l=0, r=3)])
+                                 dict(d=64, H=4, M=16, dsub=4, opq=False, T=17, kg=3, l=0, r=3),
+                                 dict(d=512, H=8, M=64, dsub=8, opq=True, T=20, kg=12, l=2, r=2)])   # EnWik8-sized model dims
 def test_hgt_vs_oracle(dev, L, cfg):
     d, H, M, dsub, T, kg, l, r = (cfg[k] for k in ("d", "H", "M", "dsub", "T", "kg", "l", "r"))
     rs = np.random.RandomState(L * 100 + d)
