@@ -68,17 +68,12 @@ def parse():
     return ap.parse_args()
 
 
-def zipf_dev(n, vocab, gen, dev):
-    u = torch.rand(n, generator=gen, device=dev, dtype=torch.float64)
-    return torch.clamp((torch.exp(u * np.log(vocab + 1.0)) - 1.0).to(torch.int64), max=vocab - 1)
-
-
 def build(args, dev, rank, world):
     from gnnlm_amd.adaptive_softmax import AdaptiveSoftmax
     from gnnlm_amd.dist import Shard
     from gnnlm_amd.engine import GnnLmEngine
     from gnnlm_amd.hgt import HGT, CodeStore
-    from gnnlm_amd.synthetic import make_asm_weights, make_codec
+    from gnnlm_amd.synthetic import device_codes, make_asm_weights, make_codec, zipf_dev
     if args.small:
         d, H, M, dsub, vocab, cutoff = 128, 8, 16, 8, 5000, [500, 2000]
     else:
@@ -87,14 +82,8 @@ def build(args, dev, rank, world):
     cen, A, b = make_codec(rs, M, dsub, d, opq=True)
     sharded = (world > 1 or args.force_exchange) and args.store == "sharded"
     shard = Shard(args.n_store, world if sharded else 1, rank if sharded else 0)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + shard.row0)
     n_local = shard.n_local
-    codes = torch.empty(n_local, M, dtype=torch.uint8, device=dev)
-    step = 1 << 22
-    for s in range(0, n_local, step):                                     # uint8 i.i.d. uniform
-        e = min(n_local, s + step)
-        codes[s:e] = torch.randint(0, 256, (e - s, M), generator=gen, device=dev, dtype=torch.uint8)
+    codes = device_codes(n_local, M, dev, 1234 + shard.row0)              # uint8 i.i.d. uniform
     # the label table (413 MB for WikiText-103) is replicated on every rank unless --shard-vals: only the
     # 13.2-GB code table needs the range sharding, and replicated labels save the k=1024-per-token exchange
     shard_vals = sharded and args.shard_vals
@@ -117,6 +106,7 @@ def build(args, dev, rank, world):
 
 def make_batches(args, dev, rank, d, vocab):
     from gnnlm_amd.engine import BlockBatch
+    from gnnlm_amd.synthetic import zipf_dev
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)
     T, B, kg, k, N = args.tokens_per_sample, args.blocks // args.streams, args.gcn_k, args.k, args.n_store

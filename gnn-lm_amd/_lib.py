@@ -54,6 +54,7 @@ def _normalise(text):
     return re.sub(r"(\w)\*\s*(\w)", r"\1 *\2", text)
 
 
+ABI_VERSION = int(re.search(r"#define\s+GNNLM_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
 STRUCTS = _parse_structs(_normalise(open(HEADER).read()))
 globals().update(STRUCTS)
 
@@ -113,8 +114,8 @@ def lib():
         for nm in ("gnnlm_gemm_nt", "gnnlm_pq_gather_decode", "gnnlm_star_attn", "gnnlm_chain_attn",
                    "gnnlm_knn_interp"):
             getattr(L, nm).argtypes = [vp, vp]
-        if L.gnnlm_target_arch() != b"gfx950" or L.gnnlm_abi_version() != 1:
-            raise GnnlmError("libgnnlm_hip.so is not the gfx950 / ABI-1 build")
+        if L.gnnlm_target_arch() != b"gfx950" or L.gnnlm_abi_version() != ABI_VERSION:
+            raise GnnlmError(f"libgnnlm_hip.so is not the gfx950 / ABI-{ABI_VERSION} build")
         _lib = L
     return _lib
 

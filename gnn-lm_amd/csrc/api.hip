@@ -4,6 +4,7 @@
 // stream (no allocation, no synchronisation), so a caller may capture them into a hipGraph.
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "kernels.h"
@@ -30,19 +31,23 @@ struct ProfRec { int kid; hipEvent_t a, b; double flops, bytes; int32_t* host_sc
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_event_pool;
 std::vector<int32_t*> g_pinned_pool;
-hipEvent_t g_pending_start[K_COUNT];
-hipEvent_t take_event() {
+// the start event of an open ProfScope is per host thread (one scope per kernel id at a time on a thread); the
+// record list and the pools are shared and guarded by g_prof_mu, so launches from several host threads may be
+// profiled together
+thread_local hipEvent_t g_pending_start[K_COUNT];
+std::mutex g_prof_mu;
+hipEvent_t take_event() {           // g_prof_mu held; nullptr on failure
     if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
-int32_t* take_pinned() {
+int32_t* take_pinned() {            // g_prof_mu held; nullptr on failure
     // slots come from slabs of 1024 pinned ints: hipHostMalloc is a heavy, device-synchronising call that must not
     // happen per launch inside a timed region
     if (g_pinned_pool.empty()) {
         int32_t* slab = nullptr;
-        (void)hipHostMalloc((void**)&slab, 1024 * sizeof(int32_t), hipHostMallocDefault);
+        if (hipHostMalloc((void**)&slab, 1024 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess || !slab) return nullptr;
         for (int i = 0; i < 1024; ++i) g_pinned_pool.push_back(slab + i);
     }
     int32_t* p = g_pinned_pool.back();
@@ -51,18 +56,29 @@ int32_t* take_pinned() {
 }
 }  // namespace
 void prof_start(int kid, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_pending_start[kid] = take_event();
-    (void)hipEventRecord(g_pending_start[kid], s);
+    if (g_pending_start[kid]) (void)hipEventRecord(g_pending_start[kid], s);
 }
-int32_t* prof_take_slot() { return take_pinned(); }
+int32_t* prof_take_slot() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    return take_pinned();           // nullptr: the launch simply does not report its device-side count
+}
 void prof_stop(int kid, hipStream_t s, double flops, double bytes, const int32_t* scale_dev, double den, int32_t* host_slot) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r{kid, g_pending_start[kid], take_event(), flops, bytes, nullptr, den};
+    if (!r.a || !r.b) {             // event creation failed: this launch is not recorded
+        if (r.a) g_event_pool.push_back(r.a);
+        if (r.b) g_event_pool.push_back(r.b);
+        if (host_slot) g_pinned_pool.push_back(host_slot);
+        return;
+    }
     (void)hipEventRecord(r.b, s);
     if (host_slot) {
         r.host_scale = host_slot;                       // written by the kernel itself
     } else if (scale_dev) {
         r.host_scale = take_pinned();
-        (void)hipMemcpyAsync(r.host_scale, scale_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (r.host_scale) (void)hipMemcpyAsync(r.host_scale, scale_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     }
     g_prof_recs.push_back(r);
 }
@@ -253,6 +269,9 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             StarAttnParams a{};
             a.U = b.U; a.ids = io.ids; a.T = (int)Tt; a.H = H; a.D = din; a.kg = kg;
             a.Z = b.Z; a.has_nb = b.has_nb;
+            a.n_store = m.n_store;
+            if (ntgt) { a.nb_valid = valid; a.nb_valid_stride = n_g; }                  // centre slot of each group
+            else if (io.fetched_valid) { a.nb_valid = io.fetched_valid; a.nb_valid_stride = io.fetched_centres_only ? 1 : n_g; }
             if (l == 0) {
                 a.codes = io.fetched_codes ? io.fetched_codes : m.codes;
                 a.codes_direct = io.fetched_codes ? (io.fetched_centres_only ? 1 : n_g) : 0;
@@ -484,12 +503,14 @@ const char* gnnlm_kernel_name(int32_t kernel_id) {
     return kernel_id >= 0 && kernel_id < K_COUNT ? kKernelNames[kernel_id] : nullptr;
 }
 int gnnlm_profile_begin(uint32_t kernel_mask) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     GNNLM_REQUIRE(g_prof_recs.empty(), "profile_begin: a profile is already open");
     g_prof_mask = kernel_mask;
     return OK;
 }
 int gnnlm_profile_end(gnnlm_profile_entry_t* out, int32_t n_max, int32_t* n_out) {
     GNNLM_REQUIRE(out && n_out && n_max >= K_COUNT, "profile_end: need room for every kernel id");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_mask = 0;
     for (int k = 0; k < K_COUNT; ++k) out[k] = gnnlm_profile_entry_t{k, 0, 0.0, 0.0, 0.0};
     for (auto& r : g_prof_recs) {
@@ -515,13 +536,14 @@ int gnnlm_profile_end(gnnlm_profile_entry_t* out, int32_t n_max, int32_t* n_out)
 
 int gnnlm_store_create(int64_t n_store, int64_t row0, int64_t n_local, int32_t M, int32_t vals_itemsize,
                        int32_t device, gnnlm_store_t** out) {
-    GNNLM_REQUIRE(out && n_store > 0 && row0 >= 0 && n_local > 0 && row0 + n_local <= n_store && M > 0,
+    GNNLM_REQUIRE(out && n_store > 0 && row0 >= 0 && n_local >= 0 && row0 + n_local <= n_store && M > 0,
                   "store_create: bad shape");
     GNNLM_REQUIRE(vals_itemsize == 2 || vals_itemsize == 4, "store_create: vals must be int16 or int32");
     GNNLM_HIP(hipSetDevice(device));
     gnnlm_store* s = new gnnlm_store{n_store, row0, n_local, M, vals_itemsize, device, nullptr, nullptr};
-    hipError_t e = hipMalloc((void**)&s->codes, (size_t)n_local * M);
-    if (e == hipSuccess) e = hipMalloc(&s->vals, (size_t)n_local * vals_itemsize);
+    // an empty shard (more ranks than rows) keeps a 1-row allocation so that the pointers stay non-null
+    hipError_t e = hipMalloc((void**)&s->codes, (size_t)std::max<int64_t>(n_local, 1) * M);
+    if (e == hipSuccess) e = hipMalloc(&s->vals, (size_t)std::max<int64_t>(n_local, 1) * vals_itemsize);
     if (e != hipSuccess) {
         if (s->codes) (void)hipFree(s->codes);
         delete s;

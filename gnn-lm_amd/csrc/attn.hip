@@ -21,6 +21,16 @@ namespace {
 
 constexpr int HB = 8;   // heads processed per pass of star_attn
 
+// Neighbour (i, j) takes part in the star softmax iff its id is a row of the store, the row is present on this
+// shard (PQ source read from the store) and the caller's validity byte (exchange / gather_decode) says so: the
+// rule of gather_decode_kernel, so layer-0 star attention and the ntgt states can never disagree.
+__device__ __forceinline__ bool star_nb_ok(const StarAttnParams& p, int i, int j, int64_t id) {
+    bool ok = id >= 0 && (p.n_store <= 0 || id < p.n_store);
+    if (p.codes && !p.codes_direct) ok = ok && id - p.row0 >= 0 && id - p.row0 < p.n_local;
+    if (ok && p.nb_valid) ok = p.nb_valid[((int64_t)i * p.kg + j) * p.nb_valid_stride] != 0;
+    return ok;
+}
+
 // Sum 8 per-lane partials over the 64 lanes with a transposing butterfly: 10 shuffles instead of 48.
 // On return lane 8*h holds the total of v[h].
 __device__ __forceinline__ float reduce8(const float (&v)[HB], int lane) {
@@ -78,7 +88,8 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
     const int64_t* ids = p.ids + (int64_t)i * kg;
     const int q_per_m = p.codes ? p.dsub / 4 : 1;
 
-    for (int j = tid; j < kg; j += 256) okf[j] = ids[j] >= 0;
+    for (int j = tid; j < kg; j += 256) okf[j] = star_nb_ok(p, i, j, ids[j]);
+    __syncthreads();
     if (p.codes && stage_codes) {
         if ((M & 15) == 0) {
             const int per_row = M >> 4;
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
                 const int64_t id = ids[j];
                 const int64_t lrow = p.codes_direct ? (p.codes_index ? (int64_t)p.codes_index[((int64_t)i * kg + j) * p.codes_direct] : ((int64_t)i * kg + j) * p.codes_direct) : id - p.row0;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (id >= 0) v = *reinterpret_cast<const uint4*>(p.codes + lrow * M + 16 * part);
+                if (okf[j]) v = *reinterpret_cast<const uint4*>(p.codes + lrow * M + 16 * part);
                 *reinterpret_cast<uint4*>(lcodes + j * M + 16 * part) = v;
             }
         } else {
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
                 const int j = e / M, m = e - j * M;
                 const int64_t id = ids[j];
                 const int64_t lrow = p.codes_direct ? (p.codes_index ? (int64_t)p.codes_index[((int64_t)i * kg + j) * p.codes_direct] : ((int64_t)i * kg + j) * p.codes_direct) : id - p.row0;
-                lcodes[e] = id >= 0 ? p.codes[lrow * M + m] : 0;
+                lcodes[e] = okf[j] ? p.codes[lrow * M + m] : 0;
             }
         }
     }
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void star_attn_sweep_kernel(StarAttnParams 
             const int64_t id = j < kg ? ids[j] : -1;
             const int64_t lrow = p.codes_direct ? (p.codes_index ? (int64_t)p.codes_index[((int64_t)i * kg + j) * p.codes_direct] : ((int64_t)i * kg + j) * p.codes_direct) : id - p.row0;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (id >= 0) v = *reinterpret_cast<const uint4*>(p.codes + lrow * M + 16 * part);
+            if (j < kg && star_nb_ok(p, i, j, id)) v = *reinterpret_cast<const uint4*>(p.codes + lrow * M + 16 * part);
             uint32_t* dst = reinterpret_cast<uint32_t*>(lcodes + j * MS + 16 * part);
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
         }
@@ -413,8 +424,8 @@ __global__ __launch_bounds__(512, 2) void star_attn_sweep_kernel(StarAttnParams 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j0 = 32 * wave + 4 * g + r, j1 = j0 + 16;
-                sc[n16 * SCS + j0] = (j0 < kg && ids[j0] >= 0) ? acc0[r] : -INFINITY;
-                sc[n16 * SCS + j1] = (j1 < kg && ids[j1] >= 0) ? acc1[r] : -INFINITY;
+                sc[n16 * SCS + j0] = (j0 < kg && star_nb_ok(p, i, j0, ids[j0])) ? acc0[r] : -INFINITY;
+                sc[n16 * SCS + j1] = (j1 < kg && star_nb_ok(p, i, j1, ids[j1])) ? acc1[r] : -INFINITY;
             }
         }
     }

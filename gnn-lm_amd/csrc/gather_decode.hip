@@ -228,9 +228,12 @@ int pq_encode(const float* x, int64_t ldx, const float* cen, const float* norm2,
 }
 
 int gather_decode(const GatherParams& p, hipStream_t stream) {
-    GNNLM_REQUIRE(p.codes && (p.direct ? p.in_valid != nullptr : p.ids != nullptr), "gather_decode: null codes/ids");
-    GNNLM_REQUIRE(p.M > 0 && p.dsub > 0 && p.dsub % 4 == 0, "gather_decode: dsub must be a multiple of 4");
     GNNLM_REQUIRE(p.left >= 0 && p.right >= 0 && p.n_groups >= 0, "gather_decode: bad shape");
+    // an empty request (a rank of the sharded exchange that receives no rows) or an empty shard is legal and must
+    // not fail on the null pointers torch hands out for empty tensors: its peers are already inside the next collective
+    if (p.n_groups == 0) return OK;
+    GNNLM_REQUIRE((p.codes || p.n_local == 0) && (p.direct ? p.in_valid != nullptr : p.ids != nullptr), "gather_decode: null codes/ids");
+    GNNLM_REQUIRE(p.M > 0 && p.dsub > 0 && p.dsub % 4 == 0, "gather_decode: dsub must be a multiple of 4");
     GNNLM_REQUIRE(!p.out_x || (p.centroids && p.ld_x % 4 == 0 && (uintptr_t)p.out_x % 16 == 0),
                   "gather_decode: out_x needs centroids, 16-byte alignment and ld % 4 == 0");
     GNNLM_REQUIRE(p.vals_itemsize == 2 || p.vals_itemsize == 4, "gather_decode: vals must be int16 or int32");

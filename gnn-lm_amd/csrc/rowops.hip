@@ -213,8 +213,10 @@ __global__ __launch_bounds__(256) void knn_interp_kernel(KnnInterpParams p, floa
         } else {
             // numpy indexing semantics of vals[knns] (knn_model.py:198): -1 wraps to the last row
             const int64_t row = (id < 0 ? id + p.n_store : id) - p.row0;
-            val = p.vals_itemsize == 2 ? (int64_t) reinterpret_cast<const int16_t*>(p.vals)[row]
-                                       : (int64_t) reinterpret_cast<const int32_t*>(p.vals)[row];
+            val = -1;                                       // rows outside the shard / the store never match a target
+            if (row >= 0 && row < p.n_local)
+                val = p.vals_itemsize == 2 ? (int64_t) reinterpret_cast<const int16_t*>(p.vals)[row]
+                                           : (int64_t) reinterpret_cast<const int32_t*>(p.vals)[row];
         }
         const bool hit = val == tgt;                                             // :211
         den += e;
@@ -264,8 +266,9 @@ __global__ __launch_bounds__(256) void knn_interp_regs_kernel(KnnInterpParams p,
                 val[t] = p.knn_vals[i * p.k + j];
             } else {
                 const int64_t row = (id[t] < 0 ? id[t] + p.n_store : id[t]) - p.row0;
-                val[t] = p.vals_itemsize == 2 ? (int64_t) reinterpret_cast<const int16_t*>(p.vals)[row]
-                                              : (int64_t) reinterpret_cast<const int32_t*>(p.vals)[row];
+                if (row >= 0 && row < p.n_local)
+                    val[t] = p.vals_itemsize == 2 ? (int64_t) reinterpret_cast<const int16_t*>(p.vals)[row]
+                                                  : (int64_t) reinterpret_cast<const int32_t*>(p.vals)[row];
             }
         }
     }
@@ -386,6 +389,7 @@ int tail_combine(const float* tail_picked, const float* tail_lse, const int32_t*
 int knn_interp(const KnnInterpParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(p.lm_logp && p.sims && p.ids && p.targets && p.out_logp, "knn_interp: null operand");
     GNNLM_REQUIRE(p.knn_vals || p.vals, "knn_interp: need vals or pre-fetched knn_vals");
+    GNNLM_REQUIRE(p.knn_vals || (p.n_local > 0 && p.n_store > 0 && p.row0 >= 0), "knn_interp: vals needs n_store / row0 / n_local");
     GNNLM_REQUIRE(p.k > 0 && p.temperature > 0.f && p.lmbda > 0.0 && p.lmbda < 1.0, "knn_interp: need k>0, t>0, 0<lmbda<1");
     GNNLM_REQUIRE(p.vals_itemsize == 2 || p.vals_itemsize == 4, "knn_interp: vals must be int16 or int32");
     if (p.n == 0) return OK;

@@ -131,6 +131,13 @@ def main(args):
         raise NotImplementedError("--save-knnlm-dstore needs the base LM forward (SURVEY.md 8f.4)")
     if args.knnlm and args.save_knnlm_dstore:
         raise ValueError("Cannot use knnlm while trying to build the datastore!")
+    if args.context_window > 0:
+        # LMContextWindowDataset (fairseq/data/lm_context_window_dataset.py) prepends context tokens and scores only the
+        # new ones; shrinking the block without the prefix would silently give another ppl
+        raise NotImplementedError("--context-window > 0 is not built (the GNN-LM recipes use --gcn-context-window)")
+    if args.gen_subset == "train" and args.invalid_neighbor_context > 0:
+        raise NotImplementedError("--gen-subset train with --invalid-neighbor-context > 0 (neighbours inside the token's "
+                                  "own context are dropped, token_block_dataset.py:361-368) is not built")
     if args.fp16:
         logger.warning("--fp16 ignored: the HIP path computes in float32")
     device = torch.device(args.device)

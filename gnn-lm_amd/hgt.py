@@ -179,8 +179,16 @@ class HGT(nn.Module):
 
     def prepare(self, store: CodeStore, device):
         """Fold the weights for ``store``'s codec and build the C descriptors (cached)."""
-        key = (id(store), str(device))
+        # The folded weights depend on the parameters and on the store's codec (A / b are folded into layer 0):
+        # key on their storage + in-place version counters, and keep the store alive inside the cache entry so
+        # that neither an id() reuse nor an in-place edit can serve stale weights.  Table pointers (codes / vals)
+        # are NOT part of the key: forward() refreshes them on every call.
+        ver = lambda t: None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
+        key = (str(device), ver(store.centroids), ver(store.A), ver(store.b),
+               tuple(ver(p) for p in self.parameters()))
         if self._prepared is not None and self._prepared["key"] == key:
+            self._bind_store(self._prepared["model"], store)
+            self._prepared["store"] = store
             return self._prepared
         layers, codec = prepare_hgt_weights(self.state_dict(), self.n_layers, self.n_heads, store, device)
         arr = (_lib.gnnlm_hgt_layer_t * self.n_layers)()
@@ -198,13 +206,22 @@ class HGT(nn.Module):
             m.opq_at = codec["opq_at"].data_ptr()
         if "opq_nba" in codec:
             m.opq_nba = codec["opq_nba"].data_ptr()
-        m.codes = store.codes.data_ptr()
-        if store.vals is not None:
-            m.vals, m.vals_itemsize = store.vals.data_ptr(), store.vals.element_size()
-        m.n_store, m.row0, m.n_local = store.n_store, store.row0, store.codes.shape[0]
+        self._bind_store(m, store)
         m.layers = ctypes.cast(arr, ctypes.c_void_p)
-        self._prepared = {"key": key, "model": m, "layers_arr": arr, "tensors": (layers, codec), "ws": None}
+        self._prepared = {"key": key, "model": m, "layers_arr": arr, "tensors": (layers, codec), "ws": None,
+                          "store": store}
         return self._prepared
+
+    @staticmethod
+    def _bind_store(m, store):
+        """(Re)point the descriptor at the store's tables: cheap, done on every forward."""
+        m.codes = store.codes.data_ptr()
+        m.vals, m.vals_itemsize = (store.vals.data_ptr(), store.vals.element_size()) if store.vals is not None else (None, 4)
+        m.n_store, m.row0, m.n_local = store.n_store, store.row0, store.codes.shape[0]
+
+    def invalidate(self):
+        """Drop the prepared (folded) weights, e.g. after swapping parameter tensors by hand."""
+        self._prepared = None
 
     def forward(self, G: NeighborGraph, features: Dict[str, torch.Tensor] = None, etypes=None,
                 incremental_state=None, return_ntgt: bool = False):

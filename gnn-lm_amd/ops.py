@@ -18,9 +18,17 @@ def _dev(*ts):
             raise _lib.GnnlmError("gnnlm_amd kernels need contiguous device (HIP) tensors; there is no CPU fallback")
 
 
-def _f32(t):
-    assert t.dtype == torch.float32, f"expected float32, got {t.dtype}"
-    return t
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError(f"expected float32, got {t.dtype}")
+    return ts[0]
+
+
+def _dtype(t, dt, what):
+    """The C ABI reinterprets raw pointers: a wrong dtype must fail here, not be silently re-read."""
+    if t is not None and t.dtype != dt:
+        raise TypeError(f"{what}: expected {dt}, got {t.dtype}")
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
@@ -31,7 +39,8 @@ def gemm_nt(A, W, bias=None, residual=None, alpha=1.0, out=None, bias_mode=1, ga
     """C = alpha * A @ W.T (+ gate*bias) (+ residual).  A [M,K] (row stride may exceed K), W [N,K].
     a_rows: logical row r reads A[a_rows[r]] (< 0: zero row); c_rows: row r is stored to (and its residual
     read from) row c_rows[r] of ``out`` (which must then be given)."""
-    _f32(A), _f32(W)
+    _f32(A, W, bias, residual, gate, out)
+    _dtype(a_rows, torch.int32, "a_rows"), _dtype(m_dev, torch.int32, "m_dev")
     _dev(A, W, bias, residual, gate, a_rows, m_dev, out, c_rows)
     M, K = A.shape
     N = W.shape[0]
@@ -66,7 +75,8 @@ def gemm_nt(A, W, bias=None, residual=None, alpha=1.0, out=None, bias_mode=1, ga
 def gemm_lse(A, W, pick=None, alpha=1.0, m_dev=None, precision=0):
     """lse[r] = logsumexp_n(alpha * A[r] . W[n]) and picked[r] = alpha * A[r] . W[pick[r]], without
     materialising the [M, N] logits (LSE epilogue of the GEMM + gnnlm_lse_reduce)."""
-    _f32(A), _f32(W)
+    _f32(A, W)
+    _dtype(m_dev, torch.int32, "m_dev")
     _dev(A, W, pick, m_dev)
     M, K = A.shape
     N = W.shape[0]
@@ -145,8 +155,13 @@ def pq_lookup_direct(codes, centroids):
     return x
 
 
-def star_attn(U, ids, codes=None, centroids=None, row0=0, X=None, x_group_stride=1, codes_direct=0):
-    _dev(U, ids, codes, centroids, X)
+def star_attn(U, ids, codes=None, centroids=None, row0=0, X=None, x_group_stride=1, codes_direct=0, n_store=None,
+              nb_valid=None, nb_valid_stride=1):
+    """n_store: rows of the whole store (ids >= n_store are not neighbours; default: the rows of ``codes``);
+    nb_valid (uint8): validity byte of neighbour (i, j) at [(i*kg + j) * nb_valid_stride]."""
+    _dev(U, ids, codes, centroids, X, nb_valid)
+    _f32(U, centroids, X)
+    _dtype(ids, torch.int64, "ids"), _dtype(codes, torch.uint8, "codes"), _dtype(nb_valid, torch.uint8, "nb_valid")
     T, H, D = U.shape
     kg = ids.shape[1]
     Z = torch.empty_like(U)
@@ -159,9 +174,14 @@ def star_attn(U, ids, codes=None, centroids=None, row0=0, X=None, x_group_stride
         a.M, a.dsub = centroids.shape[0], centroids.shape[2]
         a.centroids = centroids.data_ptr()
         a.codes_direct = codes_direct
+        if n_store is None and not codes_direct:
+            n_store = row0 + codes.shape[0]
     else:
         a.X, a.ldx, a.x_group_stride = X.data_ptr(), X.stride(0), x_group_stride
     a.Z, a.has_nb = Z.data_ptr(), has_nb.data_ptr()
+    a.n_store = n_store or 0
+    if nb_valid is not None:
+        a.nb_valid, a.nb_valid_stride = nb_valid.data_ptr(), nb_valid_stride
     call_desc("gnnlm_star_attn", a)
     return Z, has_nb
 
@@ -225,6 +245,10 @@ def row_lse_pick(logits, pick=None):
 
 def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_store=None, row0=0, knn_vals=None):
     _dev(lm_logp, sims, ids, targets, vals, knn_vals)
+    _f32(lm_logp, sims)
+    _dtype(ids, torch.int64, "ids"), _dtype(targets, torch.int64, "targets")
+    if vals is not None and vals.dtype not in (torch.int16, torch.int32):
+        raise TypeError(f"vals: expected int16 / int32, got {vals.dtype}")
     n, k = sims.shape
     dev = sims.device
     out = torch.empty(n, device=dev, dtype=torch.float32)

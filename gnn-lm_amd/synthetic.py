@@ -24,6 +24,26 @@ def zipf_tokens(rs, vocab, size):
     return np.minimum((np.exp(u * h) - 1.0).astype(np.int64), vocab - 1)
 
 
+def zipf_dev(n, vocab, gen, dev):
+    """Zipf(1.0) tokens generated on the device (the 103 M-row label table of the full-size workloads)."""
+    u = torch.rand(n, generator=gen, device=dev, dtype=torch.float64)
+    return torch.clamp((torch.exp(u * math.log(vocab + 1.0)) - 1.0).to(torch.int64), max=vocab - 1)
+
+
+def device_codes(n_local, M, dev, seed):
+    """uint8 i.i.d. uniform code table [n_local, M] generated on the device in 4 Mi-row pieces (WikiText-103:
+    103,227,021 x 128 B = 13.2 GB, too large to ship from the host): bench.py and the full-size parity tests
+    build the store with this one function, so they index the same bytes."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    codes = torch.empty(n_local, M, dtype=torch.uint8, device=dev)
+    step = 1 << 22
+    for s in range(0, n_local, step):
+        e = min(n_local, s + step)
+        codes[s:e] = torch.randint(0, 256, (e - s, M), generator=gen, device=dev, dtype=torch.uint8)
+    return codes
+
+
 def make_codec(rs, M, dsub, d, opq=True):
     cen = (rs.randn(M, 256, dsub) * 0.5).astype(np.float32)
     dpq = M * dsub

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNLM_ABI_VERSION 1
+#define GNNLM_ABI_VERSION 2
 #define GNNLM_OK 0
 #define GNNLM_E_INVALID (-22)
 #define GNNLM_E_NOMEM (-12)
@@ -134,6 +134,13 @@ typedef struct gnnlm_star_attn {
     float* Z;                  /* [T, H, D] */
     float* has_nb;             /* optional [T]: 1.0 if >= 1 valid neighbour */
     const int32_t* codes_index;   /* optional with codes_direct: row of (i,j) = codes_index[(i*kg+j)*codes_direct] */
+    /* Neighbour validity (ABI 2).  (i,j) takes part in the softmax iff ids[i,j] >= 0, ids[i,j] < n_store (when
+     * n_store > 0), the row lies in the shard [row0, row0+n_local) (PQ source read from the store itself) and
+     * nb_valid[(i*kg+j)*nb_valid_stride] != 0 (when nb_valid is given: the validity bytes of an exchange / of
+     * gnnlm_pq_gather_decode) -- the same rule as gnnlm_pq_gather_decode, so the star edges and the ntgt states
+     * always agree.  The reference raises IndexError for rows >= n_store (token_block_dataset.py:370). */
+    int64_t n_store;
+    const uint8_t* nb_valid;  int64_t nb_valid_stride;
 } gnnlm_star_attn_t;
 int gnnlm_star_attn(const gnnlm_star_attn_t* desc, void* stream);
 
@@ -275,7 +282,8 @@ int gnnlm_bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t r
 
 /* ------------------------------------------------------------------------------------------------
  * Opt-in live timing (bench.py's roofline): while a profile is open every launch of the selected
- * kernels is bracketed by HIP events on its own stream.  Not thread-safe; one profile at a time.
+ * kernels is bracketed by HIP events on its own stream.  One profile at a time; launches from several host threads
+ * may be recorded into it (records and pools are mutex-guarded).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct gnnlm_profile_entry {
     int32_t kernel_id;
