@@ -21,15 +21,6 @@ namespace {
 
 constexpr int HB = 8;   // heads processed per pass of star_attn
 
-// Neighbour (i, j) takes part in the star softmax iff its id is a row of the store, the row is present on this
-// shard (PQ source read from the store) and the caller's validity byte (exchange / gather_decode) says so: the
-// rule of gather_decode_kernel, so layer-0 star attention and the ntgt states can never disagree.
-__device__ __forceinline__ bool star_nb_ok(const StarAttnParams& p, int i, int j, int64_t id) {
-    bool ok = id >= 0 && (p.n_store <= 0 || id < p.n_store);
-    if (p.codes && !p.codes_direct) ok = ok && id - p.row0 >= 0 && id - p.row0 < p.n_local;
-    if (ok && p.nb_valid) ok = p.nb_valid[((int64_t)i * p.kg + j) * p.nb_valid_stride] != 0;
-    return ok;
-}
 
 // Sum 8 per-lane partials over the 64 lanes with a transposing butterfly: 10 shuffles instead of 48.
 // On return lane 8*h holds the total of v[h].
@@ -770,6 +761,11 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(shmem <= 160 * 1024, "star_attn: kg too large for LDS");
     const int nq = p.D / 4;
     const double rows = (double)p.T * p.kg;
+    if (star_attn_tab_eligible(p) && !getenv("GNNLM_STAR_SWEEP") && !getenv("GNNLM_STAR_GENERIC")) {
+        // table-resident formulation (star_tab.hip): the default for the PQ source with k_g <= 128
+        ProfScope prof(K_STAR, stream, 4.0 * rows * p.H * p.D, rows * (8.0 + p.M) + 8.0 * p.T * p.H * p.D);
+        return star_attn_tab(p, stream);
+    }
     if (p.codes && p.kg <= 128 && (p.dsub == 4 || p.dsub == 8) && p.M % 16 == 0 && p.D % 32 == 0 &&
         (uintptr_t)p.codes % 16 == 0 && !getenv("GNNLM_STAR_GENERIC")) {
         ProfScope prof(K_STAR, stream, 4.0 * rows * p.H * p.D, rows * (8.0 + p.M) + 8.0 * p.T * p.H * p.D);

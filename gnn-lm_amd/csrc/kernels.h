@@ -33,6 +33,25 @@ int pq_encode(const float* x, int64_t ldx, const float* cen, const float* norm2,
 int bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t per, int world, int self, int64_t* counts,
                 int64_t* cursor, int64_t* send_rows, int32_t* inv, hipStream_t stream);
 int star_attn(const StarAttnParams& p, hipStream_t stream);
+// table-resident formulation for the PQ source, k_g <= 128 (star_tab.hip); star_attn dispatches to it
+bool star_attn_tab_eligible(const StarAttnParams& p);
+int star_attn_tab(const StarAttnParams& p, hipStream_t stream);
+
+// Neighbour (i, j) takes part in the star softmax iff its id is a row of the store, the row is present on this
+// shard (PQ source read from the store) and the caller's validity byte (exchange / gather_decode) says so: the
+// rule of gather_decode_kernel, so layer-0 star attention and the ntgt states can never disagree.
+__device__ __forceinline__ bool star_nb_ok(const StarAttnParams& p, int i, int j, int64_t id) {
+    bool ok = id >= 0 && (p.n_store <= 0 || id < p.n_store);
+    if (p.codes && !p.codes_direct) ok = ok && id - p.row0 >= 0 && id - p.row0 < p.n_local;
+    if (ok && p.nb_valid) ok = p.nb_valid[((int64_t)i * p.kg + j) * p.nb_valid_stride] != 0;
+    return ok;
+}
+// row of the code table that holds neighbour (i, j) (store rows, or the slots of an exchange)
+__device__ __forceinline__ int64_t star_code_row(const StarAttnParams& p, int i, int j, int64_t id) {
+    if (!p.codes_direct) return id - p.row0;
+    const int64_t s = ((int64_t)i * p.kg + j) * p.codes_direct;
+    return p.codes_index ? (int64_t)p.codes_index[s] : s;
+}
 int chain_attn(const ChainAttnParams& p, hipStream_t stream);
 
 // rows of S[b, h, w, :T] -> causal softmax (u <= w, and w-u < max_ctx if max_ctx > 0), in place

@@ -26,11 +26,11 @@ def gather_block(neighbor_idxs, codes, vals, n_store, left, right, reference_loo
     if reference_loop:
         g = og.build_graph(neighbor_idxs, np.zeros(T, np.int64), n_store, left, right)
         rows = g["ntgt_offsets"]
-        return g, np.asarray(codes)[rows], np.asarray(vals)[rows]
+        return g, codes[rows], vals[rows]
     g = og.build_graph(neighbor_idxs, np.zeros(T, np.int64), n_store, left, right)
     rows, valid = og.slot_layout(neighbor_idxs, n_store, left, right)
     flat = rows[valid]
-    return g, np.asarray(codes)[flat], np.asarray(vals)[flat]
+    return g, codes[flat], vals[flat]          # codes / vals: anything indexable by global rows (array, memmap, HostRows)
 
 
 def hgt_block(sd, n_layers, n_heads, tgt_feats, ntgt_codes, graph, centroids, A, b,

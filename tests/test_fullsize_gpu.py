@@ -25,6 +25,7 @@ from oracle import graph as og
 from oracle import hgt as ohgt
 from oracle import knn as oknn
 from oracle import pq as opq
+from oracle.hostrows import HostRows
 
 N_FULL = 103_227_021
 M, DSUB, D, H = 128, 8, 1024, 8
@@ -35,23 +36,6 @@ VOCAB = 267_744
 def dev():
     assert torch.cuda.is_available()
     return torch.device("cuda:0")
-
-
-class HostRows:
-    """Host copy of a subset of the device code table, addressable by GLOBAL row like the full array
-    (``codes[rows]`` is all the oracle ever does with it)."""
-
-    def __init__(self, codes_dev, rows):
-        self.rows = np.unique(np.asarray(rows, dtype=np.int64))
-        idx = torch.from_numpy(self.rows).to(codes_dev.device)
-        self.data = codes_dev.index_select(0, idx).cpu().numpy()
-        self.shape = (codes_dev.shape[0], codes_dev.shape[1])
-
-    def __getitem__(self, rows):
-        rows = np.asarray(rows, dtype=np.int64)
-        pos = np.searchsorted(self.rows, rows)
-        assert np.array_equal(self.rows[np.minimum(pos, len(self.rows) - 1)], rows), "row was not fetched to the host"
-        return self.data[pos]
 
 
 @pytest.fixture(scope="module")
