@@ -53,6 +53,9 @@ def parse():
                     help="HIP streams per GPU: the step's blocks are split into this many independent sub-batches "
                          "enqueued on separate streams (HBM/L2-bound and MFMA-bound kernels of different sub-batches overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the first block before timing")
+    ap.add_argument("--no-extras", dest="extras", action="store_false",
+                    help="skip the recipe_L3 and driver_path sub-benchmarks (run after the timed region, N = 1 only)")
     ap.add_argument("--cpu-tokens", type=int, default=384)
     ap.add_argument("--small", action="store_true", help="tiny shapes (plumbing check only)")
     ap.add_argument("--graph", action="store_true",
@@ -126,28 +129,237 @@ def make_batches(args, dev, rank, d, vocab):
     return out
 
 
+def _drop_page_cache(path):
+    """Best effort, no privileges needed: ask the kernel to forget the clean pages of one file."""
+    try:
+        fd = os.open(path, os.O_RDONLY)
+        os.fsync(fd)
+        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        os.close(fd)
+    except OSError:
+        pass
+
+
 def cpu_baseline(args, cpu_model):
-    """The reference algorithm as written (oracle = test infrastructure, here the timed CPU baseline):
-    per-row graph expansion, PQ decode, un-elided HGT, adaptive softmax, kNN prob, interpolation."""
+    """The reference algorithm as written, timed stage by stage on the host (the oracle is
+    test infrastructure, here it is the thing timed -- never the thing shipped):
+      (1) np.memmap row gathers from files on local disk (neighbour ids, PQ codes, labels, fp16 features;
+          cold = page cache dropped with posix_fadvise, warm = second read),
+      (2) neighbour expansion: the reference's per-row Python loop (token_block_dataset.py:354-400) and its vectorised
+          numpy equivalent,
+      (3) PQ decode, (4) HGT x L un-elided in torch-CPU fp32, (5) adaptive softmax, (6) kNN prob + interpolation
+    on every host core (`--cpu-tokens` tokens) and on ONE core (a 16-token sample; ~6 GFLOP per token and layer)."""
+    import shutil
+    import tempfile
     from gnnlm_amd.synthetic import make_block, zipf_tokens
-    from oracle import pipeline
+    from oracle import adaptive_softmax as oas
+    from oracle import graph as og
+    from oracle import hgt as ohgt
+    from oracle import knn as oknn
+    from oracle import pq as opq
     rs = np.random.RandomState(7)
     n_host = min(args.n_store, 2_000_000)
-    M = cpu_model["M"]
-    codes = rs.randint(0, 256, size=(n_host, M)).astype(np.uint8)
-    vals = zipf_tokens(rs, cpu_model["vocab"], n_host).astype(np.int32)
-    Tc = args.cpu_tokens
-    blk = make_block(rs, n_host, vals, cpu_model["vocab"], cpu_model["d"], Tc, args.gcn_k, args.k)
-    prob = {"block": blk, "sd": cpu_model["sd"], "n_layers": args.layers, "n_heads": cpu_model["H"],
-            "cen": cpu_model["cen"], "A": cpu_model["A"], "b": cpu_model["b"], "codes": codes, "vals": vals,
-            "n_store": n_host, "left": 2, "right": 2, "asm": cpu_model["asm"]}
-    cores = torch.get_num_threads()
+    M, d, V = cpu_model["M"], cpu_model["d"], cpu_model["vocab"]
+    Tc, kg, k, L = args.cpu_tokens, args.gcn_k, args.k, args.layers
+    tmp = tempfile.mkdtemp(prefix="gnnlm_cpu_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        vals_np = zipf_tokens(rs, V, n_host).astype(np.int32)
+        blk = make_block(rs, n_host, vals_np, V, d, Tc, kg, k)
+        files = {"codes": (rs.randint(0, 256, size=(n_host, M)).astype(np.uint8), np.uint8, (n_host, M)),
+                 "vals": (vals_np, np.int32, (n_host,)),
+                 "nbrs": (blk["ids"], np.int64, (Tc, kg)),
+                 "feats": (blk["tgt_feats"], np.float16, (Tc, d))}
+        for nm, (arr, _, _) in files.items():
+            arr.tofile(os.path.join(tmp, nm))
+        mm = {nm: np.memmap(os.path.join(tmp, nm), mode="r", dtype=dt, shape=sh) for nm, (_, dt, sh) in files.items()}
+        del files
+        sd = {k_: v.float() for k_, v in cpu_model["sd"].items()}
+        asm = cpu_model["asm"]
+        all_cores = torch.get_num_threads()
+
+        def run(n_tok, cores, cold):
+            torch.set_num_threads(cores)
+            ms = {}
+            clock = lambda: time.perf_counter()
+            if cold:
+                for nm in mm:
+                    _drop_page_cache(os.path.join(tmp, nm))
+            t0 = clock()
+            nb = np.array(mm["nbrs"][:n_tok])
+            feats = np.array(mm["feats"][:n_tok]).astype(np.float32)                      # token_block_dataset.py:327-329
+            rows, valid = og.slot_layout(nb, n_host, 2, 2)
+            flat = rows[valid]
+            ncodes = np.array(mm["codes"][flat])                                          # :370-371,391-393 (row gathers)
+            _ = np.array(mm["vals"][flat])                                                # neighbor_tokens[offset] (:410)
+            ms["gather_memmap_" + ("cold" if cold else "warm")] = (clock() - t0) * 1e3
+            t0 = clock()
+            graph = og.build_graph(nb, np.zeros(n_tok, np.int64), n_host, 2, 2)            # per-row loop, as written
+            ms["expand_reference_loop"] = (clock() - t0) * 1e3
+            t0 = clock()
+            og.slot_layout(nb, n_host, 2, 2)
+            ms["expand_vectorised"] = (clock() - t0) * 1e3
+            t0 = clock()
+            ntgt = opq.pq_decode(ncodes, cpu_model["cen"], cpu_model["A"], cpu_model["b"])
+            ms["pq_decode"] = (clock() - t0) * 1e3
+            t0 = clock()
+            h = ohgt.hgt_forward(sd, L, cpu_model["H"], {"tgt": torch.from_numpy(feats), "ntgt": torch.from_numpy(ntgt)}, graph)
+            ms["hgt"] = (clock() - t0) * 1e3
+            t0 = clock()
+            tgt = torch.as_tensor(blk["targets"][:n_tok]).long()
+            lm = oas.target_log_prob(h["tgt"], tgt, asm).float()
+            ms["adaptive_softmax"] = (clock() - t0) * 1e3
+            t0 = clock()
+            pk, _ = oknn.knn_target_prob(blk["knn_sims"][:n_tok], blk["knn_ids"][:n_tok], mm["vals"], tgt, args.temperature)
+            oknn.combine_knn_and_vocab_probs(pk, lm, args.lmbda)
+            ms["knn_interp"] = (clock() - t0) * 1e3
+            total = sum(v for k_, v in ms.items() if k_ != "expand_vectorised")           # the path as written
+            return {"tokens": n_tok, "cores": cores, "tokens_per_s": n_tok / (total / 1e3),
+                    "stage_ms": {k_: round(v, 2) for k_, v in ms.items()}, "seconds": round(total / 1e3, 2)}
+
+        run(min(Tc, 8), all_cores, cold=False)                # untimed: first-call costs of the torch-CPU operators
+        full = run(Tc, all_cores, cold=True)
+        warm = run(min(Tc, 64), all_cores, cold=False)
+        one = run(min(Tc, 16), 1, cold=False)
+        torch.set_num_threads(all_cores)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": round(full["tokens_per_s"], 2), "unit": "tokens/s", "cores": all_cores, "kind": "port",
+            "sample": f"{Tc} tokens of one block, k_g={kg}, l=r=2, L={L}, kNN k={k}, d={d}, {n_host}-row tables as np.memmap "
+                      f"files on local disk (cold page cache), reference-style expansion loop, torch-CPU fp32, {full['seconds']} s",
+            "all_cores": full, "all_cores_warm": warm, "one_core": one}
+
+
+def verify_block(eng, batch, args, cpu_model, n_tok):
+    """Parity gate of the bench itself: the first `n_tok` tokens of the first pooled block (causal attention makes a
+    prefix independent of the rest) through the oracle -- the reference algorithm as written, torch-CPU float32 --
+    against what the timed engine returns for them.  The rows the block touches are pulled from the device store."""
+    from oracle import graph as og
+    from oracle import pipeline
+    from oracle.hostrows import HostRows
+    st = eng.store
+    out = eng.score(batch, args.lmbda, args.temperature)
+    got = out["logp"][:n_tok].double().cpu().numpy()
+    nb = batch.ids[:n_tok].cpu().numpy()
+    rows, valid = og.slot_layout(nb, st.n_store, eng.left, eng.right)
+    model = {"sd": {k_: v.detach().float().cpu() for k_, v in cpu_model["sd"].items()}, "n_layers": args.layers,
+             "n_heads": cpu_model["H"], "centroids": cpu_model["cen"], "A": cpu_model["A"], "b": cpu_model["b"],
+             "codes": HostRows(st.codes, rows[valid]), "vals": st.vals.cpu().numpy(), "n_store": st.n_store,
+             "left": eng.left, "right": eng.right, "asm": cpu_model["asm"]}
+    one = {"neighbor_idxs": nb, "tgt_feats": batch.tgt_feats[:n_tok].cpu().numpy(), "targets": batch.targets[:n_tok].cpu().numpy(),
+           "knn_sims": batch.knn_sims[:n_tok].cpu().numpy(), "knn_ids": batch.knn_ids[:n_tok].cpu().numpy()}
     t0 = time.perf_counter()
-    pipeline.run_problem(prob, args.lmbda, args.temperature)
+    ref = pipeline.eval_block(one, model, args.lmbda, args.temperature)["logp"].double().numpy()
+    err = float(np.abs(got - ref).max())
+    res = {"tokens": n_tok, "max_abs_dlogp_vs_oracle": err, "score_sum_hip": float(got.sum()), "score_sum_oracle": float(ref.sum()),
+           "tolerance": 1e-4, "oracle_seconds": round(time.perf_counter() - t0, 1)}
+    assert err < 1e-4, f"bench parity gate failed: {res}"
+    return res
+
+
+def recipe_l3(args, eng1, batches, dev):
+    """The shipped recipe (`--graph_layer 3`, hgt_lm_wiki103_reproduce.sh:56) on the same store: 4 blocks per step."""
+    from gnnlm_amd import _lib, ops
+    from gnnlm_amd.engine import BlockBatch, GnnLmEngine
+    from gnnlm_amd.hgt import HGT
+    torch.manual_seed(4321)
+    d, H = eng1.hgt.hidden_dim, eng1.hgt.n_heads
+    hgt = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=3, n_heads=H)
+    hgt.gemm_precision = eng1.hgt.gemm_precision
+    eng = GnnLmEngine(hgt, eng1.asm, eng1.store, eng1.left, eng1.right)
+    nb, T = 4, args.tokens_per_sample
+    b0 = batches[0]
+    cut = lambda t: t[: nb * T].contiguous()
+    batch = BlockBatch(ids=cut(b0.ids), tgt_feats=cut(b0.tgt_feats), targets=cut(b0.targets), n_blocks=nb, T=T,
+                       knn_sims=cut(b0.knn_sims), knn_ids=cut(b0.knn_ids))
+    acc = torch.zeros(1, device=dev, dtype=torch.float64)
+    step = lambda: ops.masked_sum_f64(eng.score(batch, args.lmbda, args.temperature)["logp"], None, acc)
+    step()
+    torch.cuda.synchronize()
+    _lib.profile_begin()
+    step()
+    torch.cuda.synchronize()
+    kern = _lib.profile_end()
+    dominant = max(kern, key=lambda k_: kern[k_]["total_ms"])
+    steps = 5
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"value": Tc / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"1 block of {Tc} tokens, k_g={args.gcn_k}, l=r=2, L={args.layers}, kNN k={args.k}, d={cpu_model['d']}, "
-                      f"{n_host}-row host table, torch-CPU fp32, {dt:.1f} s"}
+    e = kern[dominant]
+    return {"hgt_layers": 3, "blocks_per_step": nb, "steps": steps, "tokens_per_s": round(steps * nb * T / dt, 1),
+            "ms_per_step": round(dt / steps * 1e3, 3), "dominant_kernel": dominant,
+            "dominant_share_of_step": round(e["total_ms"] / sum(v["total_ms"] for v in kern.values()), 3),
+            "dominant_TFLOPs": round(e["flops"] / (e["total_ms"] / 1e3) / 1e12, 2) if e["flops"] else None,
+            "dominant_frac_of_f32_mfma_peak": round(e["flops"] / (e["total_ms"] / 1e3) / 1e12 / PEAK["mfma_f32_tflops"], 4) if e["flops"] else None}
+
+
+def driver_path(args, eng, batches, dev):
+    """tokens/s of the DROP-IN path: `eval_lm.main` -> `SequenceScorer.generate` -> hypotheses -> score sum, the
+    reference's own loop and timer (fairseq_cli/eval_lm.py:208-331: `seconds` = time inside generate, `wall` = the
+    whole loop), one 256-token block per batch as in the recipe (--max-tokens 256) and `--max-tokens` = the bench's
+    batch.  The tables are the bench's HBM-resident ones (the driver normally uploads them from the data directory)."""
+    from gnnlm_amd import eval_lm
+    from gnnlm_amd.model import GnnLmModel
+    st = eng.store
+    T, nblk = args.tokens_per_sample, min(args.blocks, 32)
+    b0 = batches[0]
+    n = nblk * T
+    model = GnnLmModel(eng.hgt, eng.asm, None)
+    model.make_store = lambda codes, n_store, device: st                      # resident store, codec already folded
+
+    class Replay:                              # search results given (SURVEY 8d): faiss contract on device tensors
+        def __init__(self):
+            self.pos = 0
+
+        def search_device(self, q, kk):
+            m = q.shape[0]
+            sl = slice(self.pos, self.pos + m)
+            self.pos = (self.pos + m) % n
+            return b0.knn_sims[sl, :kk], b0.knn_ids[sl, :kk]
+
+    class Knn:                                 # KNNModel.interpolate contract over the resident label table
+        def __init__(self):
+            self.index = Replay()
+
+        def interpolate(self, queries, targets, lm_logp, t, lmbda, k=0):
+            from gnnlm_amd import ops
+            sims, knns = self.index.search_device(queries, args.k)
+            return ops.knn_interp(lm_logp.contiguous(), sims.contiguous(), knns.contiguous(), targets.long().contiguous(), t,
+                                  lmbda, vals=st.vals, n_store=st.n_store)
+
+    tabs = {"n_tok": n, "d": eng.hgt.hidden_dim, "vocab": None, "n_store": st.n_store, "feats": b0.tgt_feats[:n],
+            "targets": b0.targets[:n].clamp(min=4), "nbrs": b0.ids[:n], "codes": st.codes}
+    out = {}
+    for name, max_tokens in (("one_block_per_batch", T), ("bench_batch", n)):
+        a = eval_lm.get_parser().parse_args(
+            ["-", "--path", "-", "--graph", "--use-precompute-feat", "--neighbor-context", "2", "--gcn-k", str(args.gcn_k),
+             "--tokens-per-sample", str(T), "--max-tokens", str(max_tokens), "--knnlm", "--k", str(args.k), "--lmbda",
+             str(args.lmbda), "--temperature", str(args.temperature), "--knn-keytype", "gcn_feat", "--softmax-batch",
+             str(n + 1), "--device", str(dev)])
+        a.knn_model = Knn()
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            eval_lm.main(a, tables=tabs, model=model)                          # warm-up
+            a.knn_model = Knn()
+            r = eval_lm.main(a, tables=tabs, model=model)
+        out[name] = {"tokens": r["tokens"], "tokens_per_s_generate_timer": round(r["tokens"] / r["seconds"], 1),
+                     "tokens_per_s_wall": round(r["tokens"] / r["wall_seconds"], 1), "blocks_per_batch": max_tokens // T}
+    return out
+
+
+def kernel_source_hash():
+    """Identity of the kernel sources a PMC profile belongs to (csrc/ + the C header)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "gnn-lm_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "gnnlm.h")]):
+        if os.path.isfile(f) and not f.endswith("Makefile"):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel):
@@ -155,16 +367,22 @@ def pmc_traffic(kernel):
     tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same
     command; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read
     from inside the timed run, so this is the launch-weighted average over the kernel's instantiations of
-    the last profiled build, or None when no profile is committed."""
+    the profiled build -- and ONLY if that build is this one: the file carries the hash of the kernel sources
+    it was measured on; a stale profile gives (None, reason) instead of a number that no longer applies."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
     except OSError:
-        return None
+        return None, "no profiles/pmc_traffic.json"
+    meta = t.pop("_meta", {})
+    if meta.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"profiles/pmc_traffic.json ({meta.get('profile', 'unstamped')}) was measured on other kernel sources"
     family = kernel[:-len("_kernel")] if kernel.endswith("_kernel") else kernel     # gemm_nt_f32_kernel + gemm_nt_f32_dma_kernel
     rows = [v for k, v in t.items() if k.startswith(family)]
     n = sum(v["launches"] for v in rows)
-    return round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n) if n else None
+    if not n:
+        return None, "kernel not in the profile"
+    return round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n), meta.get("profile")
 
 
 def main():
@@ -268,6 +486,10 @@ def main():
     # ---- warm-up; the first warm-up step after initialisation is profiled kernel by kernel
     step(0)
     barrier()
+    # ---- parity gate: the engine that is about to be timed against the oracle on a prefix of its first block
+    parity = None
+    if rank == 0 and fetcher is None and not args.no_parity:
+        parity = verify_block(eng, batches[0], args, cpu_model, min(args.tokens_per_sample, 256 if args.layers == 1 else 64))
     dlogp = None
     if args.precision != "f32" and fetcher is None:               # accuracy of the opt-in mode on one real batch
         got = eng.score(batches[0], args.lmbda, args.temperature)["logp"].clone()
@@ -285,7 +507,7 @@ def main():
     for i in range(max(0, args.warmup - 3)):
         step(i + 3)
     dominant = max(kern, key=lambda k_: kern[k_]["total_ms"])
-    names = [_lib.lib().gnnlm_kernel_name(i).decode() for i in range(10)]
+    names = [_lib.lib().gnnlm_kernel_name(i).decode() for i in range(12)]
     # ---- timed region: exactly K steps, the dominant kernel bracketed by HIP events on its stream
     if args.graph:
         capture_graphs()
@@ -311,6 +533,11 @@ def main():
         prof = _lib.profile_end()[dominant]
     for a in accs[1:]:
         acc += a
+    recipe = drv = None
+    if rank == 0 and world == 1 and fetcher is None and not args.small and args.extras:
+        if args.layers == 1 and args.precision == "f32":
+            recipe = recipe_l3(args, eng, batches, dev)
+        drv = driver_path(args, eng, batches, dev)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -339,7 +566,7 @@ def main():
 
     if rank == 0:
         r = roof(dominant, prof)
-        r["traffic"] = pmc_traffic(dominant)
+        r["traffic"], r["traffic_source"] = pmc_traffic(dominant)
         r["launches_per_step"] = prof["launches"] / args.steps
         res = {
             "metric": "eval tokens/sec on WikiText-103 (k=1024, GNN+KNN); test ppl match",
@@ -347,8 +574,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else f"f32 via {args.precision} split-bf16 MFMA", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: WikiText-103 full PQ datastore in HBM, k_g=128, "
-                                   "context 2+2, HGT 1 layer, kNN k=1024 (search results given), 256-token blocks",
+            "config": {"workload": f"BASELINE.json configs[1]: WikiText-103 full PQ datastore in HBM, k_g={args.gcn_k}, "
+                                   f"context 2+2, HGT {args.layers} layer{'s' if args.layers > 1 else ''}, kNN k={args.k} "
+                                   f"(search results given), {args.tokens_per_sample}-token blocks",
                        "n_store": args.n_store, "blocks_per_step_per_gpu": args.blocks, "streams": args.streams, "hip_graph": bool(args.graph), "tokens_per_block": args.tokens_per_sample,
                        "gcn_k": args.gcn_k, "knn_k": args.k, "hgt_layers": args.layers, "d": d, "vocab": vocab,
                        "lmbda": args.lmbda, "temperature": args.temperature,
@@ -358,6 +586,12 @@ def main():
             "roofline": r,
             "kernels": [roof(k_, v) for k_, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"])],
         }
+        if parity is not None:
+            res["parity"] = parity
+        if recipe is not None:
+            res["recipe_L3"] = recipe
+        if drv is not None:
+            res["driver_path"] = drv
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, cpu_model)
         print(json.dumps(res))

@@ -421,7 +421,7 @@ size_t gnnlm_sizeof(const char* name) {
 #define GNNLM_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
     GNNLM_SZ(gnnlm_gemm_t) GNNLM_SZ(gnnlm_gather_t) GNNLM_SZ(gnnlm_star_attn_t) GNNLM_SZ(gnnlm_chain_attn_t)
     GNNLM_SZ(gnnlm_adaptive_softmax_t) GNNLM_SZ(gnnlm_knn_interp_t) GNNLM_SZ(gnnlm_hgt_layer_t)
-    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t)
+    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t)
 #undef GNNLM_SZ
     return 0;
 }
@@ -478,6 +478,7 @@ int gnnlm_adaptive_target_logp(const gnnlm_adaptive_softmax_t* w, const float* x
     return adaptive_impl(*w, x, ldx, target, n, lm_logp, workspace, workspace_bytes, (hipStream_t)stream);
 }
 int gnnlm_knn_interp(const gnnlm_knn_interp_t* d, void* stream) { GNNLM_DESC(d); return knn_interp(*d, (hipStream_t)stream); }
+int gnnlm_topk_merge(const gnnlm_topk_t* d, void* stream) { GNNLM_DESC(d); return topk_merge(*d, (hipStream_t)stream); }
 int gnnlm_masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, void* stream) {
     return masked_sum_f64(x, mask, n, out, (hipStream_t)stream);
 }
@@ -498,7 +499,8 @@ int gnnlm_hgt_forward(const gnnlm_hgt_t* m, const gnnlm_hgt_io_t* io, void* work
 
 static const char* kKernelNames[K_COUNT] = {"gemm_nt_f32_kernel", "gather_decode_kernel", "star_attn_kernel",
                                             "chain_attn_kernel", "causal_attn_kernel", "layernorm_kernel",
-                                            "row_lse_pick_kernel", "knn_interp_kernel", "misc", "split_planes_kernel"};
+                                            "row_lse_pick_kernel", "knn_interp_kernel", "misc", "split_planes_kernel",
+                                            "topk_merge_kernel", "ivfpq_scan_kernel"};
 const char* gnnlm_kernel_name(int32_t kernel_id) {
     return kernel_id >= 0 && kernel_id < K_COUNT ? kKernelNames[kernel_id] : nullptr;
 }

@@ -31,6 +31,7 @@ namespace gnnlm {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
+typedef __attribute__((address_space(3))) const float lds_cfloat_t;
 
 namespace {
 
@@ -132,81 +133,112 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
     }
     STAB_DMA(0, 0)
 
+    // Both sweeps are software-pipelined over the chunks.  Step c, between two barriers:
+    //     DMA(c + 2) -> buffer c & 1          (the look-ups of chunk c completed before the barrier that opened the step)
+    //     look-ups of chunk c + 1 -> register set (c + 1) & 1       (its table landed before that barrier)
+    //     MFMAs of chunk c from register set c & 1
+    //     wait for the DMA, barrier
+    // so the LDS latency of a chunk's look-ups and the DMA of the one after hide under a chunk of MFMAs.  (A first
+    // version read and multiplied the SAME chunk between two barriers: 1.01 ms per 8192 tokens, of which 0.67 ms
+    // remained with every MFMA removed -- each wave may have 15 LDS operations in flight and there are only two
+    // waves per SIMD, so the look-up phase was a latency chain with the matrix pipe idle.)  The loops are unrolled
+    // by two so that the register sets have static names.
+
     // ================================================================ pass 1: S[128 nb x 16 (8 real) heads] = X U^T
     {
         // lane (n16, g) carries U[head n16 & 7][chunk dims of k slot g]: the 8 dims of sub-quantizer 4c + g (dsub 8; odd
         // g with the two halves swapped, see the header) or of the pair 8c + 2g, 8c + 2g + 1 (dsub 4)
         const float* Ur = p.U + ((int64_t)i_tok * H + h0 + min(n16 & 7, H - 1 - h0)) * D + 8 * g;
         const int lo = DSUB == 8 ? 4 * (g & 1) : 0, hi = 4 - lo;
-        float4 ua = *reinterpret_cast<const float4*>(Ur + lo), ub = *reinterpret_cast<const float4*>(Ur + hi);
-        float4 ua_n = ua, ub_n = ub;
         f32x4 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         // code bytes of this lane: neighbour 64 half + 16 q + n16, sub-quantizer(s) of k slot g (padding rows are zeros)
         const unsigned char* crow = lcodes + (t * KGM + 64 * half + n16) * MS + (DSUB == 8 ? g : 2 * g);
-        unsigned code[4], code_n[4];
+        unsigned code[4];
+        float4 xaA[4], xbA[4], xaB[4], xbB[4], uaA, ubA, uaB, ubB;
+#define STAB_CODES(c_)                                                                               \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                   \
+        code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS + MPC * (c_)]                              \
+                            : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS + MPC * (c_));
+#define STAB_LOOK1(c_, S)      /* the look-ups ARE the A operands */                                 \
+    {                                                                                                \
+        const float* tb_ = tab + ((c_) & 1) * TABF;                                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+            if constexpr (DSUB == 8) {                                                               \
+                const float* r_ = tb_ + (g * 256 + (GNNLM_STAB_EXP == 3 ? 0u : code[q])) * 8;       \
+                xa##S[q] = *reinterpret_cast<const float4*>(r_ + lo);                                \
+                xb##S[q] = *reinterpret_cast<const float4*>(r_ + hi);                                \
+            } else {                                                                                 \
+                xa##S[q] = *reinterpret_cast<const float4*>(tb_ + ((2 * g) * 256 + (GNNLM_STAB_EXP == 3 ? 0u : (code[q] & 255u))) * 4); \
+                xb##S[q] = *reinterpret_cast<const float4*>(tb_ + ((2 * g + 1) * 256 + (GNNLM_STAB_EXP == 3 ? 0u : (code[q] >> 8))) * 4); \
+            }                                                                                        \
+        }                                                                                            \
+    }
+#define STAB_ULOAD(c_, S)                                                                            \
+    if (GNNLM_STAB_EXP != 6 || (c_) == 0) {                                                          \
+        ua##S = *reinterpret_cast<const float4*>(Ur + (c_) * CD + lo);                               \
+        ub##S = *reinterpret_cast<const float4*>(Ur + (c_) * CD + hi);                               \
+    }
+#define STAB_MMA1(S)                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
+        if (GNNLM_STAB_EXP != 1 && GNNLM_STAB_EXP != 8) {                                            \
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa##S[q].x, ua##S.x, acc[q], 0, 0, 0);     \
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa##S[q].y, ua##S.y, acc[q], 0, 0, 0);     \
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa##S[q].z, ua##S.z, acc[q], 0, 0, 0);     \
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa##S[q].w, ua##S.w, acc[q], 0, 0, 0);     \
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb##S[q].x, ub##S.x, acc[q], 0, 0, 0);     \
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb##S[q].y, ub##S.y, acc[q], 0, 0, 0);     \
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb##S[q].z, ub##S.z, acc[q], 0, 0, 0);     \
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb##S[q].w, ub##S.w, acc[q], 0, 0, 0);     \
+        } else {                                                                                     \
+            asm volatile("" :: "v"(xa##S[q].x), "v"(xa##S[q].w), "v"(xb##S[q].x), "v"(xb##S[q].w), "v"(ua##S.x), "v"(ub##S.w)); \
+        }                                                                                            \
+    }
+        // step c: CUR = register set of chunk c, NXT = set that receives chunk c + 1
+#define STAB_STEP1(c_, CUR, NXT)                                                                     \
+    {                                                                                                \
+        if ((c_) + 2 < NCH && GNNLM_STAB_EXP != 4) STAB_DMA((c_) + 2, (c_) & 1)                      \
+        if ((c_) + 1 < NCH) {                                                                        \
+            STAB_LOOK1((c_) + 1, NXT)                                                                \
+            STAB_ULOAD((c_) + 1, NXT)                                                                \
+            if ((c_) + 2 < NCH) STAB_CODES((c_) + 2)                                                 \
+        }                                                                                            \
+        STAB_MMA1(CUR)                                                                               \
+        STAB_LAND();                                                                                 \
+        __syncthreads();                                                                             \
+    }
+        STAB_ULOAD(0, A)
         STAB_LAND();
         __syncthreads();                                               // codes staged, chunk 0 landed
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS] : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS);
-        for (int c = 0; c < NCH; ++c) {
-            const float* tb = tab + (c & 1) * TABF;
-            float4 xa[4], xb[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                              // the look-ups ARE the A operands
-                if constexpr (DSUB == 8) {
-                    const float* r_ = tb + (g * 256 + (GNNLM_STAB_EXP == 3 ? 0u : code[q])) * 8;
-                    xa[q] = *reinterpret_cast<const float4*>(r_ + lo);
-                    xb[q] = *reinterpret_cast<const float4*>(r_ + hi);
-                } else {
-                    xa[q] = *reinterpret_cast<const float4*>(tb + ((2 * g) * 256 + (GNNLM_STAB_EXP == 3 ? 0u : (code[q] & 255u))) * 4);
-                    xb[q] = *reinterpret_cast<const float4*>(tb + ((2 * g + 1) * 256 + (GNNLM_STAB_EXP == 3 ? 0u : (code[q] >> 8))) * 4);
-                }
-            }
-            if (c + 1 < NCH) {                                         // next chunk: table by DMA, U and code bytes to registers
-                if (GNNLM_STAB_EXP != 6) {
-                    ua_n = *reinterpret_cast<const float4*>(Ur + (c + 1) * CD + lo);
-                    ub_n = *reinterpret_cast<const float4*>(Ur + (c + 1) * CD + hi);
-                }
-                if (GNNLM_STAB_EXP != 4) STAB_DMA(c + 1, (c + 1) & 1)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    code_n[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS + MPC * (c + 1)]
-                                          : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS + MPC * (c + 1));
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (GNNLM_STAB_EXP != 1 && GNNLM_STAB_EXP != 8) {
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].x, ua.x, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].y, ua.y, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].z, ua.z, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].w, ua.w, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].x, ub.x, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].y, ub.y, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].z, ub.z, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].w, ub.w, acc[q], 0, 0, 0);
-                } else {
-                    asm volatile("" :: "v"(xa[q].x), "v"(xa[q].w), "v"(xb[q].x), "v"(xb[q].w));
-                }
-            }
-            STAB_LAND();
-            __syncthreads();            // chunk c + 1 landed in every wave's piece; buffer c & 1 is free
-            ua = ua_n; ub = ub_n;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) code[q] = code_n[q];
+        if (NCH > 1) STAB_DMA(1, 1)
+        STAB_CODES(0)
+        STAB_LOOK1(0, A)
+        if (NCH > 1) STAB_CODES(1)
+        STAB_LAND();
+        __syncthreads();                                               // chunk 1 landed; set A holds chunk 0
+        for (int c = 0; c < NCH; c += 2) {
+            STAB_STEP1(c, A, B)
+            if (c + 1 < NCH) STAB_STEP1(c + 1, B, A)
         }
-        STAB_DMA(0, 0)                  // pass 2's first chunk flies under the softmax
+#undef STAB_CODES
+#undef STAB_LOOK1
+#undef STAB_ULOAD
+#undef STAB_MMA1
+#undef STAB_STEP1
+        STAB_DMA(0, 0)                  // pass 2's first chunks fly under the softmax
+        if (NCH > 1) STAB_DMA(1, 1)
         // C layout: acc[q][rr] = S[neighbour 64 half + 16 q + 4 g + rr][head n16]
         if (n16 < HB) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t okw = *reinterpret_cast<const uint32_t*>(okf + t * KGM + 64 * half + 16 * q + 4 * g);
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int j = 64 * half + 16 * q + 4 * g + rr;
-                    sc[(t * HB + n16) * SCS + j] = okf[t * KGM + j] ? acc[q][rr] : -INFINITY;
+                    sc[(t * HB + n16) * SCS + j] = ((okw >> (8 * rr)) & 1u) ? acc[q][rr] : -INFINITY;
                 }
+            }
         }
     }
     __syncthreads();
@@ -224,7 +256,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
         if (q == 0 && half == 0 && h0 == 0 && lane == 0 && p.has_nb && live) p.has_nb[i_tok] = sum > 0.f ? 1.f : 0.f;
     }
     STAB_LAND();
-    __syncthreads();                    // alphas written, chunk 0 landed
+    __syncthreads();                    // alphas written, chunks 0 and 1 landed
 
     // ================================================================ pass 2: Z[16 (8 real) heads x 32 dims] = alpha^T X per chunk
     {
@@ -234,70 +266,93 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) a_reg[ks] = n16 < HB ? sc[(t * HB + n16) * SCS + 64 * kh + 4 * ks + g] : 0.f;
         // B operand of column tile ct: dim 16 ct + n16 of the chunk = sub-quantizer mloc, component n16 % DSUB
-        int toff[2], shift[2], widx[2];
+        constexpr unsigned ROWSH = DSUB == 8 ? 5 : 4;      // log2 of a centroid row in bytes
+        unsigned lbase[2], shift[2];                       // LDS byte address of (row 0, this lane's component) in buffer 0
+        int widx[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int dl = 16 * ct + n16, mloc = dl / DSUB;
-            toff[ct] = mloc * 256 * DSUB + (dl % DSUB);
+            lbase[ct] = (unsigned)(uintptr_t)(lds_void_t*)tab + (mloc * 256 * DSUB + (dl % DSUB)) * 4;
             shift[ct] = 8 * (mloc & 3);
             widx[ct] = mloc >> 2;
         }
         const unsigned char* cbase = lcodes + (t * KGM + 64 * kh + g) * MS;
         float* zp = zpart + t * 512 + lane;
         float* zo = p.Z + ((int64_t)i_tok * H + h0 + 4 * g) * D + n16;
-        uint32_t w0[16], w1[16];        // code words of this lane's 16 neighbours for the current chunk
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const uint32_t* wp = reinterpret_cast<const uint32_t*>(cbase + 4 * ks * MS);
-            w0[ks] = wp[widx[0]];
-            w1[ks] = MPC == 4 ? w0[ks] : wp[widx[1]];
+        uint32_t w0[16], w1[16];        // code words of this lane's 16 neighbours for the chunk whose look-ups come next
+        float b0A[16], b1A[16], b0B[16], b1B[16];
+        f32x4 z0, z1;
+#define STAB_WORDS(c_)                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) {                                             \
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(cbase + 4 * ks * MS + MPC * (c_));   \
+        w0[ks] = wp[widx[0]];                                                                        \
+        w1[ks] = MPC == 4 ? w0[ks] : wp[widx[1]];                                                    \
+    }
+    // Two VALU operations per look-up (v_bfe_u32 + v_lshl_add_u32 on integer LDS addresses): the compiler's own
+    // address arithmetic took five and made the VALU, not the matrix pipe, the longest chain of this pass.
+#define STAB_LOOK2(c_, S)      /* the look-ups ARE the B operands */                                 \
+    {                                                                                                \
+        const unsigned sb0_ = lbase[0] + ((c_) & 1) * (TABF * 4), sb1_ = lbase[1] + ((c_) & 1) * (TABF * 4); \
+        _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) {                                         \
+            const unsigned c0 = GNNLM_STAB_EXP == 3 ? 0u : __builtin_amdgcn_ubfe(w0[ks], shift[0], 8u); \
+            const unsigned c1 = GNNLM_STAB_EXP == 3 ? 0u : __builtin_amdgcn_ubfe(w1[ks], shift[1], 8u); \
+            b0##S[ks] = *(lds_cfloat_t*)(uintptr_t)((c0 << ROWSH) + sb0_);                           \
+            b1##S[ks] = *(lds_cfloat_t*)(uintptr_t)((c1 << ROWSH) + sb1_);                           \
+        }                                                                                            \
+    }
+    // A wave can have 15 LDS operations in flight (lgkmcnt is 4 bits) and issues in order: 48 look-ups placed in front of
+    // the 32 MFMAs are a latency chain the matrix pipe waits behind, whatever chunk they belong to.  So the step
+    // interleaves: per k step, the two look-ups of chunk c + 1 (+ the code word of chunk c + 2), then the two MFMAs
+    // of chunk c; the sched_barrier pins that order.  Past the last chunk the look-ups run on a clamped index (unused).
+#define STAB_STEP2(c_, CUR, NXT)                                                                     \
+    {                                                                                                \
+        if ((c_) + 2 < NCH && GNNLM_STAB_EXP != 4) STAB_DMA((c_) + 2, (c_) & 1)                      \
+        const unsigned sb0_ = lbase[0] + (((c_) + 1) & 1) * (TABF * 4), sb1_ = lbase[1] + (((c_) + 1) & 1) * (TABF * 4); \
+        const unsigned char* cw_ = cbase + MPC * min((c_) + 2, NCH - 1);                             \
+        z0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                              \
+        z1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) {                                         \
+            const unsigned c0 = GNNLM_STAB_EXP == 3 ? 0u : __builtin_amdgcn_ubfe(w0[ks], shift[0], 8u); \
+            const unsigned c1 = GNNLM_STAB_EXP == 3 ? 0u : __builtin_amdgcn_ubfe(w1[ks], shift[1], 8u); \
+            b0##NXT[ks] = *(lds_cfloat_t*)(uintptr_t)((c0 << ROWSH) + sb0_);                         \
+            b1##NXT[ks] = *(lds_cfloat_t*)(uintptr_t)((c1 << ROWSH) + sb1_);                         \
+            const uint32_t* wp = reinterpret_cast<const uint32_t*>(cw_ + 4 * ks * MS);               \
+            w0[ks] = wp[widx[0]];                                                                    \
+            w1[ks] = MPC == 4 ? w0[ks] : wp[widx[1]];                                                \
+            if (GNNLM_STAB_EXP != 2 && GNNLM_STAB_EXP != 8) {                                        \
+                z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b0##CUR[ks], z0, 0, 0, 0);      \
+                z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b1##CUR[ks], z1, 0, 0, 0);      \
+            } else {                                                                                 \
+                asm volatile("" :: "v"(b0##CUR[ks]), "v"(b1##CUR[ks]));                              \
+            }                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
+        }                                                                                            \
+        /* C layout: z[rr] = Z[head 4 g + rr][dim 32 c + 16 ct + n16]; heads 8..15 (g >= 2) are padding */ \
+        float* zb = zp + ((c_) & 1) * 256;                                                           \
+        if (kh == 1 && g < 2) {                                                                      \
+            _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) { zb[32 * rr] = z0[rr]; zb[128 + 32 * rr] = z1[rr]; } \
+        }                                                                                            \
+        STAB_LAND();                                                                                 \
+        __syncthreads();        /* partial sums of the other half written; chunk c + 2 landed; look-ups of c + 1 done */ \
+        if (kh == 0 && g < 2 && live && GNNLM_STAB_EXP != 7) {                                       \
+            _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                        \
+                if (h0 + 4 * g + rr < H) {                                                           \
+                    zo[(int64_t)rr * D + (c_) * CD] = z0[rr] + zb[32 * rr];                          \
+                    zo[(int64_t)rr * D + (c_) * CD + 16] = z1[rr] + zb[128 + 32 * rr];               \
+                }                                                                                    \
+        }                                                                                            \
+    }
+        STAB_WORDS(0)
+        STAB_LOOK2(0, A)
+        if (NCH > 1) STAB_WORDS(1)
+        __syncthreads();                // every wave's look-ups of chunk 0 are done before step 0 refills buffer 0
+        for (int c = 0; c < NCH; c += 2) {
+            STAB_STEP2(c, A, B)
+            if (c + 1 < NCH) STAB_STEP2(c + 1, B, A)
         }
-        for (int c = 0; c < NCH; ++c) {
-            const float* tb = tab + (c & 1) * TABF;
-            float b0[16], b1[16];
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {                          // the look-ups ARE the B operands
-                const unsigned c0 = GNNLM_STAB_EXP == 3 ? 0u : ((w0[ks] >> shift[0]) & 255u);
-                const unsigned c1 = GNNLM_STAB_EXP == 3 ? 0u : ((w1[ks] >> shift[1]) & 255u);
-                b0[ks] = tb[toff[0] + c0 * DSUB];
-                b1[ks] = tb[toff[1] + c1 * DSUB];
-            }
-            if (c + 1 < NCH) {
-                if (GNNLM_STAB_EXP != 4) STAB_DMA(c + 1, (c + 1) & 1)
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    const uint32_t* wp = reinterpret_cast<const uint32_t*>(cbase + 4 * ks * MS + MPC * (c + 1));
-                    w0[ks] = wp[widx[0]];
-                    w1[ks] = MPC == 4 ? w0[ks] : wp[widx[1]];
-                }
-            }
-            f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                if (GNNLM_STAB_EXP != 2 && GNNLM_STAB_EXP != 8) {
-                    z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b0[ks], z0, 0, 0, 0);
-                    z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b1[ks], z1, 0, 0, 0);
-                } else {
-                    asm volatile("" :: "v"(b0[ks]), "v"(b1[ks]));
-                }
-            }
-            // C layout: z[rr] = Z[head 4 g + rr][dim 32 c + 16 ct + n16]; heads 8..15 (g >= 2) are padding
-            float* zb = zp + (c & 1) * 256;
-            if (kh == 1 && g < 2) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) { zb[32 * rr] = z0[rr]; zb[128 + 32 * rr] = z1[rr]; }
-            }
-            STAB_LAND();
-            __syncthreads();            // partial sums of the other half written; chunk c + 1 landed; buffer c & 1 free
-            if (kh == 0 && g < 2 && live && GNNLM_STAB_EXP != 7) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-                    if (h0 + 4 * g + rr < H) {
-                        zo[(int64_t)rr * D + c * CD] = z0[rr] + zb[32 * rr];
-                        zo[(int64_t)rr * D + c * CD + 16] = z1[rr] + zb[128 + 32 * rr];
-                    }
-            }
-        }
+#undef STAB_WORDS
+#undef STAB_LOOK2
+#undef STAB_STEP2
     }
 #undef STAB_DMA
 #undef STAB_LAND

@@ -1,0 +1,159 @@
+// Running top-k over score chunks: the selection half of the on-device kNN search
+// (replaces faiss `index.search`'s k-selection, knn/knn_model.py:87-101 and knn/find_knn.py:55-70; the scores come
+// from the f32 MFMA GEMM over a chunk of keys, or from the IVF-PQ scan).
+//
+// One workgroup per query.  The running state (best_val / best_id, k entries, best first) lives in HBM between
+// calls; a call folds one chunk of `ncols` scores into it.  Only scores that beat the current k-th best survive the
+// scan (after the first chunks that is a handful per row), are appended to an LDS candidate buffer, sorted with a
+// bitonic network and merged into the sorted state with one bitonic merge.  No [n, N] score matrix, no global sort.
+// Order: better value first; equal values by ascending id (what a stable argsort of the full row gives), so the
+// result does not depend on the chunking.
+#include <cmath>
+
+#include "kernels.h"
+
+namespace gnnlm {
+namespace {
+
+struct Item {
+    float v;
+    int64_t id;
+};
+// true if a ranks before b
+__device__ __forceinline__ bool before(float av, int64_t ai, float bv, int64_t bi) { return av > bv || (av == bv && ai < bi); }
+
+// compare-exchange network helpers over LDS arrays val[], id[]; `n` threads cooperate, L is a power of two
+template <int NT>
+__device__ __forceinline__ void bitonic_merge_desc(float* val, int64_t* id, int L, int first_stride, int tid) {
+    for (int stride = first_stride; stride > 0; stride >>= 1) {
+        for (int e = tid; e < L / 2; e += NT) {
+            const int i = ((e & ~(stride - 1)) << 1) | (e & (stride - 1));
+            const int j = i + stride;
+            const float a = val[i], b = val[j];
+            const int64_t ia = id[i], ib = id[j];
+            if (before(b, ib, a, ia)) { val[i] = b; val[j] = a; id[i] = ib; id[j] = ia; }
+        }
+        __syncthreads();
+    }
+}
+// full bitonic sort, best first
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_desc(float* val, int64_t* id, int L, int tid) {
+    for (int size = 2; size <= L; size <<= 1) {
+        // first step of each stage pairs i with its mirror inside the block of `size` (makes every block sorted best-first)
+        for (int e = tid; e < L / 2; e += NT) {
+            const int blk = e / (size / 2), off = e % (size / 2);
+            const int i = blk * size + off, j = blk * size + size - 1 - off;
+            const float a = val[i], b = val[j];
+            const int64_t ia = id[i], ib = id[j];
+            if (before(b, ib, a, ia)) { val[i] = b; val[j] = a; id[i] = ib; id[j] = ia; }
+        }
+        __syncthreads();
+        bitonic_merge_desc<NT>(val, id, L, size / 4, tid);
+    }
+}
+
+struct TopkParams {
+    const float* scores; int64_t ld; int64_t n; int ncols;
+    int64_t col0; const int64_t* col_ids; const float* col_scale; const float* col_bias; float alpha;
+    int k, largest, init;
+    float* best_val; int64_t* best_id;
+    const int32_t* row_ncols;       // optional [n]: row r only has its first row_ncols[r] columns (ragged candidate lists)
+};
+
+// KP: power of two >= k.  LDS: val[2 KP] + id[2 KP]; [0, KP) the state (padded with -inf), [KP, 2 KP) the candidates.
+template <int KP>
+__global__ __launch_bounds__(256) void topk_merge_kernel(TopkParams p) {
+    constexpr int NT = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int64_t* id = reinterpret_cast<int64_t*>(smem_raw);                 // [2 KP]
+    float* val = reinterpret_cast<float*>(id + 2 * KP);                 // [2 KP]
+    __shared__ int cnt;
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const float sign = p.largest ? 1.f : -1.f;
+    const float NEG = -INFINITY;
+
+    for (int e = tid; e < KP; e += NT) {
+        const bool have = !p.init && e < p.k;
+        val[e] = have ? sign * p.best_val[row * p.k + e] : NEG;
+        id[e] = have ? p.best_id[row * p.k + e] : (int64_t)-1;
+        if (have && id[e] < 0) val[e] = NEG;                            // unfilled slots of an earlier call
+    }
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    float tau = p.k <= KP ? val[p.k - 1] : NEG;                         // current k-th best (-inf while fewer than k)
+
+    auto flush = [&]() {
+        // candidates [KP, KP + cnt) -> sort best-first, reverse into a bitonic sequence with the state, merge
+        const int m = cnt;
+        for (int e = m + tid; e < KP; e += NT) { val[KP + e] = NEG; id[KP + e] = (int64_t)0x7fffffffffffffffll; }
+        __syncthreads();
+        bitonic_sort_desc<NT>(val + KP, id + KP, KP, tid);
+        // reverse the candidate half in place -> [state best-first | candidates worst-first] is bitonic
+        for (int e = tid; e < KP / 2; e += NT) {
+            const int i = KP + e, j = 2 * KP - 1 - e;
+            const float a = val[i]; val[i] = val[j]; val[j] = a;
+            const int64_t ia = id[i]; id[i] = id[j]; id[j] = ia;
+        }
+        __syncthreads();
+        bitonic_merge_desc<NT>(val, id, 2 * KP, KP, tid);
+        if (tid == 0) cnt = 0;
+        __syncthreads();
+        tau = val[p.k - 1];
+    };
+
+    const float* srow = p.scores + row * p.ld;
+    const int ncols = p.row_ncols ? min(p.ncols, p.row_ncols[row]) : p.ncols;
+    constexpr int SB = KP / 2 >= NT ? KP / 2 : NT;                      // columns per sub-block: at most SB new candidates
+    for (int c0 = 0; c0 < ncols; c0 += SB) {
+        if (cnt + SB > KP) flush();                                     // uniform: cnt is read after a barrier
+        for (int c = c0 + tid; c < min(ncols, c0 + SB); c += NT) {
+            float v = srow[c] * p.alpha;
+            if (p.col_scale) v *= p.col_scale[c];
+            if (p.col_bias) v += p.col_bias[c];
+            v *= sign;
+            const int64_t cid = p.col_ids ? p.col_ids[c] : p.col0 + c;
+            // strictly better than the k-th best, or tied with it and earlier (tau's id is not tracked: keep ties, the merge decides)
+            if (cid >= 0 && v >= tau && v > NEG) {
+                const int pos = atomicAdd(&cnt, 1);
+                val[KP + pos] = v;
+                id[KP + pos] = cid;
+            }
+        }
+        __syncthreads();
+    }
+    if (cnt > 0) flush();
+    for (int e = tid; e < p.k; e += NT) {
+        const bool real = val[e] > NEG;
+        p.best_val[row * p.k + e] = real ? sign * val[e] : (p.largest ? NEG : INFINITY);
+        p.best_id[row * p.k + e] = real ? id[e] : (int64_t)-1;         // faiss pads with -1
+    }
+}
+
+}  // namespace
+
+int topk_merge(const gnnlm_topk_t& d, hipStream_t stream) {
+    GNNLM_REQUIRE(d.best_val && d.best_id && d.k > 0 && d.k <= 2048, "topk_merge: need state buffers and 0 < k <= 2048");
+    GNNLM_REQUIRE(d.n >= 0 && d.ncols >= 0 && d.n < (1ll << 31), "topk_merge: bad shape");
+    if (d.n == 0) return OK;
+    GNNLM_REQUIRE(d.ncols == 0 || d.scores, "topk_merge: null scores");
+    TopkParams p{d.scores, d.ld, d.n, d.ncols, d.col0, d.col_ids, d.col_scale, d.col_bias, d.alpha == 0.f ? 1.f : d.alpha,
+                 d.k, d.largest, d.init, d.best_val, d.best_id, d.row_ncols};
+    ProfScope prof(K_TOPK, stream, 0.0, 4.0 * (double)d.n * d.ncols + 24.0 * (double)d.n * d.k);
+    const dim3 grid((unsigned)d.n), block(256);
+#define GNNLM_TOPK_LAUNCH(KP)                                                                                    \
+    {                                                                                                            \
+        const size_t lds = (size_t)2 * KP * 12;                                                                  \
+        hipLaunchKernelGGL((topk_merge_kernel<KP>), grid, block, lds, stream, p);                                \
+    }
+    if (d.k <= 64) GNNLM_TOPK_LAUNCH(64)
+    else if (d.k <= 256) GNNLM_TOPK_LAUNCH(256)
+    else if (d.k <= 1024) GNNLM_TOPK_LAUNCH(1024)
+    else GNNLM_TOPK_LAUNCH(2048)
+#undef GNNLM_TOPK_LAUNCH
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // namespace gnnlm

@@ -217,6 +217,29 @@ typedef struct gnnlm_knn_interp {
 } gnnlm_knn_interp_t;
 int gnnlm_knn_interp(const gnnlm_knn_interp_t* desc, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * On-device kNN search, selection half: fold one chunk of scores into a running top-k per query.
+ * Replaces the k-selection of faiss `index.search` (knn/knn_model.py:87-101, knn/find_knn.py:55-70); the
+ * scores of a chunk come from gnnlm_gemm_nt over a chunk of keys (exact search) or from gnnlm_ivfpq_scan.
+ *   value of column c for row r:  v = col_bias[c] + alpha * col_scale[c] * scores[r, c]
+ *   (cosine index: col_scale = 1/|key|;  L2: alpha = -2, col_bias = |key|^2, largest = 0, add |q|^2 afterwards)
+ * State: best_val / best_id [n, k], best first, ties by ascending id (== a stable argsort of the whole row, so the
+ * result is independent of the chunking); unfilled slots hold id -1 like faiss.  No [n, N] matrix is ever built.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gnnlm_topk {
+    const float* scores;  int64_t ld;     /* [n, ncols] chunk, row stride ld elements */
+    int64_t n;  int32_t ncols;
+    int64_t col0;                         /* id of column c = col_ids ? col_ids[c] : col0 + c (col_ids < 0: skipped) */
+    const int64_t* col_ids;
+    const float* col_scale;  const float* col_bias;  float alpha;   /* alpha 0 is read as 1 */
+    int32_t k;                            /* <= 2048 */
+    int32_t largest;                      /* 1: keep the k largest values, 0: the k smallest */
+    int32_t init;                         /* 1: the state is empty (first chunk), buffers need no initialisation */
+    float* best_val;  int64_t* best_id;   /* [n, k] */
+    const int32_t* row_ncols;             /* optional [n]: row r only has its first row_ncols[r] columns */
+} gnnlm_topk_t;
+int gnnlm_topk_merge(const gnnlm_topk_t* desc, void* stream);
+
 /* out[0] += sum_i x[i] * (mask ? mask[i] != 0 : 1), accumulated in f64 (score_sum of
  * fairseq_cli/eval_lm.py:273; the reference accumulates in f32 on the CPU) */
 int gnnlm_masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, void* stream);
