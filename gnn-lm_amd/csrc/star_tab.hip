@@ -32,13 +32,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 typedef __attribute__((address_space(3))) const float lds_cfloat_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f32x2 lds_cfloat2_t;
 
 namespace {
 
-#ifndef GNNLM_STAB_EXP
-#define GNNLM_STAB_EXP 0     // timing-only ablations (wrong results): 1 no pass-1 MFMAs, 2 no pass-2 MFMAs,
-#endif                       // 3 every look-up reads row 0 (no bank conflicts), 4 no table DMA after the first chunk,
-                             // 5 no code staging (phase 0 loads), 6 no U loads in the sweep, 7 no Z stores, 8 no MFMAs at all
+#ifndef GNNLM_STAB_OFF
+#define GNNLM_STAB_OFF 0     // timing-only ablations (wrong results), a bit mask of what to switch OFF:
+#endif                       //   1 pass-1 MFMAs, 2 pass-2 MFMAs, 4 bank conflicts (every look-up reads row 0), 8 the table DMA,
+                             //   16 code staging, 32 U loads in the sweep, 64 Z stores, 128 the table look-ups themselves
+#define STAB_OFF(bit_) ((GNNLM_STAB_OFF & (bit_)) != 0)
 
 constexpr int TPW = 4;                  // tokens per workgroup
 constexpr int KGM = 128;                // neighbours per token (padded)
@@ -46,7 +49,7 @@ constexpr int HB = 8;                   // heads per launch
 constexpr int CD = 32;                  // feature dims per chunk
 constexpr int TABF = CD * 256;          // floats per table chunk (32 KiB)
 constexpr int SCS = KGM + 4;            // score row stride: the heads of a token land on different banks
-constexpr int NTHREADS = 512;
+constexpr int NTHREADS = 768;           // 8 compute waves (two per token) + 4 loader waves (table DMA only)
 
 struct Carve {
     int tab, sc, zpart, okf, lcodes, total;     // byte offsets
@@ -63,7 +66,7 @@ __host__ __device__ inline Carve carve(int M) {
 }
 
 template <int DSUB>
-__global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnParams p, int h0) {
+__global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams p, int h0) {
     constexpr int MPC = CD / DSUB;              // sub-quantizers per chunk: 4 (dsub 8) or 8 (dsub 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = p.M, D = p.D, H = p.H, kg = p.kg, NCH = D / CD;
@@ -78,6 +81,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = wave >> 1, half = wave & 1;                          // token of this wave, neighbour half
+    const int grp = wave >> 2;                                         // ping-pong group (see the sweeps)
     const int n16 = lane & 15, g = lane >> 4;
     const int tok0 = blockIdx.x * TPW;
     const int i_tok = min(tok0 + t, p.T - 1);                          // tail workgroups recompute the last token
@@ -90,17 +94,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
     // look-up of chunk c).  The asm loads are invisible to its counters; the kernel waits for them itself
     // (STAB_LAND before the chunk barrier).  M0 = LDS byte address of the wave's 1-KiB piece.
     const float* cen = p.centroids;
-    const unsigned tab_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)tab) + wave * 4096;
-#define STAB_DMA(c_, b_)                                                                             \
+    const unsigned tab_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)tab);
+    // pieces [p0_, p0_ + n_) of chunk c_ (32 pieces of 1 KiB) -> buffer b_
+#define STAB_DMA_PIECES(c_, b_, p0_, n_)                                                             \
     {                                                                                                \
-        const float* src_ = cen + (int64_t)(c_) * TABF + wave * 1024 + lane * 4;                    \
-        const unsigned dst_ = tab_lds + (b_) * (TABF * 4);                                          \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+        const float* src_ = cen + (int64_t)(c_) * TABF + (p0_) * 256 + lane * 4;                    \
+        const unsigned dst_ = tab_lds + (b_) * (TABF * 4) + (p0_) * 1024;                           \
+        _Pragma("unroll") for (int q = 0; q < (n_); ++q) {                                          \
             unsigned keep_;                                                                          \
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
                          : "=&s"(keep_) : "v"(src_ + q * 256), "s"(dst_ + q * 1024) : "memory");    \
         }                                                                                            \
     }
+#define STAB_DMA(c_, b_) STAB_DMA_PIECES(c_, b_, (wave - 8) * 8, 8)    /* the four loader waves, 8 pieces each */
+    // Loader waves 8..11 own the table DMA.  Issuing a 1-KiB LDS-DMA costs the issuing wave ~100-150 cycles here; with
+    // the compute waves issuing their own (4 or 8 per chunk) that was the longest item of their look-up phase (1.76k
+    // cycles per phase measured against 1.0k of MFMAs).  Global phase P: A's L(c) = 2c, B's L(c) = 2c + 1; chunk c + 1
+    // replaces chunk c - 1 (last read in phase 2c - 1): issued in phase 2c, landed by the end of phase 2c + 1.
+#define STAB_LOADER_SWEEP()                                                                          \
+    for (int P = 0; P <= 2 * NCH; ++P) {                                                             \
+        const int c1 = (P >> 1) + 1;                                                                 \
+        if (!(P & 1) && c1 < NCH && !STAB_OFF(8)) STAB_DMA(c1, c1 & 1)                        \
+        if (P & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
+        STAB_PHASE()                                                                                 \
+    }
+// -DGNNLM_STAB_CLK=1: cycle stamps of wave 0 of the first 256 workgroups, written over has_nb (a timing build, wrong has_nb):
+// [0] staging, [1] pass 1, [2] softmax, [3] pass 2
+#ifndef GNNLM_STAB_CLK
+#define GNNLM_STAB_CLK 0
+#endif
+#if GNNLM_STAB_CLK
+#define STAB_CLK() clock64()
+#else
+#define STAB_CLK() 0ll
+#endif
 // the sched_barrier keeps the chunk's MFMAs (register-only, free to move for the compiler) ABOVE the wait: the DMA
 // of the next chunk then flies under them instead of being waited for first
 #define STAB_LAND()                                   \
@@ -108,6 +135,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
         __builtin_amdgcn_sched_barrier(0);            \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
     }
+// Phase barrier of the ping-pong: LDS traffic of this wave done, then s_barrier -- and NOTHING else: __syncthreads()
+// would also drain the vector-memory counter, i.e. wait in every phase for the U loads / Z stores / DMA that are
+// meant to fly across phases (a first ping-pong version did, and every phase cost a memory round trip: 1.42 ms).
+// The "memory" clobber keeps the compiler's loads and stores on their side; MFMAs are pinned by the sched_barriers.
+#define STAB_PHASE()                                                  \
+    {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    }
+    [[maybe_unused]] const long long clk0 = STAB_CLK();
 
     // ---------------------------------------------------------------- phase 0: validity, code rows (zeros when invalid)
     for (int e = tid; e < TPW * KGM; e += NTHREADS) {
@@ -123,7 +161,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
             const int tt = row >> 7, j = row & (KGM - 1);
             const int i = min(tok0 + tt, p.T - 1);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (okf[row] && GNNLM_STAB_EXP != 5) {
+            if (okf[row] && !STAB_OFF(16)) {
                 const int64_t lrow = star_code_row(p, i, j, p.ids[(int64_t)i * kg + j]);
                 v = *reinterpret_cast<const uint4*>(p.codes + lrow * M + 16 * part);
             }
@@ -131,18 +169,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
         }
     }
-    STAB_DMA(0, 0)
+    if (wave >= 8) {
+        // ============================================================ loader waves: the table DMA of both sweeps, and
+        // every barrier of the compute path below, in the same order
+        STAB_DMA(0, 0)
+        STAB_LAND();
+        __syncthreads();                // codes staged, chunk 0 landed
+        STAB_LOADER_SWEEP()
+        __syncthreads();                // end of pass 1
+        STAB_DMA(0, 0)
+        __syncthreads();                // scores written
+        STAB_LAND();
+        __syncthreads();                // alphas written, chunk 0 landed
+        STAB_LOADER_SWEEP()
+        return;
+    }
 
-    // Both sweeps are software-pipelined over the chunks.  Step c, between two barriers:
-    //     DMA(c + 2) -> buffer c & 1          (the look-ups of chunk c completed before the barrier that opened the step)
-    //     look-ups of chunk c + 1 -> register set (c + 1) & 1       (its table landed before that barrier)
-    //     MFMAs of chunk c from register set c & 1
-    //     wait for the DMA, barrier
-    // so the LDS latency of a chunk's look-ups and the DMA of the one after hide under a chunk of MFMAs.  (A first
-    // version read and multiplied the SAME chunk between two barriers: 1.01 ms per 8192 tokens, of which 0.67 ms
-    // remained with every MFMA removed -- each wave may have 15 LDS operations in flight and there are only two
-    // waves per SIMD, so the look-up phase was a latency chain with the matrix pipe idle.)  The loops are unrolled
-    // by two so that the register sets have static names.
+    // Both sweeps run as a PING-PONG between the two halves of the workgroup.  Waves w and w + 4 share a SIMD (the
+    // dispatcher deals a workgroup's waves round the SIMDs; measured with tools/probes/mfma_16x16x4.hip), group A =
+    // waves 0..3 (tokens 0, 1), group B = waves 4..7 (tokens 2, 3).  Every chunk c is two phases per group,
+    //     L(c): the look-ups of chunk c into registers, barrier
+    //     M(c): the 32 MFMAs of chunk c, barrier
+    // and B runs one phase behind A, so on every SIMD one wave is on the matrix pipe while its partner is on the LDS /
+    // DMA path.  Why: with all eight waves in the same phase (first versions of this kernel, 1.0 ms per 8192 tokens)
+    // the burst of look-ups and DMA issues of a step and its MFMAs never overlapped -- in-kernel cycle stamps
+    // (-DGNNLM_STAB_CLK=1) showed ~1000 cycles of look-up latency + ~1000 cycles of MFMAs at full rate + ~1400 cycles
+    // waiting for the slower waves per step, against 2048 cycles of MFMA issue per SIMD; software pipelining inside a
+    // wave cannot fix that (in-order issue, 15 LDS operations in flight per wave).
+    // Table buffer c & 1 is read in L(c): by A in phase 2c, by B in phase 2c + 1; the loader waves refill it with chunk
+    // c + 2 in phases 2c + 2 / 2c + 3 (STAB_LOADER_SWEEP).
+    [[maybe_unused]] long long clk1 = 0, clk2 = 0, clk3 = 0;
 
     // ================================================================ pass 1: S[128 nb x 16 (8 real) heads] = X U^T
     {
@@ -156,78 +212,78 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
         // code bytes of this lane: neighbour 64 half + 16 q + n16, sub-quantizer(s) of k slot g (padding rows are zeros)
         const unsigned char* crow = lcodes + (t * KGM + 64 * half + n16) * MS + (DSUB == 8 ? g : 2 * g);
         unsigned code[4];
-        float4 xaA[4], xbA[4], xaB[4], xbB[4], uaA, ubA, uaB, ubB;
-#define STAB_CODES(c_)                                                                               \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                   \
-        code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS + MPC * (c_)]                              \
-                            : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS + MPC * (c_));
-#define STAB_LOOK1(c_, S)      /* the look-ups ARE the A operands */                                 \
-    {                                                                                                \
-        const float* tb_ = tab + ((c_) & 1) * TABF;                                                  \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
-            if constexpr (DSUB == 8) {                                                               \
-                const float* r_ = tb_ + (g * 256 + (GNNLM_STAB_EXP == 3 ? 0u : code[q])) * 8;       \
-                xa##S[q] = *reinterpret_cast<const float4*>(r_ + lo);                                \
-                xb##S[q] = *reinterpret_cast<const float4*>(r_ + hi);                                \
-            } else {                                                                                 \
-                xa##S[q] = *reinterpret_cast<const float4*>(tb_ + ((2 * g) * 256 + (GNNLM_STAB_EXP == 3 ? 0u : (code[q] & 255u))) * 4); \
-                xb##S[q] = *reinterpret_cast<const float4*>(tb_ + ((2 * g + 1) * 256 + (GNNLM_STAB_EXP == 3 ? 0u : (code[q] >> 8))) * 4); \
-            }                                                                                        \
-        }                                                                                            \
-    }
-#define STAB_ULOAD(c_, S)                                                                            \
-    if (GNNLM_STAB_EXP != 6 || (c_) == 0) {                                                          \
-        ua##S = *reinterpret_cast<const float4*>(Ur + (c_) * CD + lo);                               \
-        ub##S = *reinterpret_cast<const float4*>(Ur + (c_) * CD + hi);                               \
-    }
-#define STAB_MMA1(S)                                                                                 \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
-        if (GNNLM_STAB_EXP != 1 && GNNLM_STAB_EXP != 8) {                                            \
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa##S[q].x, ua##S.x, acc[q], 0, 0, 0);     \
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa##S[q].y, ua##S.y, acc[q], 0, 0, 0);     \
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa##S[q].z, ua##S.z, acc[q], 0, 0, 0);     \
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa##S[q].w, ua##S.w, acc[q], 0, 0, 0);     \
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb##S[q].x, ub##S.x, acc[q], 0, 0, 0);     \
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb##S[q].y, ub##S.y, acc[q], 0, 0, 0);     \
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb##S[q].z, ub##S.z, acc[q], 0, 0, 0);     \
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb##S[q].w, ub##S.w, acc[q], 0, 0, 0);     \
-        } else {                                                                                     \
-            asm volatile("" :: "v"(xa##S[q].x), "v"(xa##S[q].w), "v"(xb##S[q].x), "v"(xb##S[q].w), "v"(ua##S.x), "v"(ub##S.w)); \
-        }                                                                                            \
-    }
-        // step c: CUR = register set of chunk c, NXT = set that receives chunk c + 1
-#define STAB_STEP1(c_, CUR, NXT)                                                                     \
-    {                                                                                                \
-        if ((c_) + 2 < NCH && GNNLM_STAB_EXP != 4) STAB_DMA((c_) + 2, (c_) & 1)                      \
-        if ((c_) + 1 < NCH) {                                                                        \
-            STAB_LOOK1((c_) + 1, NXT)                                                                \
-            STAB_ULOAD((c_) + 1, NXT)                                                                \
-            if ((c_) + 2 < NCH) STAB_CODES((c_) + 2)                                                 \
-        }                                                                                            \
-        STAB_MMA1(CUR)                                                                               \
-        STAB_LAND();                                                                                 \
-        __syncthreads();                                                                             \
-    }
-        STAB_ULOAD(0, A)
+        float4 xa[4], xb[4];
+        float4 ua = *reinterpret_cast<const float4*>(Ur + lo), ub = *reinterpret_cast<const float4*>(Ur + hi), ua_n = ua, ub_n = ub;
         STAB_LAND();
         __syncthreads();                                               // codes staged, chunk 0 landed
-        if (NCH > 1) STAB_DMA(1, 1)
-        STAB_CODES(0)
-        STAB_LOOK1(0, A)
-        if (NCH > 1) STAB_CODES(1)
-        STAB_LAND();
-        __syncthreads();                                               // chunk 1 landed; set A holds chunk 0
-        for (int c = 0; c < NCH; c += 2) {
-            STAB_STEP1(c, A, B)
-            if (c + 1 < NCH) STAB_STEP1(c + 1, B, A)
+        clk1 = STAB_CLK();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS] : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS);
+        if (grp) STAB_PHASE()                                          // B starts one phase late
+        for (int c = 0; c < NCH; ++c) {
+            // ---------------- L(c)
+            {
+                const float* tb = tab + (c & 1) * TABF;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                          // the look-ups ARE the A operands
+                    if (STAB_OFF(128)) {
+                        xa[q] = make_float4(1.f, 2.f, 3.f, (float)code[q]);
+                        xb[q] = xa[q];
+                    } else if constexpr (DSUB == 8) {
+                        const float* r_ = tb + (g * 256 + (STAB_OFF(4) ? 0u : code[q])) * 8;
+                        xa[q] = *reinterpret_cast<const float4*>(r_ + lo);
+                        xb[q] = *reinterpret_cast<const float4*>(r_ + hi);
+                    } else {
+                        xa[q] = *reinterpret_cast<const float4*>(tb + ((2 * g) * 256 + (STAB_OFF(4) ? 0u : (code[q] & 255u))) * 4);
+                        xb[q] = *reinterpret_cast<const float4*>(tb + ((2 * g + 1) * 256 + (STAB_OFF(4) ? 0u : (code[q] >> 8))) * 4);
+                    }
+                }
+                ua = ua_n; ub = ub_n;
+                if (c + 1 < NCH) {
+                    if (!STAB_OFF(32)) {
+                        ua_n = *reinterpret_cast<const float4*>(Ur + (c + 1) * CD + lo);
+                        ub_n = *reinterpret_cast<const float4*>(Ur + (c + 1) * CD + hi);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS + MPC * (c + 1)]
+                                            : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS + MPC * (c + 1));
+                }
+                STAB_PHASE()
+            }
+            // ---------------- M(c)
+#if GNNLM_STAB_CLK
+            if (c == 5 && blockIdx.x < 256 && lane == 0 && (wave == 0 || wave == 4) && p.has_nb)
+                reinterpret_cast<unsigned*>(p.has_nb)[blockIdx.x * 8 + 4 + (wave >> 2)] = (unsigned)(STAB_CLK() - clk0);
+            if (c == 6 && blockIdx.x < 256 && lane == 0 && wave == 0 && p.has_nb)
+                reinterpret_cast<unsigned*>(p.has_nb)[blockIdx.x * 8 + 6] = (unsigned)(STAB_CLK() - clk0);
+#endif
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!STAB_OFF(1)) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].x, ua.x, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].y, ua.y, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].z, ua.z, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].w, ua.w, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].x, ub.x, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].y, ub.y, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].z, ub.z, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].w, ub.w, acc[q], 0, 0, 0);
+                } else {
+                    asm volatile("" :: "v"(xa[q].x), "v"(xa[q].w), "v"(xb[q].x), "v"(xb[q].w), "v"(ua.x), "v"(ub.w));
+                }
+            }
+#if GNNLM_STAB_CLK
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == 5 && blockIdx.x < 256 && lane == 0 && wave == 0 && p.has_nb)
+                reinterpret_cast<unsigned*>(p.has_nb)[blockIdx.x * 8 + 7] = (unsigned)(STAB_CLK() - clk0);
+#endif
+            STAB_PHASE()
         }
-#undef STAB_CODES
-#undef STAB_LOOK1
-#undef STAB_ULOAD
-#undef STAB_MMA1
-#undef STAB_STEP1
-        STAB_DMA(0, 0)                  // pass 2's first chunks fly under the softmax
-        if (NCH > 1) STAB_DMA(1, 1)
+        if (!grp) STAB_PHASE()                                         // A finished one phase early
+        __syncthreads();
+        clk2 = STAB_CLK();
         // C layout: acc[q][rr] = S[neighbour 64 half + 16 q + 4 g + rr][head n16]
         if (n16 < HB) {
 #pragma unroll
@@ -253,10 +309,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
         const float inv = sum > 0.f ? 1.f / sum : 0.f;
         row[lane] = e0 * inv;
         row[64 + lane] = e1 * inv;
-        if (q == 0 && half == 0 && h0 == 0 && lane == 0 && p.has_nb && live) p.has_nb[i_tok] = sum > 0.f ? 1.f : 0.f;
+        if (q == 0 && half == 0 && h0 == 0 && lane == 0 && p.has_nb && live && !GNNLM_STAB_CLK) p.has_nb[i_tok] = sum > 0.f ? 1.f : 0.f;
     }
     STAB_LAND();
-    __syncthreads();                    // alphas written, chunks 0 and 1 landed
+    __syncthreads();                    // alphas written, chunk 0 landed
+    clk3 = STAB_CLK();
 
     // ================================================================ pass 2: Z[16 (8 real) heads x 32 dims] = alpha^T X per chunk
     {
@@ -265,97 +322,88 @@ __global__ __launch_bounds__(NTHREADS, 2) void star_attn_tab_kernel(StarAttnPara
         float a_reg[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) a_reg[ks] = n16 < HB ? sc[(t * HB + n16) * SCS + 64 * kh + 4 * ks + g] : 0.f;
-        // B operand of column tile ct: dim 16 ct + n16 of the chunk = sub-quantizer mloc, component n16 % DSUB
+        // The two 16-column MFMA tiles of a chunk take the EVEN and the ODD dims: column n of tile ct is dim
+        // DSUB * mloc + 2 * dp + ct with mloc = n / (DSUB / 2), dp = n % (DSUB / 2).  A lane's two B operands are then
+        // neighbours in one centroid row: ONE ds_read_b64 and one code byte per k step feed both MFMAs (a first version
+        // gave tile ct the dims 16 ct .. 16 ct + 15: two ds_read_b32 from two rows, twice the look-ups and twice the
+        // address arithmetic; the LDS, not the matrix pipe, set the pace of this pass).
         constexpr unsigned ROWSH = DSUB == 8 ? 5 : 4;      // log2 of a centroid row in bytes
-        unsigned lbase[2], shift[2];                       // LDS byte address of (row 0, this lane's component) in buffer 0
-        int widx[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int dl = 16 * ct + n16, mloc = dl / DSUB;
-            lbase[ct] = (unsigned)(uintptr_t)(lds_void_t*)tab + (mloc * 256 * DSUB + (dl % DSUB)) * 4;
-            shift[ct] = 8 * (mloc & 3);
-            widx[ct] = mloc >> 2;
-        }
+        const int mloc = n16 / (DSUB / 2), dp = n16 % (DSUB / 2);
+        const unsigned lbase = (unsigned)(uintptr_t)(lds_void_t*)tab + (mloc * 256 * DSUB + 2 * dp) * 4;   // (row 0, dim pair) in buffer 0
+        const unsigned shift = 8 * (mloc & 3);
+        const int widx = mloc >> 2;
         const unsigned char* cbase = lcodes + (t * KGM + 64 * kh + g) * MS;
-        float* zp = zpart + t * 512 + lane;
-        float* zo = p.Z + ((int64_t)i_tok * H + h0 + 4 * g) * D + n16;
-        uint32_t w0[16], w1[16];        // code words of this lane's 16 neighbours for the chunk whose look-ups come next
-        float b0A[16], b1A[16], b0B[16], b1B[16];
-        f32x4 z0, z1;
-#define STAB_WORDS(c_)                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) {                                             \
-        const uint32_t* wp = reinterpret_cast<const uint32_t*>(cbase + 4 * ks * MS + MPC * (c_));   \
-        w0[ks] = wp[widx[0]];                                                                        \
-        w1[ks] = MPC == 4 ? w0[ks] : wp[widx[1]];                                                    \
+        float* zb = zpart + t * 512 + lane;                 // [2 tiles][4][32] partial sums of the kh = 1 wave
+        uint32_t w[16];                 // code words of this lane's 16 neighbours for the chunk whose look-ups come next
+        f32x2 b[16];
+        f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) w[ks] = reinterpret_cast<const uint32_t*>(cbase + 4 * ks * MS)[widx];
+        // (parking the chunk's 8 x 32 sums in LDS to leave with one 16-B store per lane instead of four 8-B stores
+        //  measured slower: 982 vs 962 us per 8192 tokens)
+        float* zo = p.Z + ((int64_t)i_tok * H + h0 + 4 * g) * D + DSUB * mloc + 2 * dp;
+#define STAB_ZSTORE(c_)                                                                              \
+    if (kh == 0 && g < 2 && live && !STAB_OFF(64)) {                                                 \
+        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                            \
+            if (h0 + 4 * g + rr < H)                                                                 \
+                *reinterpret_cast<float2*>(zo + (int64_t)rr * D + (c_) * CD) =                       \
+                    make_float2(z0[rr] + zb[32 * rr], z1[rr] + zb[128 + 32 * rr]);                   \
     }
-    // Two VALU operations per look-up (v_bfe_u32 + v_lshl_add_u32 on integer LDS addresses): the compiler's own
-    // address arithmetic took five and made the VALU, not the matrix pipe, the longest chain of this pass.
-#define STAB_LOOK2(c_, S)      /* the look-ups ARE the B operands */                                 \
-    {                                                                                                \
-        const unsigned sb0_ = lbase[0] + ((c_) & 1) * (TABF * 4), sb1_ = lbase[1] + ((c_) & 1) * (TABF * 4); \
-        _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) {                                         \
-            const unsigned c0 = GNNLM_STAB_EXP == 3 ? 0u : __builtin_amdgcn_ubfe(w0[ks], shift[0], 8u); \
-            const unsigned c1 = GNNLM_STAB_EXP == 3 ? 0u : __builtin_amdgcn_ubfe(w1[ks], shift[1], 8u); \
-            b0##S[ks] = *(lds_cfloat_t*)(uintptr_t)((c0 << ROWSH) + sb0_);                           \
-            b1##S[ks] = *(lds_cfloat_t*)(uintptr_t)((c1 << ROWSH) + sb1_);                           \
-        }                                                                                            \
-    }
-    // A wave can have 15 LDS operations in flight (lgkmcnt is 4 bits) and issues in order: 48 look-ups placed in front of
-    // the 32 MFMAs are a latency chain the matrix pipe waits behind, whatever chunk they belong to.  So the step
-    // interleaves: per k step, the two look-ups of chunk c + 1 (+ the code word of chunk c + 2), then the two MFMAs
-    // of chunk c; the sched_barrier pins that order.  Past the last chunk the look-ups run on a clamped index (unused).
-#define STAB_STEP2(c_, CUR, NXT)                                                                     \
-    {                                                                                                \
-        if ((c_) + 2 < NCH && GNNLM_STAB_EXP != 4) STAB_DMA((c_) + 2, (c_) & 1)                      \
-        const unsigned sb0_ = lbase[0] + (((c_) + 1) & 1) * (TABF * 4), sb1_ = lbase[1] + (((c_) + 1) & 1) * (TABF * 4); \
-        const unsigned char* cw_ = cbase + MPC * min((c_) + 2, NCH - 1);                             \
-        z0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                              \
-        z1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) {                                         \
-            const unsigned c0 = GNNLM_STAB_EXP == 3 ? 0u : __builtin_amdgcn_ubfe(w0[ks], shift[0], 8u); \
-            const unsigned c1 = GNNLM_STAB_EXP == 3 ? 0u : __builtin_amdgcn_ubfe(w1[ks], shift[1], 8u); \
-            b0##NXT[ks] = *(lds_cfloat_t*)(uintptr_t)((c0 << ROWSH) + sb0_);                         \
-            b1##NXT[ks] = *(lds_cfloat_t*)(uintptr_t)((c1 << ROWSH) + sb1_);                         \
-            const uint32_t* wp = reinterpret_cast<const uint32_t*>(cw_ + 4 * ks * MS);               \
-            w0[ks] = wp[widx[0]];                                                                    \
-            w1[ks] = MPC == 4 ? w0[ks] : wp[widx[1]];                                                \
-            if (GNNLM_STAB_EXP != 2 && GNNLM_STAB_EXP != 8) {                                        \
-                z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b0##CUR[ks], z0, 0, 0, 0);      \
-                z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b1##CUR[ks], z1, 0, 0, 0);      \
-            } else {                                                                                 \
-                asm volatile("" :: "v"(b0##CUR[ks]), "v"(b1##CUR[ks]));                              \
-            }                                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                       \
-        }                                                                                            \
-        /* C layout: z[rr] = Z[head 4 g + rr][dim 32 c + 16 ct + n16]; heads 8..15 (g >= 2) are padding */ \
-        float* zb = zp + ((c_) & 1) * 256;                                                           \
-        if (kh == 1 && g < 2) {                                                                      \
-            _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) { zb[32 * rr] = z0[rr]; zb[128 + 32 * rr] = z1[rr]; } \
-        }                                                                                            \
-        STAB_LAND();                                                                                 \
-        __syncthreads();        /* partial sums of the other half written; chunk c + 2 landed; look-ups of c + 1 done */ \
-        if (kh == 0 && g < 2 && live && GNNLM_STAB_EXP != 7) {                                       \
-            _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                        \
-                if (h0 + 4 * g + rr < H) {                                                           \
-                    zo[(int64_t)rr * D + (c_) * CD] = z0[rr] + zb[32 * rr];                          \
-                    zo[(int64_t)rr * D + (c_) * CD + 16] = z1[rr] + zb[128 + 32 * rr];               \
-                }                                                                                    \
-        }                                                                                            \
-    }
-        STAB_WORDS(0)
-        STAB_LOOK2(0, A)
-        if (NCH > 1) STAB_WORDS(1)
-        __syncthreads();                // every wave's look-ups of chunk 0 are done before step 0 refills buffer 0
-        for (int c = 0; c < NCH; c += 2) {
-            STAB_STEP2(c, A, B)
-            if (c + 1 < NCH) STAB_STEP2(c + 1, B, A)
+        if (grp) STAB_PHASE()                                          // B starts one phase late
+        for (int c = 0; c < NCH; ++c) {
+            // ---------------- L(c): look-ups of chunk c; the partial sums of chunk c - 1 meet and leave
+            if (c > 0) STAB_ZSTORE(c - 1)
+            {
+                const unsigned sb = lbase + (c & 1) * (TABF * 4);
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {                      // the look-ups ARE the B operands
+                    const unsigned cc = STAB_OFF(4) ? 0u : __builtin_amdgcn_ubfe(w[ks], shift, 8u);
+                    if (STAB_OFF(128)) b[ks] = f32x2{(float)cc, 1.f};
+                    else b[ks] = *(lds_cfloat2_t*)(uintptr_t)((cc << ROWSH) + sb);
+                }
+                if (c + 1 < NCH) {
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks)
+                        w[ks] = reinterpret_cast<const uint32_t*>(cbase + 4 * ks * MS + MPC * (c + 1))[widx];
+                }
+                STAB_PHASE()
+            }
+            // ---------------- M(c)
+            z0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            z1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if (!STAB_OFF(2)) {
+                    z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[ks].x, z0, 0, 0, 0);
+                    z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[ks].y, z1, 0, 0, 0);
+                } else {
+                    asm volatile("" :: "v"(b[ks].x), "v"(b[ks].y));
+                }
+            }
+            // C layout: z<ct>[rr] = Z[head 4 g + rr][dim of column n16 of tile ct]; heads 8..15 (g >= 2) are padding
+            if (kh == 1 && g < 2) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { zb[32 * rr] = z0[rr]; zb[128 + 32 * rr] = z1[rr]; }
+            }
+            STAB_PHASE()
         }
-#undef STAB_WORDS
-#undef STAB_LOOK2
-#undef STAB_STEP2
+        STAB_ZSTORE(NCH - 1)                                           // the last chunk's sums
+#undef STAB_ZSTORE
+        if (!grp) STAB_PHASE()                                         // A finished one phase early
     }
+#if GNNLM_STAB_CLK
+    if (blockIdx.x < 256 && tid == 0 && p.has_nb) {   // T >= 2048
+        const long long clk4 = STAB_CLK();
+        unsigned* o = reinterpret_cast<unsigned*>(p.has_nb) + blockIdx.x * 8;
+        o[0] = (unsigned)(clk1 - clk0); o[1] = (unsigned)(clk2 - clk1); o[2] = (unsigned)(clk3 - clk2); o[3] = (unsigned)(clk4 - clk3);
+    }
+#endif
 #undef STAB_DMA
+#undef STAB_LOADER_SWEEP
+#undef STAB_DMA_PIECES
+#undef STAB_PHASE
 #undef STAB_LAND
+#undef STAB_CLK
 }
 
 }  // namespace
