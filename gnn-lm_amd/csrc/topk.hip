@@ -15,10 +15,6 @@
 namespace gnnlm {
 namespace {
 
-struct Item {
-    float v;
-    int64_t id;
-};
 // true if a ranks before b
 __device__ __forceinline__ bool before(float av, int64_t ai, float bv, int64_t bi) { return av > bv || (av == bv && ai < bi); }
 
@@ -105,6 +101,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(TopkParams p) {
 
     const float* srow = p.scores + row * p.ld;
     const int ncols = p.row_ncols ? min(p.ncols, p.row_ncols[row]) : p.ncols;
+    static_assert(KP >= NT, "a sub-block of NT columns must fit the candidate half");
     constexpr int SB = KP / 2 >= NT ? KP / 2 : NT;                      // columns per sub-block: at most SB new candidates
     for (int c0 = 0; c0 < ncols; c0 += SB) {
         if (cnt + SB > KP) flush();                                     // uniform: cnt is read after a barrier
@@ -147,8 +144,7 @@ int topk_merge(const gnnlm_topk_t& d, hipStream_t stream) {
         const size_t lds = (size_t)2 * KP * 12;                                                                  \
         hipLaunchKernelGGL((topk_merge_kernel<KP>), grid, block, lds, stream, p);                                \
     }
-    if (d.k <= 64) GNNLM_TOPK_LAUNCH(64)
-    else if (d.k <= 256) GNNLM_TOPK_LAUNCH(256)
+    if (d.k <= 256) GNNLM_TOPK_LAUNCH(256)          // KP >= the 256 columns a sub-block may append
     else if (d.k <= 1024) GNNLM_TOPK_LAUNCH(1024)
     else GNNLM_TOPK_LAUNCH(2048)
 #undef GNNLM_TOPK_LAUNCH

@@ -5,10 +5,12 @@
 Same flags and file format (raw int64 ``[N_split, k]``, ``-1`` = none).  The reference searches a faiss
 ``faiss_store.cosine`` index of the candidate subset with the query subset's keys, WITHOUT normalising
 the queries (find_knn.py:63-65 -- unlike knn_model.py:181-184; ranking by inner product is unaffected by
-the query scale, appendix D.5); only the ids are kept, the distances are dropped (:65-66).  Here the
-search is exact on the GPU (``ExactIndex``: f32-MFMA GEMM + top-k) -- fine for stores whose keys fit in
-HBM next to the similarity tile; a faiss index is used instead when faiss is importable and the index
-file exists.  ``--truncate-to`` reproduces ``knn/truncate_neighbor_file.py:54`` (column truncation).
+the query scale, appendix D.5); the reference keeps only the ids and drops the distances (:65-66) --
+``--save-distances`` also writes them (``distances.mmap.{k}``, raw float32 ``[N_split, k]``; nothing in the
+reference reads that file).  Here the search is exact on the GPU (``ExactIndex``: keys resident in HBM in
+their stored dtype, chunked f32-MFMA GEMM + running top-k, no [n, N] matrix); a faiss index is used
+instead when faiss is importable and the index file exists.  ``--truncate-to`` reproduces
+``knn/truncate_neighbor_file.py:54`` (column truncation).
 """
 import argparse
 import logging
@@ -35,6 +37,7 @@ def get_parser():
     p.add_argument("--k", type=int, default=32)
     p.add_argument("--bsz", type=int, default=1024)
     p.add_argument("--truncate-to", type=int, nargs="*", default=[], help="also write neighbors.mmap.{k'} for k' < k")
+    p.add_argument("--save-distances", action="store_true", help="also write distances.mmap.{k} (float32)")
     return p
 
 
@@ -61,12 +64,20 @@ def main(args):
     index = open_index(args, device)
     out_file = neighbor_path(args.data_dir, args.subset, args.k)
     out = np.memmap(out_file, mode="w+", shape=(ds.dstore_size, args.k), dtype=np.int64)
+    dist = None
+    if args.save_distances:
+        dist = np.memmap(os.path.join(os.path.dirname(out_file), f"distances.mmap.{args.k}"), mode="w+",
+                         shape=(ds.dstore_size, args.k), dtype=np.float32)
     for start in range(0, ds.dstore_size, args.bsz):
         end = min(start + args.bsz, ds.dstore_size)
         q = np.asarray(ds.keys[start:end]).astype(np.float32)                    # not normalised, as written
-        _, knns = index.search(q, args.k)
+        d, knns = index.search(q, args.k)
         out[start:end] = knns
+        if dist is not None:
+            dist[start:end] = d
     out.flush()
+    if dist is not None:
+        dist.flush()
     for k2 in args.truncate_to:
         assert k2 < args.k
         t = np.memmap(neighbor_path(args.data_dir, args.subset, k2), mode="w+", shape=(ds.dstore_size, k2), dtype=np.int64)

@@ -25,28 +25,64 @@ LOGGING = logging.getLogger(__name__)
 
 class ExactIndex:
     """Exact top-k search on the device with faiss's ``search`` contract (IP: larger = closer, returned
-    descending; L2: squared distances ascending).  The similarity matrix runs on the f32 MFMA GEMM."""
+    descending; L2: squared distances ascending; missing results padded with id -1).
 
-    def __init__(self, keys, metric="ip", cosine=False, device="cuda"):
-        k = torch.as_tensor(np.array(keys)).to(device, torch.float32)
-        if cosine:
-            k = k / (k ** 2).sum(-1, keepdim=True).sqrt()                 # index_builder.py:90-95,118
-        self.keys, self.metric = k.contiguous(), metric
-        self.ntotal = k.shape[0]
+    Scales with the store: the keys stay in HBM in their stored dtype (fp16 ``keys.npy`` is read in place, no f32
+    copy of the table), the search walks them in chunks -- chunk -> f32 (one conversion pass, ~2 % of the chunk's
+    GEMM) -> scores of the chunk on the f32 MFMA GEMM -> ``gnnlm_topk_merge`` folds them into the running top-k.
+    Neither the [n, N] score matrix nor a sort of it ever exists.  Cosine: the per-key 1/|key| is a column scale of
+    the merge (index_builder.py:90-95,118 normalises the keys it adds)."""
+
+    def __init__(self, keys, metric="ip", cosine=False, device="cuda", chunk_rows=65536, score_bytes=256 << 20):
+        self.metric, self.cosine, self.device = metric, cosine, torch.device(device)
+        self.chunk_rows, self.score_bytes = chunk_rows, score_bytes
+        if isinstance(keys, torch.Tensor):
+            self.keys = keys.to(self.device).contiguous()
+        else:                                               # numpy array / memmap: upload piecewise, dtype kept
+            n, d = keys.shape
+            dt = torch.float16 if keys.dtype == np.float16 else torch.float32
+            self.keys = torch.empty(n, d, dtype=dt, device=self.device)
+            step = max(1, (256 << 20) // max(1, d * keys.dtype.itemsize))
+            for r0 in range(0, n, step):
+                self.keys[r0:r0 + step] = torch.from_numpy(np.ascontiguousarray(keys[r0:r0 + step])).to(self.device)
+        self.ntotal, self.d = self.keys.shape
+        self.col_scale = self.col_bias = None
+        if cosine or metric == "l2":                        # one pass over the keys: |key|^2
+            n2 = torch.empty(self.ntotal, device=self.device, dtype=torch.float32)
+            for r0 in range(0, self.ntotal, chunk_rows):
+                n2[r0:r0 + chunk_rows] = (self._chunk(r0) ** 2).sum(-1)
+            if cosine:
+                self.col_scale = n2.rsqrt()
+            if metric == "l2":
+                self.col_bias = n2 * self.col_scale ** 2 if cosine else n2
+
+    def _chunk(self, r0):
+        kc = self.keys[r0:r0 + self.chunk_rows]
+        return ops.half_to_float(kc) if kc.dtype == torch.float16 else kc
 
     def search_device(self, q, k):
-        q = q.to(self.keys.device, torch.float32).contiguous()
-        ip = ops.gemm_nt(q, self.keys)
-        if self.metric == "ip":
-            d, i = torch.topk(ip, min(k, self.ntotal), dim=1, largest=True, sorted=True)
-        else:
-            l2 = (q ** 2).sum(-1, keepdim=True) + (self.keys ** 2).sum(-1)[None, :] - 2 * ip
-            d, i = torch.topk(l2, min(k, self.ntotal), dim=1, largest=False, sorted=True)
-        if i.shape[1] < k:                                               # faiss pads with -1
-            pad = k - i.shape[1]
-            i = torch.nn.functional.pad(i, (0, pad), value=-1)
-            d = torch.nn.functional.pad(d, (0, pad), value=float("-inf") if self.metric == "ip" else float("inf"))
-        return d, i
+        q = q.to(self.device, torch.float32).contiguous()
+        n = q.shape[0]
+        val = torch.empty(n, k, device=self.device, dtype=torch.float32)
+        idx = torch.empty(n, k, device=self.device, dtype=torch.int64)
+        ip = self.metric == "ip"
+        qb = max(1, min(n, self.score_bytes // (4 * min(self.chunk_rows, max(self.ntotal, 1)))))
+        for q0 in range(0, n, qb):
+            qs, vs, ids = q[q0:q0 + qb], val[q0:q0 + qb], idx[q0:q0 + qb]
+            for r0 in range(0, max(self.ntotal, 1), self.chunk_rows):
+                kc = self._chunk(r0)
+                if kc.shape[0] == 0:
+                    s = torch.empty(qs.shape[0], 0, device=self.device, dtype=torch.float32)
+                else:
+                    s = ops.gemm_nt(qs, kc)
+                sl = slice(r0, r0 + kc.shape[0])
+                ops.topk_merge(s, vs, ids, col0=r0,
+                               col_scale=None if self.col_scale is None else self.col_scale[sl],
+                               col_bias=None if self.col_bias is None else self.col_bias[sl],
+                               alpha=1.0 if ip else -2.0, largest=ip, init=(r0 == 0))
+        if not ip:
+            val += (q ** 2).sum(-1, keepdim=True)           # |q|^2 + |k|^2 - 2 q.k
+        return val, idx
 
     def search(self, queries, k):
         d, i = self.search_device(torch.as_tensor(np.asarray(queries)), k)
@@ -102,6 +138,18 @@ class KNNModel(object):
         base = "l2" if self.metric_type.endswith("l2") else "ip"
         return ExactIndex(self.keys, base, self.cosine, self.device)
 
+    def _keys_device(self):
+        if isinstance(getattr(self.index, "keys", None), torch.Tensor):
+            return self.index.keys
+        if isinstance(self.keys, torch.Tensor):
+            return self.keys
+        need = self.dstore_size * self.hidden_size * (2 if self.dstore_fp16 else 4)
+        free = torch.cuda.mem_get_info(self.device)[0]
+        if need > 0.9 * free:
+            raise MemoryError(f"--knn-sim-func {self.metric_type} recomputes similarities from the keys: {need / 2**30:.0f} GiB "
+                              f"do not fit in the {free / 2**30:.0f} GiB of free HBM; use do_not_recomp_* or shard the store")
+        return self.data_store.keys_to_device(self.device)
+
     def vals_device(self):
         if self._vals_dev is None:
             self._vals_dev = self.data_store.vals_to_device(self.device)
@@ -128,14 +176,12 @@ class KNNModel(object):
             return -1 * dists
         if fn == "do_not_recomp_ip":
             return dists
-        idx = knns.clamp(min=0)
-        if isinstance(self.keys, torch.Tensor):
-            vecs = self.keys[idx].float()
-        else:                                             # host memmap, as the reference (:163,170)
-            vecs = torch.from_numpy(np.asarray(self.keys)[idx.cpu().numpy()].astype(np.float32)).to(queries.device)
-            neg = (knns < 0).cpu().numpy()
-            if neg.any():                                 # numpy wraps -1 to the last row
-                vecs[knns < 0] = torch.from_numpy(np.asarray(self.keys[-1]).astype(np.float32)).to(queries.device)
+        # the recomputed similarities gather key rows: from HBM (the exact index's table, or the store's keys uploaded
+        # once -- the reference's per-query np.memmap gather on the host, :163,170, is what this replaces); numpy's
+        # negative-index wrap of the -1 padding is kept (row N - 1)
+        keys_dev = self._keys_device()
+        idx = torch.where(knns < 0, knns + keys_dev.shape[0], knns)
+        vecs = keys_dev[idx].float()
         if fn == "l2":
             return -1 * torch.sum((queries[:, None, :] - vecs) ** 2, dim=2)
         if fn == "ip":

@@ -272,6 +272,33 @@ def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_sto
     return out, pk, rec
 
 
+def topk_merge(scores, best_val, best_id, col0=0, col_ids=None, col_scale=None, col_bias=None, alpha=1.0, largest=True,
+               init=False, row_ncols=None):
+    """Fold the score chunk ``scores`` [n, ncols] into the running top-k state (``best_val`` f32 / ``best_id`` i64
+    [n, k], best first): value of column c = col_bias[c] + alpha * col_scale[c] * scores[:, c], id = col_ids[c] or
+    col0 + c.  In place; ``init=True`` treats the state as empty (first chunk)."""
+    _dev(scores, best_val, best_id, col_ids, col_scale, col_bias, row_ncols)
+    _f32(scores, best_val, col_scale, col_bias)
+    _dtype(best_id, torch.int64, "best_id"), _dtype(col_ids, torch.int64, "col_ids"), _dtype(row_ncols, torch.int32, "row_ncols")
+    n, ncols = scores.shape
+    assert best_val.shape == best_id.shape and best_val.shape[0] == n and best_val.is_contiguous() and best_id.is_contiguous()
+    d = _lib.gnnlm_topk_t()
+    d.scores, d.ld, d.n, d.ncols = scores.data_ptr(), scores.stride(0), n, ncols
+    d.col0 = col0
+    if col_ids is not None:
+        d.col_ids = col_ids.data_ptr()
+    if col_scale is not None:
+        d.col_scale = col_scale.data_ptr()
+    if col_bias is not None:
+        d.col_bias = col_bias.data_ptr()
+    if row_ncols is not None:
+        d.row_ncols = row_ncols.data_ptr()
+    d.alpha, d.k, d.largest, d.init = alpha, best_val.shape[1], int(largest), int(init)
+    d.best_val, d.best_id = best_val.data_ptr(), best_id.data_ptr()
+    call_desc("gnnlm_topk_merge", d)
+    return best_val, best_id
+
+
 def masked_sum_f64(x, mask=None, acc=None):
     if acc is None:
         acc = torch.zeros(1, device=x.device, dtype=torch.float64)

@@ -1,0 +1,97 @@
+"""On-device kNN search: the running top-k merge kernel and the chunked exact index against a
+stable argsort / the oracle's brute-force search (knn/knn_model.py:87-101 contract: best first, -1 padding)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import knn as oknn
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def ref_topk(vals, ids, k, largest):
+    """Stable selection: better value first, ties by ascending id."""
+    key = -vals if largest else vals
+    order = np.lexsort((ids, key), axis=-1) if vals.ndim == 1 else np.stack([np.lexsort((ids[r], key[r])) for r in range(len(vals))])
+    top = order[..., :k]
+    return np.take_along_axis(vals, top, -1), np.take_along_axis(ids, top, -1)
+
+
+@pytest.mark.parametrize("k", [8, 70, 256, 1024, 1500])
+@pytest.mark.parametrize("largest", [True, False])
+def test_topk_merge_chunked(dev, k, largest):
+    from gnnlm_amd import ops
+    rs = np.random.RandomState(k + largest)
+    n, N = 37, 9000
+    scores = rs.randn(n, N).astype(np.float32)
+    scores[:, ::50] = scores[:, 1::50]                                   # exact ties across columns
+    scale = rs.uniform(0.5, 2.0, N).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    alpha = -2.0 if not largest else 0.7
+    val = np.float32(alpha) * scores * scale[None] + bias[None]
+    ids = np.tile(np.arange(N, dtype=np.int64) + 1000, (n, 1))
+    v_ref, i_ref = ref_topk(val, ids, k, largest)
+    bv = torch.empty(n, k, device=dev)
+    bi = torch.empty(n, k, device=dev, dtype=torch.int64)
+    s_dev = torch.from_numpy(scores).to(dev)
+    edges = [0, 1, 700, 701, 4096, 8999, N]                               # ragged chunks, incl. 1-column ones
+    for a, b in zip(edges[:-1], edges[1:]):
+        ops.topk_merge(s_dev[:, a:b], bv, bi, col0=1000 + a, col_scale=torch.from_numpy(scale[a:b]).to(dev),
+                       col_bias=torch.from_numpy(bias[a:b]).to(dev), alpha=alpha, largest=largest, init=(a == 0))
+    assert np.array_equal(bi.cpu().numpy(), i_ref)                        # ids: exact, ties by ascending id
+    np.testing.assert_allclose(bv.cpu().numpy(), v_ref, rtol=1e-6, atol=1e-6)
+
+
+def test_topk_merge_fewer_than_k_and_explicit_ids(dev):
+    from gnnlm_amd import ops
+    rs = np.random.RandomState(3)
+    n, N, k = 5, 40, 64
+    scores = rs.randn(n, N).astype(np.float32)
+    col_ids = rs.permutation(10_000_000_000 + np.arange(N)).astype(np.int64)     # ids beyond int32
+    col_ids[7] = -1                                                       # skipped column
+    ncols = np.array([40, 0, 13, 40, 1], dtype=np.int32)                  # ragged rows
+    bv = torch.full((n, k), 123.0, device=dev)
+    bi = torch.full((n, k), 77, device=dev, dtype=torch.int64)
+    ops.topk_merge(torch.from_numpy(scores).to(dev), bv, bi, col_ids=torch.from_numpy(col_ids).to(dev), largest=True, init=True,
+                   row_ncols=torch.from_numpy(ncols).to(dev))
+    bv, bi = bv.cpu().numpy(), bi.cpu().numpy()
+    for r in range(n):
+        ok = (np.arange(N) < ncols[r]) & (col_ids >= 0)
+        v, i = ref_topk(scores[r][ok], col_ids[ok], k, True)
+        m = ok.sum()
+        assert np.array_equal(bi[r, :m], i) and (bi[r, m:] == -1).all()   # faiss pads with -1
+        np.testing.assert_allclose(bv[r, :m], v)
+        assert np.isneginf(bv[r, m:]).all()
+
+
+@pytest.mark.parametrize("metric,cosine", [("ip", False), ("ip", True), ("l2", False)])
+def test_exact_index_chunked_fp16_store(dev, metric, cosine):
+    """200k fp16 keys searched in 7 chunks x 2 query blocks == the oracle's brute force over the whole table."""
+    from gnnlm_amd.knn_model import ExactIndex
+    rs = np.random.RandomState(5)
+    N, d, n, k = 200_000, 64, 300, 100
+    keys = rs.randn(N, d).astype(np.float16)
+    q = rs.randn(n, d).astype(np.float32)
+    idx = ExactIndex(keys, metric, cosine, dev, chunk_rows=30_000, score_bytes=4 * 30_000 * 160)
+    assert idx.keys.dtype == torch.float16                                # read in place, no f32 copy of the table
+    d_got, i_got = idx.search(q, k)
+    d_ref, i_ref = oknn.brute_force_search(q, keys, k, metric, cosine)
+    # float32 scores of near-equal candidates may swap ranks: compare as sets with a small allowance, values tightly
+    same = np.mean([len(set(a) & set(b)) / k for a, b in zip(i_got, i_ref)])
+    assert same > 0.999, same
+    np.testing.assert_allclose(d_got, d_ref, rtol=2e-4, atol=2e-4)
+    assert (np.diff(d_got, axis=1) <= 1e-6).all() if metric == "ip" else (np.diff(d_got, axis=1) >= -1e-6).all()
+
+
+def test_exact_index_small_store_pads(dev):
+    from gnnlm_amd.knn_model import ExactIndex
+    rs = np.random.RandomState(1)
+    keys = rs.randn(5, 16).astype(np.float32)
+    d, i = ExactIndex(keys, "ip", False, dev).search(rs.randn(3, 16).astype(np.float32), 8)
+    assert (i[:, 5:] == -1).all() and (np.sort(i[:, :5], 1) == np.arange(5)).all()
