@@ -66,6 +66,9 @@ def parse():
                     help="GEMM arithmetic: f32 = native f32 MFMA (headline, the reference's precision); bf16x3 / bf16x6 = "
                          "opt-in split-bf16 emulation of the f32 product on the bf16 MFMA (max |dlogp| vs f32 is reported)")
     ap.add_argument("--shard-vals", action="store_true", help="also range-shard the label table (default: replicated)")
+    ap.add_argument("--exchange", choices=["padded", "exact"], default="padded",
+                    help="sharded store: fixed-capacity sync-free exchange (2 all-to-alls, no host round trip; dropped rows are "
+                         "checked for after the run) or the exact variable-split one (3 all-to-alls, 2 host syncs per table)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the sharded-store exchange even with one rank (exercises the RCCL path on one GPU)")
     return ap.parse_args()
@@ -405,7 +408,7 @@ def main():
     from gnnlm_amd.dist import ShardedFetcher
     eng, shard, sharded, cpu_model, (d, vocab) = build(args, dev, rank, world)
     batches = make_batches(args, dev, rank, d, vocab)
-    fetcher = ShardedFetcher(eng.store, shard) if sharded else None
+    fetcher = ShardedFetcher(eng.store, shard, mode=args.exchange) if sharded else None
     centres_only = args.layers == 1
     acc = torch.zeros(1, device=dev, dtype=torch.float64)
 
@@ -425,7 +428,10 @@ def main():
         torch.cuda.set_stream(compute_stream)
     pending = {}
 
+    n_fetches = [0]
+
     def issue_fetch(bi):
+        n_fetches[0] += 1
         b = batches[bi % len(batches)]
         with torch.cuda.stream(fetch_stream):
             codes, valid, index = fetcher.fetch_codes(b.ids, 2, 2, centres_only)
@@ -533,6 +539,38 @@ def main():
         prof = _lib.profile_end()[dominant]
     for a in accs[1:]:
         acc += a
+    link_bytes_per_step = replicated = None
+    if fetcher is not None:
+        fetcher.check()                                           # no request was dropped by the fixed-capacity buckets
+        link_bytes_per_step = fetcher.link_bytes / max(1, n_fetches[0])
+        # the same steps on a REPLICATED store (every rank holds the whole table, no exchange): what the sharding costs
+        from gnnlm_amd.engine import GnnLmEngine
+        from gnnlm_amd.hgt import CodeStore
+        from gnnlm_amd.synthetic import device_codes
+        st = eng.store
+        full = st.codes if st.codes.shape[0] == args.n_store else device_codes(args.n_store, st.codes.shape[1], dev, 1234)
+        vfull = st.vals if st.vals.shape[0] == args.n_store else None
+        if vfull is not None:
+            eng_r = GnnLmEngine(eng.hgt, eng.asm, CodeStore(codes=full, centroids=st.centroids, n_store=args.n_store, row0=0,
+                                                            vals=vfull, A=st.A, b=st.b), 2, 2)
+            for b_ in batches:
+                b_.fetched_codes = b_.fetched_valid = b_.fetched_index = b_.knn_vals = None
+                b_.fetched_centres_only = False
+            acc_r = torch.zeros(1, device=dev, dtype=torch.float64)
+            run_r = lambda i: ops.masked_sum_f64(eng_r.score(batches[i % len(batches)], args.lmbda, args.temperature)["logp"], None, acc_r)
+            run_r(0)
+            barrier()
+            t0r = time.perf_counter()
+            for i in range(args.steps):
+                run_r(i)
+            barrier()
+            dtr = time.perf_counter() - t0r
+            if world > 1:
+                ttr = torch.tensor([dtr], device=dev, dtype=torch.float64)
+                dist.all_reduce(ttr, op=dist.ReduceOp.MAX)
+                dtr = ttr.item()
+            replicated = {"tokens_per_s": round(args.steps * args.blocks * args.tokens_per_sample * world / dtr, 1),
+                          "ms_per_step": round(dtr / args.steps * 1e3, 4)}
     recipe = drv = None
     if rank == 0 and world == 1 and fetcher is None and not args.small and args.extras:
         if args.layers == 1 and args.precision == "f32":
@@ -581,6 +619,10 @@ def main():
                        "gcn_k": args.gcn_k, "knn_k": args.k, "hgt_layers": args.layers, "d": d, "vocab": vocab,
                        "lmbda": args.lmbda, "temperature": args.temperature,
                        "store": ("range-sharded + RCCL all-to-all" if sharded else "replicated" if world > 1 else "single GPU"),
+                       "rccl_ranks": world if dist.is_initialized() else 0,
+                       "exchange": (args.exchange if sharded else None),
+                       "xgmi_bytes_per_step_per_rank": (round(link_bytes_per_step) if link_bytes_per_step is not None else None),
+                       "replicated_store": replicated,
                        "gemm_precision": args.precision, "max_abs_dlogp_vs_f32": dlogp,
                        "synthetic_ppl": round(float(2 ** (-score_sum / tokens / np.log(2))), 4)},
             "roofline": r,

@@ -106,6 +106,7 @@ def lib():
         L.gnnlm_lse_reduce.argtypes = [vp, i32, i64, vp, vp, vp]
         L.gnnlm_pq_encode.argtypes = [vp, i64, vp, vp, i32, i32, i64, vp, vp]
         L.gnnlm_bucket_rows.argtypes = [vp, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp]
+        L.gnnlm_bucket_rows_padded.argtypes = [vp, i64, i64, i64, i32, i64, vp, vp, vp, vp, vp]
         L.gnnlm_adaptive_workspace_bytes.argtypes = [vp, i64]
         L.gnnlm_adaptive_target_logp.argtypes = [vp, vp, i64, vp, i64, vp, vp, ctypes.c_size_t, vp]
         L.gnnlm_masked_sum_f64.argtypes = [vp, vp, i64, vp, vp]

@@ -444,6 +444,10 @@ int gnnlm_bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t r
                       int32_t self_rank, int64_t* counts, int64_t* cursor, int64_t* send_rows, int32_t* inv, void* stream) {
     return bucket_rows(rows, n, n_store, rows_per_rank, world, self_rank, counts, cursor, send_rows, inv, (hipStream_t)stream);
 }
+int gnnlm_bucket_rows_padded(const int64_t* rows, int64_t n, int64_t n_store, int64_t rows_per_rank, int32_t world,
+                             int64_t cap, int64_t* cursor, int64_t* send_rows, int32_t* inv, int64_t* overflow, void* stream) {
+    return bucket_rows_padded(rows, n, n_store, rows_per_rank, world, cap, cursor, send_rows, inv, overflow, (hipStream_t)stream);
+}
 int gnnlm_pq_gather_decode(const gnnlm_gather_t* d, void* stream) { GNNLM_DESC(d); return gather_decode(*d, (hipStream_t)stream); }
 int gnnlm_star_attn(const gnnlm_star_attn_t* d, void* stream) { GNNLM_DESC(d); return star_attn(*d, (hipStream_t)stream); }
 int gnnlm_chain_attn(const gnnlm_chain_attn_t* d, void* stream) { GNNLM_DESC(d); return chain_attn(*d, (hipStream_t)stream); }

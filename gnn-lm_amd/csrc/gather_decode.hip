@@ -192,6 +192,48 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int64_t* rows
     }
 }
 
+// Fixed-capacity variant for the sync-free exchange: owner o's requests go to send_rows[o * cap .. o * cap + cap), the
+// unused tail keeps its -1 prefill, nothing depends on the bucket sizes on the host.  Rows that are not rows of the
+// store are not sent at all; a request that does not fit its bucket is counted in *overflow.  Both get the index
+// world * cap (the all-zero row the requester appends to the returned payload).
+__global__ __launch_bounds__(256) void bucket_scatter_padded_kernel(const int64_t* rows, int64_t n, int64_t n_store, int64_t per,
+                                                                    int world, int64_t cap, unsigned long long* cursor,
+                                                                    int64_t* send_rows, int32_t* inv, unsigned long long* overflow) {
+    __shared__ unsigned int h[64];
+    __shared__ unsigned long long base[64];
+    const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per_block, hi = min(n, lo + per_block);
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int64_t row = rows[i];
+        if (row >= 0 && row < n_store) atomicAdd(&h[owner_of(row, n_store, per, world, 0)], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < world) {
+        base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)h[threadIdx.x]) : 0ull;
+        h[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    unsigned lost = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int64_t row = rows[i];
+        int32_t where = (int32_t)(world * cap);
+        if (row >= 0 && row < n_store) {
+            const int o = owner_of(row, n_store, per, world, 0);
+            const unsigned long long pos = base[o] + atomicAdd(&h[o], 1u);
+            if ((int64_t)pos < cap) {
+                send_rows[o * cap + (int64_t)pos] = row;
+                where = (int32_t)(o * cap + (int64_t)pos);
+            } else {
+                ++lost;
+            }
+        }
+        inv[i] = where;
+    }
+    if (lost) atomicAdd(overflow, (unsigned long long)lost);
+}
+
 __global__ void bucket_prefix_kernel(const unsigned long long* counts, unsigned long long* cursor, int world) {
     if (threadIdx.x == 0) {
         unsigned long long acc = 0;
@@ -213,6 +255,22 @@ int bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t per, in
                        reinterpret_cast<unsigned long long*>(cursor), world);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, stream, rows, n, n_store, per, world, self,
                        reinterpret_cast<unsigned long long*>(cursor), send_rows, inv);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int bucket_rows_padded(const int64_t* rows, int64_t n, int64_t n_store, int64_t per, int world, int64_t cap, int64_t* cursor,
+                       int64_t* send_rows, int32_t* inv, int64_t* overflow, hipStream_t stream) {
+    GNNLM_REQUIRE(world >= 1 && world <= 64 && per > 0 && cap > 0 && n >= 0 && n < (1ll << 31) && world * cap < (1ll << 31) - 1,
+                  "bucket_rows_padded: bad arguments");
+    GNNLM_REQUIRE(cursor && send_rows && overflow, "bucket_rows_padded: null operand");
+    GNNLM_HIP(hipMemsetAsync(cursor, 0, sizeof(int64_t) * world, stream));
+    GNNLM_HIP(hipMemsetAsync(send_rows, 0xFF, sizeof(int64_t) * (size_t)(world * cap), stream));      // -1 everywhere
+    if (n == 0) return OK;
+    GNNLM_REQUIRE(rows && inv, "bucket_rows_padded: null operand");
+    const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 1024), 1024);
+    hipLaunchKernelGGL(bucket_scatter_padded_kernel, dim3(blocks), dim3(256), 0, stream, rows, n, n_store, per, world, cap,
+                       reinterpret_cast<unsigned long long*>(cursor), send_rows, inv, reinterpret_cast<unsigned long long*>(overflow));
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

@@ -6,9 +6,10 @@ is the row fetch from the range-sharded PQ code table / label table:
 
     rank g owns rows [g*per, (g+1)*per)   with per = ceil(n_store / world)
 
-Per step: bucket the requested rows by owner (HIP histogram + scatter, no sort) -> all_to_all of the
-counts -> all_to_all of the row ids (8 B/row) -> every owner gathers its rows with the HIP gather
-kernel -> all_to_all of the payload back (M = 128 B/row of codes).  The payload stays in bucketed order:
+Per step (exact mode): bucket the requested rows by owner (HIP histogram + scatter, no sort) -> all_to_all
+of the counts -> all_to_all of the row ids (8 B/row) -> every owner gathers its rows with the HIP gather
+kernel -> all_to_all of the payload back (M = 128 B/row of codes).  Padded mode (`exchange_fetch_padded`)
+ships fixed-capacity buckets instead: two equal-split all-to-alls, no counts, no host synchronisation.  The payload stays in bucketed order:
 the consumer kernels read row ``index[s]`` for request s, so the 128-B rows are not shuffled again.
 The label table (4 B/row, 413 MB for WikiText-103) is replicated by default -- sharding it would add a
 k = 1024-per-token exchange for 3 % of the store's bytes (``bench.py --shard-vals`` does it anyway).  xGMI is point-to-point
@@ -100,6 +101,65 @@ def exchange_fetch(rows: torch.Tensor, shard: Shard, local_gather: Callable[[tor
     return back[inv.long()]
 
 
+def bucket_capacity(n_requests: int, world: int, slack: float = 1.25) -> int:
+    """Slots per owner of the fixed-capacity exchange: the uniform-id expectation n / world plus `slack` and a
+    constant (a binomial count exceeds 1.25 n/world + 256 with negligible probability from a few thousand requests
+    on), rounded to 64."""
+    cap = int(-(-n_requests // world) * slack) + 256
+    return (cap + 63) // 64 * 64
+
+
+def bucket_padded_torch(rows: torch.Tensor, shard: Shard, cap: int):
+    """Backend-agnostic fixed-capacity bucketing, no host round trip.
+    -> (send [world*cap] i64 with -1 in unused slots, index [S] i32 = slot of request s or world*cap for a request
+    that is not sent (not a row of the store) or did not fit, overflow [1] i64 = requests that did not fit)."""
+    W = shard.world
+    ok_row = (rows >= 0) & (rows < shard.n_store)
+    owner = torch.where(ok_row, shard.owner(rows), torch.full_like(rows, W))          # W: "not sent"
+    order = torch.sort(owner, stable=True).indices
+    counts = torch.bincount(owner, minlength=W + 1)
+    start = torch.cumsum(counts, 0) - counts
+    pos = torch.empty_like(rows)
+    pos[order] = torch.arange(rows.numel(), device=rows.device) - start[owner[order]]
+    fits = ok_row & (pos < cap)
+    index = torch.where(fits, owner * cap + pos, torch.full_like(rows, W * cap))
+    send = torch.full((W * cap + 1,), -1, dtype=rows.dtype, device=rows.device)
+    send[index] = torch.where(fits, rows, torch.full_like(rows, -1))
+    return send[:W * cap].contiguous(), index.to(torch.int32), (ok_row & ~fits).sum().reshape(1)
+
+
+def bucket_padded_hip(rows: torch.Tensor, shard: Shard, cap: int):
+    """The same by the HIP kernel gnnlm_bucket_rows_padded (one scatter pass)."""
+    from . import _lib
+    n, dev, W = rows.numel(), rows.device, shard.world
+    cursor = torch.empty(W, dtype=torch.int64, device=dev)
+    send = torch.empty(W * cap, dtype=torch.int64, device=dev)
+    index = torch.empty(n, dtype=torch.int32, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.call("gnnlm_bucket_rows_padded", _lib.ptr(rows), n, shard.n_store, shard.per, W, cap, _lib.ptr(cursor),
+              _lib.ptr(send), _lib.ptr(index), _lib.ptr(overflow), _lib.stream())
+    return send, index, overflow
+
+
+def exchange_fetch_padded(rows: torch.Tensor, shard: Shard, local_gather: Callable[[torch.Tensor], torch.Tensor], cap: int,
+                          group=None, bucket=bucket_padded_torch):
+    """Sync-free exchange: TWO equal-split all-to-alls (row ids out, payload back), no counts exchange and no host
+    round trip -- the bucket sizes never reach the host.  Every rank sends `cap` slots to every rank (-1 padded;
+    `bucket_capacity` sizes cap from the uniform-id bound, so the padding costs ~25 % more bytes than the exact
+    variable-split exchange above and saves its two stream synchronisations).
+    -> (payload [world*cap + 1, C] whose last row is zeros, index [S] i32, overflow [1] i64): payload[index[s]]
+    answers request s; requests that are not rows of the store, or overflowed their bucket, point at the zero row.
+    A non-zero `overflow` means some rows were NOT fetched: the caller must check it (ShardedFetcher.check)."""
+    rows = rows.reshape(-1).contiguous()
+    send, index, overflow = bucket(rows, shard, cap)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    payload = local_gather(recv).contiguous()                       # [world*cap, ...]; -1 ids give zero rows
+    back = torch.zeros((shard.world * cap + 1,) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
+    dist.all_to_all_single(back[:shard.world * cap], payload, group=group)
+    return back, index, overflow
+
+
 def slot_rows(ids: torch.Tensor, left: int, right: int, n_store: int) -> torch.Tensor:
     """Global row of every slot of every group (centre, o-left..o-1, o+1..o+right); -1 if invalid
     (token_block_dataset.py:358,380-385)."""
@@ -112,10 +172,34 @@ def slot_rows(ids: torch.Tensor, left: int, right: int, n_store: int) -> torch.T
 class ShardedFetcher:
     """Product-side exchange: the owner-side lookup is the HIP gather kernel."""
 
-    def __init__(self, store, shard: Shard, group=None):
+    def __init__(self, store, shard: Shard, group=None, mode: str = "exact", slack: float = 1.25):
+        """mode "exact": variable-split exchange (two host syncs per call, never drops a row);
+        mode "padded": fixed-capacity, sync-free exchange; call :meth:`check` (it synchronises) before trusting a run."""
         from . import ops
         self.ops, self.store, self.shard, self.group = ops, store, shard, group
+        assert mode in ("exact", "padded")
+        self.mode, self.slack = mode, slack
+        self.overflow = None                                # device counter of rows that did not fit (padded mode)
+        self.link_bytes = 0                                 # bytes this rank put on / took off its xGMI links so far
         assert store.row0 == shard.row0 and store.codes.shape[0] == shard.n_local
+
+    def check(self):
+        """Raise if the fixed-capacity exchange dropped requests (skewed ids): rerun with mode='exact' or more slack."""
+        if self.overflow is not None and int(self.overflow.item()) > 0:
+            raise RuntimeError(f"sharded exchange: {int(self.overflow.item())} row requests did not fit their fixed-capacity "
+                               f"buckets (slack {self.slack}); use mode='exact' or a larger slack")
+
+    def _padded(self, rows, gather, row_bytes):
+        W = self.shard.world
+        cap = bucket_capacity(rows.numel(), W, self.slack)
+        back, index, ovf = exchange_fetch_padded(rows, self.shard, gather, cap, self.group, bucket=bucket_padded_hip)
+        self.overflow = ovf if self.overflow is None else self.overflow + ovf
+        self.link_bytes += cap * (W - 1) * 2 * (8 + row_bytes)       # ids out + payload in, and the same served to the peers
+        return back, index, cap
+
+    def _account_exact(self, n_rows, row_bytes):
+        W = self.shard.world
+        self.link_bytes += int(n_rows * (W - 1) / W) * 2 * (8 + row_bytes)     # uniform-id expectation
 
     def _gather_codes(self, rows):
         st = self.store
@@ -132,10 +216,19 @@ class ShardedFetcher:
         for the slots of ``ids`` [n, kg]: slot s lives in row ``fetched_index[s]``."""
         rows = ids.reshape(-1) if centres_only else slot_rows(ids, left, right, self.store.n_store)
         rows = torch.where((rows >= 0) & (rows < self.store.n_store), rows, torch.full_like(rows, -1))
+        if self.mode == "padded":
+            codes, index, cap = self._padded(rows, self._gather_codes, self.store.codes.shape[1])
+            return codes, ((rows >= 0) & (index.long() < self.shard.world * cap)).to(torch.uint8), index
+        self._account_exact(rows.numel(), self.store.codes.shape[1])
         codes, index = exchange_fetch(rows, self.shard, self._gather_codes, self.group, bucket=bucket_hip, unpermute=False)
         return codes, (rows >= 0).to(torch.uint8), index
 
     def fetch_knn_vals(self, knn_ids):
         """vals[knn_ids] with numpy's negative-index wrap for the -1 padding (knn_model.py:198)."""
         rows = torch.where(knn_ids < 0, knn_ids + self.store.n_store, knn_ids).reshape(-1)
+        if self.mode == "padded":
+            back, index, _ = self._padded(rows, self._gather_vals, 4)
+            back[-1] = -1                                    # rows outside the store never match a target
+            return back[index.long()].reshape(knn_ids.shape)
+        self._account_exact(rows.numel(), 4)
         return exchange_fetch(rows, self.shard, self._gather_vals, self.group, bucket=bucket_hip).reshape(knn_ids.shape)

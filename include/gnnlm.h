@@ -303,6 +303,13 @@ int gnnlm_bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t r
                       int32_t self_rank, int64_t* counts, int64_t* cursor, int64_t* send_rows, int32_t* inv,
                       void* stream);
 
+/* Fixed-capacity variant (no host round trip anywhere in the exchange): owner o's requests are written to
+ * send_rows[o*cap, (o+1)*cap), unused slots hold -1 (the call prefills), inv[s] = slot of request s, or world*cap
+ * for a request that is not a row of the store or did not fit its bucket (the latter are counted in *overflow,
+ * which the call ADDS to).  `cursor` is an int64[world] scratch.  Equal-split all-to-alls can then be used. */
+int gnnlm_bucket_rows_padded(const int64_t* rows, int64_t n, int64_t n_store, int64_t rows_per_rank, int32_t world,
+                             int64_t cap, int64_t* cursor, int64_t* send_rows, int32_t* inv, int64_t* overflow, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Opt-in live timing (bench.py's roofline): while a profile is open every launch of the selected
  * kernels is bracketed by HIP events on its own stream.  One profile at a time; launches from several host threads

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gnnlm_amd.dist import Shard, exchange_fetch, slot_rows
+from gnnlm_amd.dist import Shard, bucket_capacity, bucket_padded_torch, exchange_fetch, exchange_fetch_padded, slot_rows
 from oracle import graph as og
 
 
@@ -68,6 +68,25 @@ def _worker(rank, world, port, n_store, M, seed, q):
         # ragged / empty requests
         empty = exchange_fetch(torch.zeros(0, dtype=torch.int64), shard, gather_vals)
         assert empty.numel() == 0
+        # fixed-capacity (sync-free) exchange: same answers; rows that are not rows of the store and overflowed requests
+        # point at the zero row; an empty shard / a rank that receives only padding must not stall its peers
+        for left, right in [(0, 0), (2, 2)]:
+            rows = slot_rows(torch.from_numpy(ids), left, right, n_store)
+            ref_rows, ref_valid = og.slot_layout(ids, n_store, left, right)
+            cap = bucket_capacity(rows.numel(), world)
+            back, index, ovf = exchange_fetch_padded(rows, shard, gather_codes, cap)
+            assert int(ovf) == 0 and back.shape[0] == world * cap + 1 and not back[-1].any()
+            got = back.numpy()[index.numpy()]
+            v = ref_valid.reshape(-1)
+            assert np.array_equal(got[v], codes[ref_rows.reshape(-1)[v]]) and not got[~v].any()
+        # every rank asks the same owner for more than fits: the overflow is counted, the rest is still right
+        own0 = torch.arange(0, min(10, shard.per), dtype=torch.int64)
+        back, index, ovf = exchange_fetch_padded(own0, shard, gather_codes, 4)
+        assert int(ovf) == own0.numel() - 4
+        kept = index.numpy() < world * 4
+        assert kept.sum() == 4 and np.array_equal(back.numpy()[index.numpy()][kept], codes[own0.numpy()[kept]])
+        empty_back, empty_idx, ovf = exchange_fetch_padded(torch.zeros(0, dtype=torch.int64), shard, gather_codes, 64)
+        assert empty_idx.numel() == 0 and int(ovf) == 0
         # final reduction of (score_sum, count) as the eval driver does it
         t = torch.tensor([float(rank + 1), 10.0 * (rank + 1)], dtype=torch.float64)
         dist.all_reduce(t)
@@ -92,6 +111,15 @@ def test_exchange_fetch_gloo(world, n_store):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_bucket_padded_layout():
+    s = Shard(1000, 3, 1)
+    rows = torch.tensor([5, 999, -1, 400, 1000, 333, 334, 700, 2], dtype=torch.int64)
+    send, index, ovf = bucket_padded_torch(rows, s, 2)
+    assert send.tolist() == [5, 333, 400, 334, 999, 700] and ovf.tolist() == [1]          # owner 0 got 3 requests, 2 fit
+    assert index.tolist() == [0, 4, 6, 2, 6, 1, 3, 5, 6]                                  # 6 = the zero row
+    assert bucket_capacity(1_048_576, 8) % 64 == 0 and bucket_capacity(1_048_576, 8) >= 1.25 * 131072
 
 
 def test_shard_geometry():

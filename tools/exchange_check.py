@@ -1,26 +1,44 @@
 #!/usr/bin/env python3
-"""Single-GPU exercise of the sharded-store exchange over RCCL (world size 1): the routing, the HIP
-owner-side gather and the fetched-codes path of the HGT must give the same result as the direct path."""
+"""Exercise of the sharded-store exchange over RCCL: the routing, the HIP owner-side gather and the fetched-codes path
+of the HGT must give the same result as the direct path on a replicated store -- with any number of ranks
+(`python tools/exchange_check.py` = one rank; `python -m torch.distributed.run --nproc-per-node N ...` = N ranks),
+in the exact (variable-split) and the padded (fixed-capacity, sync-free) mode."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 import numpy as np, torch, torch.distributed as dist
-dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 from gnnlm_amd.dist import Shard, ShardedFetcher
+from gnnlm_amd.hgt import CodeStore
 from gnnlm_amd.synthetic import make_problem, build_engine, to_batch
 for L in (1, 2):
     prob = make_problem(n_store=5000, d=64, n_heads=4, M=16, dsub=4, vocab=600, cutoff=[100, 300], T=16, kg=8,
-                        left=2, right=2, n_layers=L, k=32, seed=L, n_blocks=2)
-    eng = build_engine(prob, dev)
+                        left=2, right=2, n_layers=L, k=32, seed=10 * L + rank, n_blocks=2)
+    eng = build_engine(prob, dev)                       # replicated store: the reference
     b = to_batch(prob["block"], dev)
     ref = eng.score(b, 0.25, 0.01)
-    f = ShardedFetcher(eng.store, Shard(prob["n_store"], 1, 0))
-    b.fetched_codes, b.fetched_valid, b.fetched_index = f.fetch_codes(b.ids, 2, 2, centres_only=(L == 1))
-    b.fetched_centres_only = (L == 1)
-    b.knn_vals = f.fetch_knn_vals(b.knn_ids)
-    out = eng.score(b, 0.25, 0.01)
-    torch.cuda.synchronize()
-    assert torch.equal(out["logp"], ref["logp"]) and torch.equal(out["recall"], ref["recall"]), L
-    print("exchange path == direct path, L =", L)
+    shard = Shard(prob["n_store"], world, rank)
+    full = eng.store
+    sl = slice(shard.row0, shard.row0 + shard.n_local)
+    # the table itself is the same on every rank (seeded by L only); the requests differ per rank
+    tab = make_problem(n_store=5000, d=64, n_heads=4, M=16, dsub=4, vocab=600, cutoff=[100, 300], T=16, kg=8, left=2, right=2,
+                       n_layers=L, k=32, seed=10 * L, n_blocks=2)
+    codes = torch.from_numpy(tab["codes"]).to(dev); vals = torch.from_numpy(tab["vals"]).to(dev)
+    full.codes, full.vals = codes, vals                 # direct path on the common table
+    ref = eng.score(b, 0.25, 0.01)
+    part = CodeStore(codes=codes[sl].contiguous(), centroids=full.centroids, n_store=full.n_store, row0=shard.row0,
+                     vals=vals[sl].contiguous(), A=full.A, b=full.b)
+    for mode in ("exact", "padded"):
+        f = ShardedFetcher(part, shard, mode=mode)
+        b.fetched_codes, b.fetched_valid, b.fetched_index = f.fetch_codes(b.ids, 2, 2, centres_only=(L == 1))
+        b.fetched_centres_only = (L == 1)
+        b.knn_vals = f.fetch_knn_vals(b.knn_ids)
+        out = eng.score(b, 0.25, 0.01)
+        torch.cuda.synchronize()
+        f.check()
+        assert torch.equal(out["logp"], ref["logp"]) and torch.equal(out["recall"], ref["recall"]), (L, mode)
+        if rank == 0:
+            print("exchange path == direct path, L =", L, mode, "ranks", world)
 dist.destroy_process_group()
