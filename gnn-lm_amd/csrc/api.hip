@@ -165,8 +165,11 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
     GNNLM_REQUIRE(io.n_blocks >= 0 && io.T >= 0 && io.kg > 0, "hgt: bad io shape");
     if ((int64_t)io.n_blocks * io.T == 0) return OK;                 // empty batch: nothing to do
     GNNLM_REQUIRE(io.tgt_feats && io.ids && io.out_tgt, "hgt: null io");
-    GNNLM_REQUIRE(m.centroids && m.M > 0 && m.dsub > 0, "hgt: codec missing");
-    GNNLM_REQUIRE(io.fetched_codes || m.codes, "hgt: no code store");
+    const bool dense0 = io.ntgt_feats != nullptr;        // layer-0 ntgt states given (input adapters): no code store
+    GNNLM_REQUIRE(dense0 || (m.centroids && m.M > 0 && m.dsub > 0), "hgt: codec missing");
+    GNNLM_REQUIRE(dense0 || io.fetched_codes || m.codes, "hgt: no code store");
+    GNNLM_REQUIRE(!dense0 || (io.ntgt_valid && io.ld_ntgt >= m.d && io.ld_ntgt % 4 == 0 && !io.fetched_codes),
+                  "hgt: ntgt_feats needs ntgt_valid, ld_ntgt >= d (a multiple of 4) and no fetched_codes");
     const bool ntgt = needs_ntgt(m, io);
     GNNLM_REQUIRE(!(io.fetched_centres_only && ntgt), "hgt: fetched_centres_only needs n_layers == 1 and no out_ntgt");
     GNNLM_REQUIRE(!io.fetched_codes || io.fetched_valid || io.fetched_centres_only, "hgt: fetched_codes needs fetched_valid");
@@ -174,10 +177,10 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
     if (Tt == 0) return OK;
     const int d = m.d, H = m.n_heads, dk = d / H, T = io.T, kg = io.kg, nb = io.n_blocks;
     const int n_g = 1 + m.left + m.right;
-    const int dpq = m.M * m.dsub;
+    const int dpq = dense0 ? d : m.M * m.dsub;
     const int64_t G = Tt * kg, S = G * n_g;
     GNNLM_REQUIRE(dk % 4 == 0 && d % 4 == 0 && dpq % 4 == 0, "hgt: d_k and the PQ dimension must be multiples of 4");
-    GNNLM_REQUIRE(m.opq_at || dpq == d, "hgt: without OPQ the PQ dimension must equal d");
+    GNNLM_REQUIRE(dense0 || m.opq_at || dpq == d, "hgt: without OPQ the PQ dimension must equal d");
 
     Carver c(ws, ws_bytes);
     HgtBufs b;
@@ -186,8 +189,14 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
     const int64_t Tp = b.Tp;
 
     const float* hn_cur = nullptr;
+    int64_t ld_hn = d;                                   // row stride of hn_cur (the caller's buffer in the dense0 case)
     const uint8_t* valid = nullptr;
-    if (ntgt) {
+    if (dense0) {
+        hn_cur = io.ntgt_feats;
+        ld_hn = io.ld_ntgt;
+        valid = io.ntgt_valid;
+        if (io.out_valid) GNNLM_HIP(hipMemcpyAsync(io.out_valid, valid, (size_t)S, hipMemcpyDeviceToDevice, s));
+    } else if (ntgt) {
         // layer-0 ntgt states: PQ lookup of every slot, then the OPQ rotation (pq_wrapper.py:189-202)
         GatherParams g{};
         g.codes = io.fetched_codes ? io.fetched_codes : m.codes;
@@ -270,15 +279,15 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             a.U = b.U; a.ids = io.ids; a.T = (int)Tt; a.H = H; a.D = din; a.kg = kg;
             a.Z = b.Z; a.has_nb = b.has_nb;
             a.n_store = m.n_store;
-            if (ntgt) { a.nb_valid = valid; a.nb_valid_stride = n_g; }                  // centre slot of each group
+            if (ntgt || dense0) { a.nb_valid = valid; a.nb_valid_stride = n_g; }        // centre slot of each group
             else if (io.fetched_valid) { a.nb_valid = io.fetched_valid; a.nb_valid_stride = io.fetched_centres_only ? 1 : n_g; }
-            if (l == 0) {
+            if (l == 0 && !dense0) {
                 a.codes = io.fetched_codes ? io.fetched_codes : m.codes;
                 a.codes_direct = io.fetched_codes ? (io.fetched_centres_only ? 1 : n_g) : 0;
                 a.codes_index = io.fetched_codes ? io.fetched_index : nullptr;
                 a.row0 = m.row0; a.n_local = m.n_local; a.M = m.M; a.dsub = m.dsub; a.centroids = m.centroids;
             } else {
-                a.X = hn_cur; a.ldx = d; a.x_group_stride = n_g;
+                a.X = hn_cur; a.ldx = ld_hn; a.x_group_stride = n_g;
             }
             TRY(star_attn(a, s));
         }
@@ -303,9 +312,9 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         // ---- ntgt update (only when a later layer -- or the caller -- consumes it)
         if (ntgt && (!last || io.out_ntgt)) {
             GNNLM_REQUIRE(w.wq_n && w.wk_n && w.wv_n && w.wa_n && w.ln_g_n && w.ln_b_n, "hgt: layer has null ntgt weights");
-            TRY(linear(hn_cur, d, w.wq_n, w.bq_n, b.nq, S, d, d, nullptr, 1.f, s));
-            TRY(linear(hn_cur, d, w.wk_n, w.bk_n, b.nk, S, d, d, nullptr, 1.f, s));
-            TRY(linear(hn_cur, d, w.wv_n, w.bv_n, b.nv, S, d, d, nullptr, 1.f, s));
+            TRY(linear(hn_cur, ld_hn, w.wq_n, w.bq_n, b.nq, S, d, d, nullptr, 1.f, s));
+            TRY(linear(hn_cur, ld_hn, w.wk_n, w.bk_n, b.nk, S, d, d, nullptr, 1.f, s));
+            TRY(linear(hn_cur, ld_hn, w.wv_n, w.bv_n, b.nv, S, d, d, nullptr, 1.f, s));
             ChainAttnParams ca{};
             ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
             ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
@@ -313,8 +322,9 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             TRY(chain_attn(ca, s));
             TRY(linear(b.nq, d, w.wa_n, w.ba_n, b.nk, S, d, d, nullptr, 1.f, s));
             float* hn_out = (last && io.out_ntgt) ? io.out_ntgt : (hn_cur == b.hn[0] ? b.hn[1] : b.hn[0]);
-            TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, S, d, m.ln_eps, valid, s, hn_cur, d));
+            TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, S, d, m.ln_eps, valid, s, hn_cur, ld_hn));
             hn_cur = hn_out;
+            ld_hn = d;
         }
         ht_in = ht_out;
     }
@@ -462,6 +472,7 @@ int gnnlm_layernorm(const float* x, int64_t ldx, const float* gamma, const float
                     int64_t rows, int32_t d, float eps, const uint8_t* valid, void* stream) {
     return layernorm(x, ldx, gamma, beta, out, ldo, rows, d, eps, valid, (hipStream_t)stream);
 }
+int gnnlm_gelu(float* x, int64_t n, void* stream) { return gelu(x, n, (hipStream_t)stream); }
 int gnnlm_half_to_float(const void* src, float* dst, int64_t n, void* stream) {
     return half_to_float(src, dst, n, (hipStream_t)stream);
 }

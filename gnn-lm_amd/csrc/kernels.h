@@ -73,6 +73,8 @@ int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta
 // out = 0.5 * (a + b)
 int mean2(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
 
+int gelu(float* x, int64_t n, hipStream_t stream);
+
 // fp16 -> fp32 row convert
 int half_to_float(const void* src, float* dst, int64_t n, hipStream_t stream);
 

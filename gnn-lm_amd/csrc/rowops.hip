@@ -306,6 +306,14 @@ __global__ __launch_bounds__(256) void knn_interp_regs_kernel(KnnInterpParams p,
     }
 }
 
+__global__ __launch_bounds__(256) void gelu_kernel(float* x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float v = x[i];
+        x[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    }
+}
+
 __global__ __launch_bounds__(1024) void masked_sum_f64_kernel(const float* x, const uint8_t* mask, int64_t n, double* out) {
     __shared__ double red[1024];
     double s = 0.0;
@@ -400,6 +408,15 @@ int knn_interp(const KnnInterpParams& p, hipStream_t stream) {
     if (p.k <= 256) hipLaunchKernelGGL(knn_interp_regs_kernel<4>, grid, block, 0, stream, p, log_1ml, log_l);
     else if (p.k <= 1024) hipLaunchKernelGGL(knn_interp_regs_kernel<16>, grid, block, 0, stream, p, log_1ml, log_l);
     else hipLaunchKernelGGL(knn_interp_kernel, grid, block, 0, stream, p, log_1ml, log_l);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int gelu(float* x, int64_t n, hipStream_t stream) {
+    GNNLM_REQUIRE(n >= 0, "gelu: bad size");
+    if (n == 0) return OK;
+    GNNLM_REQUIRE(x, "gelu: null");
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, x, n);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

@@ -86,15 +86,16 @@ class HGTLayer(nn.Module):
 
 
 def prepare_hgt_weights(sd: Dict[str, torch.Tensor], n_layers: int, n_heads: int, store: CodeStore,
-                        device, prefix: str = ""):
+                        device, prefix: str = "", fold_codec: bool = True):
     """Fold / absorb the reference weights (state-dict names of hgt.py) into the layout of
     ``gnnlm_hgt_layer_t``.  Returns (list of dicts of device tensors, dict of codec tensors)."""
     f64 = lambda t: t.detach().to("cpu", torch.float64)
     dev32 = lambda t: t.to(torch.float32).contiguous().to(device)
     d = sd[prefix + "gcs.0.q_linears.0.weight"].shape[0]
     H, dk = n_heads, d // n_heads
-    A = f64(store.A) if store.A is not None else None                     # [dpq, d]
-    bq = f64(store.b) if (store.b is not None and store.b.numel() > 0) else None
+    # fold_codec=False: layer 0 sees explicit ntgt states (input adapters, hgt.py:505-507), nothing of the codec is folded
+    A = f64(store.A) if (store.A is not None and fold_codec) else None    # [dpq, d]
+    bq = f64(store.b) if (A is not None and store.b is not None and store.b.numel() > 0) else None
     layers = []
     for i in range(n_layers):
         p = f"{prefix}gcs.{i}."
@@ -158,18 +159,19 @@ class HGT(nn.Module):
         if dict(ntype2idx) != NTYPE2IDX or dict(etype2idx) != ETYPE2IDX:
             raise NotImplementedError("only the node/edge types of TokenGraphTransformerDecoder "
                                       "(transformer.py:913-920) are supported")
-        if not (in_dim == hidden_dim == out_dim):
-            raise NotImplementedError("in_dim == hidden_dim == out_dim required (the GNN-LM recipes; "
-                                      "hgt.py:505-513 adapters are not built)")
         if two_stream or not use_norm:
             raise NotImplementedError("two_stream=True / use_norm=False are not on the eval path (transformer.py:931)")
         self.ntype2idx, self.etype2idx = ntype2idx, etype2idx
-        self.in_dim = self.hidden_dim = self.out_dim = hidden_dim
+        self.in_dim, self.hidden_dim, self.out_dim = in_dim, hidden_dim, out_dim
         self.n_layers, self.n_heads = n_layers, n_heads
         self.gcs = nn.ModuleList([HGTLayer(hidden_dim, hidden_dim, ntype2idx, etype2idx, n_heads,
                                            use_norm=use_norm, dropout=dropout, attn_drop=attn_drop)
                                   for _ in range(n_layers)])
-        self.adapt_ws = nn.ModuleList()
+        # hgt.py:476-479,491-492: input adapters (one Linear per node type, followed by GELU) when in_dim != hidden_dim,
+        # an output Linear when hidden_dim != out_dim
+        self.adapt_ws = nn.ModuleList([nn.Linear(in_dim, hidden_dim) for _ in ntype2idx] if in_dim != hidden_dim else [])
+        if hidden_dim != out_dim:
+            self.out = nn.Linear(hidden_dim, out_dim)
         self._prepared = None
         self.gemm_precision = 0     # 0 exact f32 MFMA | 1 bf16x3 | 2 bf16x6 (opt-in split-bf16 emulation)
 
@@ -190,7 +192,8 @@ class HGT(nn.Module):
             self._bind_store(self._prepared["model"], store)
             self._prepared["store"] = store
             return self._prepared
-        layers, codec = prepare_hgt_weights(self.state_dict(), self.n_layers, self.n_heads, store, device)
+        layers, codec = prepare_hgt_weights(self.state_dict(), self.n_layers, self.n_heads, store, device,
+                                            fold_codec=(self.in_dim == self.hidden_dim))
         arr = (_lib.gnnlm_hgt_layer_t * self.n_layers)()
         for i, (w, din) in enumerate(layers):
             for name, t in w.items():
@@ -235,6 +238,27 @@ class HGT(nn.Module):
         if not tgt.is_cuda:
             raise _lib.GnnlmError("HGT.forward needs device tensors; gnnlm_amd has no CPU fallback")
         tgt = tgt.to(torch.float32).contiguous()
+        adapted = self.in_dim != self.hidden_dim
+        n_g = 1 + G.left + G.right
+        if adapted:
+            # F.gelu(adapt_ws[ntype](feat)) (hgt.py:505-507): the ntgt features are the decoded PQ rows of every slot
+            # (transformer.py:1043-1045) -- decoded here explicitly, a non-linearity sits between them and the layer
+            from . import ops
+            if G.fetched_codes is not None:
+                raise NotImplementedError("input adapters with a sharded store (fetched codes) are not built")
+            st = G.store
+            lin = lambda x, mod: ops.gemm_nt(x, mod.weight.detach().to(tgt.device).contiguous(),
+                                             bias=mod.bias.detach().to(tgt.device).contiguous())
+            dec = ops.pq_gather_decode(st.codes, st.centroids, G.ids.reshape(-1).contiguous(), G.left, G.right,
+                                       n_store=st.n_store, row0=st.row0)
+            x0 = dec["x"]
+            if st.A is not None:                                        # (x - b) @ A  (pq_wrapper.py:198-202)
+                At = st.A.t().contiguous()
+                x0 = ops.gemm_nt(x0, At, bias=None if st.b is None or st.b.numel() == 0 else -(st.b @ st.A).contiguous())
+            ntgt0 = ops.gelu_(lin(x0, self.adapt_ws[self.ntype2idx["ntgt"]]))
+            ntgt0 *= dec["valid"].to(torch.float32)[:, None]            # rows of invalid slots stay zero (they are not nodes)
+            ntgt_valid = dec["valid"]
+            tgt = ops.gelu_(lin(tgt, self.adapt_ws[self.ntype2idx["tgt"]]))
         prep = self.prepare(G.store, tgt.device)
         m = prep["model"]
         m.left, m.right, m.max_intra_context = G.left, G.right, G.max_intra_context
@@ -250,9 +274,10 @@ class HGT(nn.Module):
             io.fetched_centres_only = int(G.fetched_centres_only)
             if G.fetched_index is not None:
                 io.fetched_index = G.fetched_index.data_ptr()
+        if adapted:
+            io.ntgt_feats, io.ld_ntgt, io.ntgt_valid = ntgt0.data_ptr(), ntgt0.stride(0), ntgt_valid.data_ptr()
         out_tgt = torch.empty_like(tgt)
         io.out_tgt = out_tgt.data_ptr()
-        n_g = 1 + G.left + G.right
         S = ids.shape[0] * G.kg * n_g
         if return_ntgt:
             out_ntgt = torch.empty(S, self.hidden_dim, device=tgt.device, dtype=torch.float32)
@@ -272,4 +297,8 @@ class HGT(nn.Module):
         out = {"tgt": out_tgt}
         if return_ntgt:
             out["ntgt"] = out_ntgt[out_valid.bool()]
+        if self.hidden_dim != self.out_dim:                               # hgt.py:513
+            from . import ops
+            W, bo = self.out.weight.detach().to(tgt.device).contiguous(), self.out.bias.detach().to(tgt.device).contiguous()
+            out = {k_: ops.gemm_nt(v.contiguous(), W, bias=bo) for k_, v in out.items()}
         return out

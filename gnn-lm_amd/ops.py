@@ -229,6 +229,15 @@ def layernorm(x, gamma, beta, eps=1e-5, valid=None):
     return out
 
 
+def gelu_(x):
+    """In place, exact (erf) GELU == torch.nn.functional.gelu's default."""
+    _dev(x)
+    _f32(x)
+    assert x.is_contiguous()
+    call("gnnlm_gelu", ptr(x), x.numel(), stream())
+    return x
+
+
 def half_to_float(x):
     out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     call("gnnlm_half_to_float", ptr(x), ptr(out), x.numel(), stream())

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNLM_ABI_VERSION 2
+#define GNNLM_ABI_VERSION 3
 #define GNNLM_OK 0
 #define GNNLM_E_INVALID (-22)
 #define GNNLM_E_NOMEM (-12)
@@ -286,7 +286,17 @@ typedef struct gnnlm_hgt_io {
     float* out_tgt;            /* [n_blocks*T, d] */
     float* out_ntgt;           /* optional [n_slots, d]: last layer's ntgt states (API parity / tests) */
     uint8_t* out_valid;        /* optional [n_slots] */
+    /* ABI 3.  Layer-0 ntgt states given densely instead of as PQ codes: [n_slots, d] rows (row stride ld_ntgt) with
+     * their validity bytes [n_slots] -- what HGT.forward has after its input adapters
+     * (`F.gelu(adapt_ws[ntype](feat))` when in_dim != hidden_dim, fairseq/models/hgt.py:476-479,505-507), where the
+     * decoded features pass a non-linearity and cannot be folded into the star-edge weights.  The code store is then
+     * not read; layer 0's `din` must be d. */
+    const float* ntgt_feats;  int64_t ld_ntgt;
+    const uint8_t* ntgt_valid;
 } gnnlm_hgt_io_t;
+
+/* x = gelu(x) in place, the exact (erf) form of torch.nn.functional.gelu (input adapters of HGT, hgt.py:507) */
+int gnnlm_gelu(float* x, int64_t n, void* stream);
 size_t gnnlm_hgt_workspace_bytes(const gnnlm_hgt_t* model, const gnnlm_hgt_io_t* io);
 int gnnlm_hgt_forward(const gnnlm_hgt_t* model, const gnnlm_hgt_io_t* io, void* workspace,
                       size_t workspace_bytes, void* stream);

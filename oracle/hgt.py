@@ -114,7 +114,8 @@ def hgt_layer_forward(sd: Dict[str, torch.Tensor], layer: int, n_heads: int,
 
 
 def hgt_forward(sd, n_layers, n_heads, feats, graph, return_all_layers=False):
-    """HGT.forward with in_dim == hidden_dim == out_dim (hgt.py:494-513).
+    """HGT.forward (hgt.py:494-513), incl. the input adapters `F.gelu(adapt_ws[ntype](feat))` (:505-507) and the
+    output Linear (:513) when the state dict carries them (in_dim != hidden_dim / hidden_dim != out_dim).
 
     ``graph`` is the dict returned by :func:`oracle.graph.build_graph`."""
     ten = lambda a: torch.as_tensor(a, dtype=torch.int64)
@@ -124,8 +125,14 @@ def hgt_forward(sd, n_layers, n_heads, feats, graph, return_all_layers=False):
         ("ntgt", "intra", "ntgt"): tuple(map(ten, graph["intra_ntgt"])),
     }
     h = dict(feats)
+    if "adapt_ws.0.weight" in sd:
+        h = {nt: torch.nn.functional.gelu(torch.nn.functional.linear(x, sd[f"adapt_ws.{NTYPE2IDX[nt]}.weight"],
+                                                                      sd[f"adapt_ws.{NTYPE2IDX[nt]}.bias"]))
+             for nt, x in h.items()}
     outs = []
     for i in range(n_layers):
         h = hgt_layer_forward(sd, i, n_heads, h, edges)
         outs.append(h)
+    if "out.weight" in sd:
+        outs[-1] = h = {nt: torch.nn.functional.linear(x, sd["out.weight"], sd["out.bias"]) for nt, x in h.items()}
     return outs if return_all_layers else h

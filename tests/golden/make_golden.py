@@ -494,6 +494,49 @@ def gen_graph_and_hgt():
     np.savez_compressed(os.path.join(OUT, "hgt.npz"), **out_h)
 
 
+def gen_hgt_adapters():
+    """HGT with in_dim != hidden_dim != out_dim: the reference's own forward incl. `F.gelu(adapt_ws[ntype](feat))`
+    (hgt.py:505-507) and the output Linear (:513).  Own random stream: the fixtures above do not move."""
+    GB = load_graph_builder()
+    H = load_hgt()
+    import knn.pq_wrapper as pqw
+    rs = np.random.RandomState(77)
+    n_store, M, dsub = 50, 4, 4
+    codes = rs.randint(0, 256, size=(n_store, M)).astype(np.uint8)
+    vals = rs.randint(0, 30, size=n_store).astype(np.int32)
+    cen = (rs.randn(M, 256, dsub) * 0.5).astype(np.float32)
+    out = {"codes": codes, "cen": cen}
+    etypes = [("tgt", "intra", "tgt"), ("ntgt", "inter", "tgt"), ("ntgt", "intra", "ntgt")]
+    for case, (d_in, d_hid, d_out, L, Hh, T, k, l, r) in enumerate([(24, 32, 24, 2, 4, 6, 3, 1, 1), (16, 32, 16, 1, 2, 5, 4, 2, 0),
+                                                                    (32, 16, 32, 3, 2, 7, 2, 0, 2), (32, 32, 8, 2, 8, 6, 3, 2, 2)]):
+        A = (rs.randn(M * dsub, d_in) / np.sqrt(d_in)).astype(np.float32)
+        b = (rs.randn(M * dsub) * 0.1).astype(np.float32)
+        codec = make_ref_codec(pqw, cen, A, b)
+        nb = rs.randint(0, n_store, size=(T, k)).astype(np.int64)
+        nb[1, 0] = -1
+        nb[2, :] = -1
+        nb[0, 0], nb[3, 0] = 0, n_store - 1
+        g = ref_build_graph(GB, nb, np.zeros(T, np.int64), codes, vals, l, r, n_store)
+        torch.manual_seed(500 + case)
+        model = H["HGT"](ntype2idx={"tgt": 0, "ntgt": 1}, etype2idx={"intra": 0, "inter": 1}, in_dim=d_in, hidden_dim=d_hid,
+                         out_dim=d_out, n_layers=L, n_heads=Hh, dropout=0.1, two_stream=False, attn_drop=0.1).eval()
+        with torch.no_grad():
+            for nm, p_ in model.named_parameters():
+                if "norms" in nm or "relation_pri" in nm or "bias" in nm:
+                    p_.add_(torch.randn_like(p_) * 0.1)
+        tgt = torch.from_numpy(rs.randn(T, d_in).astype(np.float16).astype(np.float32))
+        with torch.no_grad(), g.local_scope():
+            g.nodes["ntgt"].data["h"] = codec.decode(g.nodes["ntgt"].data["h"])      # transformer.py:1043-1045
+            full = model(g, features={"tgt": tgt}, etypes=etypes)
+        key = f"c{case}"
+        out[key + ".cfg"] = np.array([d_in, d_hid, d_out, L, Hh, T, k, l, r], dtype=np.int64)
+        out[key + ".A"], out[key + ".b"], out[key + ".nb"], out[key + ".tgt_in"] = A, b, nb, tgt.numpy()
+        out[key + ".tgt_out"], out[key + ".ntgt_out"] = full["tgt"].numpy(), full["ntgt"].numpy()
+        for nm, p_ in model.state_dict().items():
+            out[key + ".sd." + nm] = p_.numpy()
+    np.savez_compressed(os.path.join(OUT, "hgt_adapt.npz"), **out)
+
+
 def gen_adaptive_and_scorer():
     asm_mod = load_by_path("ref_adaptive_softmax", "fairseq/modules/adaptive_softmax.py")
     ain_mod = load_by_path("ref_adaptive_input", "fairseq/modules/adaptive_input.py")
@@ -584,6 +627,7 @@ if __name__ == "__main__":
     gen_combine()
     gen_graph_and_hgt()
     gen_adaptive_and_scorer()
+    gen_hgt_adapters()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

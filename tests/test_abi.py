@@ -11,7 +11,7 @@ from gnnlm_amd import _lib
 def test_library_loads_and_is_gfx950():
     L = _lib.lib()
     assert L.gnnlm_target_arch() == b"gfx950"
-    assert L.gnnlm_abi_version() == _lib.ABI_VERSION == 2
+    assert L.gnnlm_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_every_declared_symbol_is_exported():
@@ -51,3 +51,28 @@ def test_product_package_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_integration_c_snippet_compiles(tmp_path):
+    """The C caller shown in INTEGRATION.md section 2.7 is real code against include/gnnlm.h: it must compile as C and as
+    C++ (syntax + types only; HIP's allocator is declared by hand, the image's host compiler has no HIP headers on
+    its default path)."""
+    import re
+    import shutil
+    import subprocess
+    text = open(os.path.join(_lib.ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("### 2.7"):]
+    snippet = re.search(r"```c\n(.*?)```", sec, flags=re.S).group(1)
+    body = snippet.replace('#include "gnnlm.h"\n', "")
+    src = ('#include <stdio.h>\n#include "gnnlm.h"\n'
+           '#ifdef __cplusplus\nextern "C"\n#endif\nint hipMalloc(void** p, size_t n);\n'
+           "int caller(int64_t n_store, const uint8_t* host_codes, const int32_t* host_vals, gnnlm_hgt_io_t io, void* stream) {\n"
+           + body + "    gnnlm_store_destroy(st);\n    return 0;\n}\n")
+    for cc, std, name in (("gcc", "-std=c11", "caller.c"), ("g++", "-std=c++17", "caller.cpp")):
+        if shutil.which(cc) is None:
+            pytest.skip(cc + " not found")
+        f = tmp_path / name
+        f.write_text(src)
+        r = subprocess.run([cc, std, "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(_lib.ROOT, "include"), str(f)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

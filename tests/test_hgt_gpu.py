@@ -59,6 +59,24 @@ def test_hgt_golden_reference_forward(dev, golden):
         np.testing.assert_allclose(out["ntgt"], g[key + f".ntgt_out{L - 1}"], atol=TOL, rtol=1e-4, err_msg=key)
 
 
+def test_hgt_adapters_golden(dev, golden):
+    """in_dim != hidden_dim != out_dim (hgt.py:476-492,505-513) against the reference's own forward."""
+    from gnnlm_amd.hgt import HGT, NeighborGraph
+    g = golden("hgt_adapt")
+    for key in sorted({k.split(".")[0] for k in g.files if k.endswith(".cfg")}):
+        d_in, d_hid, d_out, L, H, T, k, l, r = (int(v) for v in g[key + ".cfg"])
+        sd = {kk[len(key) + 4:]: torch.as_tensor(g[kk]) for kk in g.files if kk.startswith(key + ".sd.")}
+        model = HGT(in_dim=d_in, hidden_dim=d_hid, out_dim=d_out, n_layers=L, n_heads=H)
+        model.load_state_dict(sd, strict=True)
+        store = make_store(dev, g["codes"], g["cen"], g[key + ".A"], g[key + ".b"])
+        G = NeighborGraph(ids=torch.from_numpy(g[key + ".nb"]).to(dev), n_blocks=1, T=T, left=l, right=r, store=store)
+        out = model(G, features={"tgt": torch.from_numpy(g[key + ".tgt_in"]).to(dev)}, return_ntgt=True)
+        np.testing.assert_allclose(out["tgt"].cpu().numpy(), g[key + ".tgt_out"], atol=TOL, rtol=1e-4, err_msg=key)
+        np.testing.assert_allclose(out["ntgt"].cpu().numpy(), g[key + ".ntgt_out"], atol=TOL, rtol=1e-4, err_msg=key)
+        out1 = model(G, features={"tgt": torch.from_numpy(g[key + ".tgt_in"]).to(dev)})        # eval path: tgt only
+        assert torch.equal(out1["tgt"], out["tgt"])
+
+
 def oracle_hgt(sd, L, H, tgt, nb, codes, cen, A, b, n_store, l, r, dtype=torch.float64):
     gr = og.build_graph(nb, np.zeros(nb.shape[0], np.int64), n_store, l, r)
     ntgt = opq.pq_lookup(codes[gr["ntgt_offsets"]], cen).astype(np.float64)

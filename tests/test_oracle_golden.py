@@ -152,6 +152,23 @@ def test_hgt_layers(golden):
             np.testing.assert_allclose(h["ntgt"].numpy(), g[key + f".ntgt_out{i}"], atol=2e-5, rtol=1e-4)
 
 
+def test_hgt_adapters(golden):
+    """in_dim != hidden_dim != out_dim: the reference's adapters (hgt.py:476-492,505-513) in the oracle."""
+    g = golden("hgt_adapt")
+    cases = sorted({k.split(".")[0] for k in g.files if k.endswith(".cfg")})
+    assert len(cases) == 4
+    for key in cases:
+        d_in, d_hid, d_out, L, H, T, k, l, r = (int(v) for v in g[key + ".cfg"])
+        nb = g[key + ".nb"]
+        gr = og.build_graph(nb, np.zeros(T, np.int64), g["codes"].shape[0], l, r)
+        sd = {kk[len(key) + 4:]: torch.from_numpy(g[kk]) for kk in g.files if kk.startswith(key + ".sd.")}
+        assert ("adapt_ws.0.weight" in sd) == (d_in != d_hid) and ("out.weight" in sd) == (d_hid != d_out)
+        ntgt = opq.pq_decode(g["codes"][gr["ntgt_offsets"]], g["cen"], g[key + ".A"], g[key + ".b"])
+        h = ohgt.hgt_forward(sd, L, H, {"tgt": torch.from_numpy(g[key + ".tgt_in"]), "ntgt": torch.from_numpy(ntgt)}, gr)
+        np.testing.assert_allclose(h["tgt"].numpy(), g[key + ".tgt_out"], atol=2e-5, rtol=1e-4)
+        np.testing.assert_allclose(h["ntgt"].numpy(), g[key + ".ntgt_out"], atol=2e-5, rtol=1e-4)
+
+
 # ---------------------------------------------------------------- adaptive softmax
 def asm_weights(g):
     return {"cutoff": list(g["cutoff"]), "emb": [torch.from_numpy(g[f"emb{i}"]) for i in range(3)],
