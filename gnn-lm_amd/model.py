@@ -7,6 +7,7 @@ State-dict names follow the reference (prefix ``decoder.``): ``hgt_decoder.gcs.*
 ``tgt_quantizer.*`` (convert_ckpt.py:40-45), ``embed_tokens.embeddings.{i}.{0,1}.weight``,
 ``adaptive_softmax.head.class_proj.weight``.
 """
+import os
 from argparse import Namespace
 
 import torch
@@ -73,12 +74,11 @@ class GnnLmModel(torch.nn.Module):
                 quantizer = TorchPQCodec.from_arrays(sd["decoder.tgt_quantizer.centroids_torch"].numpy(),
                                                      sd["decoder.tgt_quantizer.A"].numpy() if "decoder.tgt_quantizer.A" in sd else None,
                                                      sd["decoder.tgt_quantizer.b"].numpy() if "decoder.tgt_quantizer.b" in sd else None)
-            elif str(getattr(args, "quantizer_path", "")).endswith(".npz"):
-                quantizer = TorchPQCodec.from_file(args.quantizer_path)
+            elif getattr(args, "quantizer_path", "") and os.path.exists(str(args.quantizer_path)):
+                quantizer = TorchPQCodec.from_file(args.quantizer_path)      # .npz or the recipe's faiss `quantizer` file
             else:
                 raise ValueError("no quantizer: the checkpoint has no decoder.tgt_quantizer.* buffers "
-                                 "(fairseq_cli/convert_ckpt.py) and quantizer_path is not an .npz; "
-                                 "a faiss index file needs faiss, which is not available")
+                                 "(fairseq_cli/convert_ckpt.py) and quantizer_path does not name a file")
         cut = [int(c) for c in str(args.adaptive_softmax_cutoff).split(",")]
         if vocab_size is None:
             n_bands = sd["decoder.adaptive_softmax.head.class_proj.weight"].shape[0] + 1

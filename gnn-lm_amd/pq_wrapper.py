@@ -62,8 +62,14 @@ class TorchPQCodec(torch.nn.Module):
 
     @classmethod
     def from_file(cls, path, metric="ip"):
-        z = np.load(path)
-        return cls(None, metric, z["centroids"], z["A"] if "A" in z.files else None, z["b"] if "b" in z.files else None)
+        """``.npz`` (keys centroids, A, b) or the reference's ``quantizer`` file itself: faiss's serialisation of
+        ``IndexPreTransform(OPQMatrix -> IndexPQ)`` (quantize_features.py:108-109), read without faiss (faiss_io.py)."""
+        if str(path).endswith(".npz"):
+            z = np.load(path)
+            return cls(None, metric, z["centroids"], z["A"] if "A" in z.files else None, z["b"] if "b" in z.files else None)
+        from .faiss_io import read_pq_quantizer
+        q = read_pq_quantizer(path)
+        return cls(None, metric, q["centroids"], q["A"], q["b"])
 
     def save(self, path):
         arrs = {"centroids": self.centroids_torch.cpu().numpy()}

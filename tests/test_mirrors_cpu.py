@@ -4,6 +4,8 @@ vectors produced by the reference's own code."""
 import json
 import os
 
+import struct
+
 import numpy as np
 import pytest
 import torch
@@ -89,3 +91,26 @@ def test_block_ranges_and_flags():
                                 "--temperature 0.01 --knn-sim-func do_not_recomp_ip".split() +
                                 ["--model-overrides", "{'orig_prob_ratio': 0.0, 'max_target_positions': 256, 'add_bias': False}"])
     assert r.graph and r.knnlm and r.gcn_k == 128 and r.lmbda == 0.25
+
+
+def test_faiss_quantizer_file_round_trip(tmp_path):
+    """The `quantizer` file layout (faiss IndexPreTransform(OPQ) -> IndexPQ, quantize_features.py:108-109) restated in
+    faiss_io.py: writer and reader agree, with and without the pre-transform / bias, and garbage is refused."""
+    import pytest
+    from gnnlm_amd.faiss_io import read_pq_quantizer, write_pq_quantizer
+    rs = np.random.RandomState(0)
+    cen = rs.randn(8, 256, 4).astype(np.float32)
+    A = rs.randn(32, 48).astype(np.float32)
+    b = rs.randn(32).astype(np.float32)
+    for a_, b_ in [(A, b), (A, None), (None, None)]:
+        f = str(tmp_path / "quantizer")
+        write_pq_quantizer(f, cen, a_, b_)
+        q = read_pq_quantizer(f)
+        assert np.array_equal(q["centroids"], cen) and q["metric"] == "ip"
+        assert (q["A"] is None) == (a_ is None) and (a_ is None or np.array_equal(q["A"], a_))
+        assert b_ is None or np.array_equal(q["b"], b_)
+    raw = open(f, "rb").read()
+    assert raw[:4] == b"IxPq" and struct.unpack_from("<i", raw, 4)[0] == 32                  # header: fourcc, int32 d
+    open(f, "wb").write(b"IxHN" + raw[4:])
+    with pytest.raises(ValueError):
+        read_pq_quantizer(f)
