@@ -55,6 +55,7 @@ struct TopkParams {
     int k, largest, init;
     float* best_val; int64_t* best_id;
     const int32_t* row_ncols;       // optional [n]: row r only has its first row_ncols[r] columns (ragged candidate lists)
+    const int64_t* ids; int64_t ld_ids;
 };
 
 // KP: power of two >= k.  LDS: val[2 KP] + id[2 KP]; [0, KP) the state (padded with -inf), [KP, 2 KP) the candidates.
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(TopkParams p) {
             if (p.col_scale) v *= p.col_scale[c];
             if (p.col_bias) v += p.col_bias[c];
             v *= sign;
-            const int64_t cid = p.col_ids ? p.col_ids[c] : p.col0 + c;
+            const int64_t cid = p.ids ? p.ids[row * p.ld_ids + c] : (p.col_ids ? p.col_ids[c] : p.col0 + c);
             // strictly better than the k-th best, or tied with it and earlier (tau's id is not tracked: keep ties, the merge decides)
             if (cid >= 0 && v >= tau && v > NEG) {
                 const int pos = atomicAdd(&cnt, 1);
@@ -136,7 +137,7 @@ int topk_merge(const gnnlm_topk_t& d, hipStream_t stream) {
     if (d.n == 0) return OK;
     GNNLM_REQUIRE(d.ncols == 0 || d.scores, "topk_merge: null scores");
     TopkParams p{d.scores, d.ld, d.n, d.ncols, d.col0, d.col_ids, d.col_scale, d.col_bias, d.alpha == 0.f ? 1.f : d.alpha,
-                 d.k, d.largest, d.init, d.best_val, d.best_id, d.row_ncols};
+                 d.k, d.largest, d.init, d.best_val, d.best_id, d.row_ncols, d.ids, d.ld_ids};
     ProfScope prof(K_TOPK, stream, 0.0, 4.0 * (double)d.n * d.ncols + 24.0 * (double)d.n * d.k);
     const dim3 grid((unsigned)d.n), block(256);
 #define GNNLM_TOPK_LAUNCH(KP)                                                                                    \

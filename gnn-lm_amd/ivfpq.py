@@ -1,0 +1,185 @@
+"""IVF-PQ index searched on the GPU -- the on-device replacement of the reference's faiss CPU search
+(``knn/knn_model.py:87-101``: ``index.search`` on ``faiss_store.cosine`` = ``OPQ64_1024,IVF4096,PQ64``, nprobe 32,
+``gnnlm_scripts/wiki103/find_knn.sh:8-13``; built by ``knn/index_builder.py``).
+
+The algorithm is faiss's published IVFADC with residual codes and an OPQ pre-rotation, inner-product metric:
+
+    x' = R x                       (cosine index: x is L2-normalised first, index_builder.py:90-95,118)
+    list(x) = argmax_l <x', c_l>   residual r = x' - c_list,  code_m = argmin_c |r_m - p_mc|^2
+    score(q, x) = <q', c_list(x)> + sum_m <q'_m, p_{m, code_m(x)}>         (ADC, look-up table per query)
+    search: the nprobe lists with the largest <q', c_l>, then the k best scores among their members.
+
+Search path (everything on the device, nothing [n, N]-sized): rotation, coarse scores and look-up tables on the f32
+MFMA GEMM (``gnnlm_gemm_nt``), probe selection and k-selection by ``gnnlm_topk_merge``, the list scan by
+``gnnlm_ivfpq_scan`` in two rounds -- the best ``dense_probes`` lists of every query are scored in full and give its
+k-th-best threshold, the remaining lists only emit scores above that threshold.
+
+``IVFPQIndex.build`` is the offline producer (the reference delegates it to faiss: index_builder.py:79-150): plain
+Lloyd k-means for the coarse and the product quantizers, a random orthonormal matrix for R (faiss alternates OPQ
+updates; any orthonormal R gives a valid index).  It runs on the GPU with torch ops -- offline tooling, not the hot path.
+
+PARITY UNPINNED against faiss itself (not in the image, no version pinned): the pin is the numpy restatement
+``oracle/ivfpq.py`` over the SAME index arrays (tests/test_knn_search_gpu.py)."""
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+def _kmeans(x, k, iters, gen, spherical=False):
+    """Lloyd's algorithm (squared L2) on the device; empty clusters are re-seeded from random points."""
+    n = x.shape[0]
+    cen = x[torch.randperm(n, generator=gen, device=x.device)[:k]].clone()
+    if cen.shape[0] < k:
+        cen = torch.cat([cen, cen[torch.randint(0, cen.shape[0], (k - cen.shape[0],), generator=gen, device=x.device)]])
+    for _ in range(iters):
+        assign = torch.empty(n, dtype=torch.int64, device=x.device)
+        c2 = (cen ** 2).sum(1)
+        for s in range(0, n, 1 << 18):
+            xs = x[s:s + (1 << 18)]
+            assign[s:s + (1 << 18)] = (c2[None, :] - 2 * xs @ cen.t()).argmin(1)
+        cnt = torch.bincount(assign, minlength=k)
+        new = torch.zeros_like(cen).index_add_(0, assign, x)
+        live = cnt > 0
+        new[live] /= cnt[live, None].to(x.dtype)
+        dead = (~live).nonzero().reshape(-1)
+        if dead.numel():
+            new[dead] = x[torch.randint(0, n, (dead.numel(),), generator=gen, device=x.device)]
+        cen = new
+    return cen
+
+
+class IVFPQIndex:
+    """faiss ``search`` contract: ``search(queries [n, d] f32, k) -> (scores [n, k] descending, ids [n, k], -1 padded)``."""
+
+    def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=4, cand_cap=16384):
+        self.R, self.coarse, self.pq = R, coarse, pq                         # [d, d], [nlist, d], [M, 256, dsub]  f32
+        self.list_off, self.list_ids, self.list_codes = list_off, list_ids, list_codes   # i64 [nlist+1], i64 [N], u8 [N, M]
+        self.nprobe, self.cosine, self.dense_probes, self.cand_cap = nprobe, cosine, dense_probes, cand_cap
+        self.device = R.device
+        self.d, self.nlist = coarse.shape[1], coarse.shape[0]
+        self.M, _, self.dsub = pq.shape
+        self.ntotal = list_ids.shape[0]
+        self.max_list = int((list_off[1:] - list_off[:-1]).max().item()) if self.nlist else 0
+
+    # ------------------------------------------------------------------------------------------ offline producer
+    @classmethod
+    def build(cls, keys, nlist, M, device="cuda", cosine=True, nprobe=32, iters=10, train_size=262144, seed=0, chunk=1 << 18):
+        device = torch.device(device)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        N, d = keys.shape
+        assert d % M == 0 and (d // M) % 4 == 0 and M % 16 == 0, "need dsub % 4 == 0 and M % 16 == 0"
+        dsub = d // M
+
+        def rows(lo, hi):
+            x = torch.from_numpy(np.ascontiguousarray(keys[lo:hi]).astype(np.float32)).to(device) if not isinstance(keys, torch.Tensor) \
+                else keys[lo:hi].to(device, torch.float32)
+            return x / (x ** 2).sum(1, keepdim=True).sqrt() if cosine else x
+
+        cpu_gen = torch.Generator().manual_seed(seed)
+        R = torch.linalg.qr(torch.randn(d, d, generator=cpu_gen, dtype=torch.float64))[0].to(torch.float32).to(device)
+        pick = np.sort(np.random.RandomState(seed).choice(N, size=min(N, train_size), replace=False))
+        xt = torch.cat([rows(int(i), int(i) + 1) for i in pick[:0]] + [rows(0, 0)]) if False else None
+        xt = torch.cat([rows(int(s), int(min(N, s + chunk)))[torch.from_numpy(pick[(pick >= s) & (pick < s + chunk)] - s).to(device)]
+                        for s in range(0, N, chunk)]) @ R.t()
+        coarse = _kmeans(xt, nlist, iters, gen)
+        resid = xt - coarse[(xt @ coarse.t()).argmax(1)]                      # inner-product assignment (IndexFlatIP quantizer)
+        pq = torch.stack([_kmeans(resid[:, m * dsub:(m + 1) * dsub].contiguous(), 256, iters, gen) for m in range(M)])
+        # add every key: list assignment + residual PQ codes (HIP argmin kernel of TorchPQCodec.encode)
+        assign = torch.empty(N, dtype=torch.int64, device=device)
+        codes = torch.empty(N, M, dtype=torch.uint8, device=device)
+        norm2 = (pq ** 2).sum(2).contiguous()
+        for s in range(0, N, chunk):
+            x = rows(s, min(N, s + chunk)) @ R.t()
+            a = (x @ coarse.t()).argmax(1)
+            assign[s:s + chunk] = a
+            r = (x - coarse[a]).contiguous()
+            _lib.call("gnnlm_pq_encode", _lib.ptr(r), r.stride(0), _lib.ptr(pq), _lib.ptr(norm2), M, dsub, r.shape[0],
+                      _lib.ptr(codes[s:s + chunk]), _lib.stream())
+        order = torch.sort(assign, stable=True).indices
+        off = torch.zeros(nlist + 1, dtype=torch.int64, device=device)
+        off[1:] = torch.cumsum(torch.bincount(assign, minlength=nlist), 0)
+        return cls(R.contiguous(), coarse.contiguous(), pq.contiguous(), off, order.contiguous(), codes[order].contiguous(),
+                   nprobe=nprobe, cosine=cosine)
+
+    def save(self, path):
+        np.savez(path, **{k: getattr(self, k).cpu().numpy() for k in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")},
+                 meta=np.array([self.nprobe, int(self.cosine)]))
+
+    @classmethod
+    def load(cls, path, device="cuda", **kw):
+        z = np.load(path)
+        t = lambda k: torch.from_numpy(z[k]).to(device)
+        kw.setdefault("nprobe", int(z["meta"][0]))
+        return cls(t("R"), t("coarse"), t("pq"), t("list_off"), t("list_ids"), t("list_codes"), cosine=bool(z["meta"][1]), **kw)
+
+    # ------------------------------------------------------------------------------------------ search
+    def _scan(self, lut, probe_val, probe_id, p_lo, p_hi, out=None, tau=None, cand=None):
+        n = lut.shape[0]
+        dev = self.device
+        pl = probe_id[:, p_lo:p_hi]
+        # tasks grouped by list (bookkeeping on the device, no host round trip): concurrent workgroups share code rows
+        order = torch.sort(pl.reshape(-1), stable=True).indices
+        task_q = torch.div(order, p_hi - p_lo, rounding_mode="floor").to(torch.int32)
+        task_p = (order % (p_hi - p_lo) + p_lo).to(torch.int32)
+        s = _lib.gnnlm_ivfpq_scan_t()
+        s.codes, s.ids, s.list_off, s.M = self.list_codes.data_ptr(), self.list_ids.data_ptr(), self.list_off.data_ptr(), self.M
+        s.lut, s.ld_lut = lut.data_ptr(), lut.stride(0)
+        s.probe_list, s.probe_bias, s.ld_probe = probe_id.data_ptr(), probe_val.data_ptr(), probe_id.stride(0)
+        s.task_q, s.task_p, s.n_tasks = task_q.data_ptr(), task_p.data_ptr(), order.numel()
+        if tau is None:
+            s.out_val, s.out_id, s.ld_out, s.p0, s.seg = out[0].data_ptr(), out[1].data_ptr(), out[0].stride(0), p_lo, self.max_list
+        else:
+            s.tau, s.cand_val, s.cand_id, s.cand_cnt, s.cap = tau.data_ptr(), cand[0].data_ptr(), cand[1].data_ptr(), cand[2].data_ptr(), self.cand_cap
+        _lib.call_desc("gnnlm_ivfpq_scan", s)
+
+    def search_device(self, q, k, query_block=1024):
+        q = q.to(self.device, torch.float32).contiguous()
+        n, dev = q.shape[0], self.device
+        nprobe = min(self.nprobe, self.nlist)
+        dense = min(self.dense_probes, nprobe)
+        val = torch.empty(n, k, device=dev, dtype=torch.float32)
+        idx = torch.empty(n, k, device=dev, dtype=torch.int64)
+        for q0 in range(0, n, query_block):
+            qs = q[q0:q0 + query_block]
+            nq = qs.shape[0]
+            qr = ops.gemm_nt(qs, self.R)                                            # q' = R q
+            cs = ops.gemm_nt(qr, self.coarse)                                       # <q', c_l>
+            pv = torch.empty(nq, nprobe, device=dev, dtype=torch.float32)
+            pi = torch.empty(nq, nprobe, device=dev, dtype=torch.int64)
+            ops.topk_merge(cs, pv, pi, largest=True, init=True)                     # the nprobe best lists, best first
+            lut = torch.empty(nq, self.M * 256, device=dev, dtype=torch.float32)    # lut[q][m][c] = <q'_m, p_mc>: M small GEMMs
+            g = _lib.gnnlm_gemm_t()
+            g.A, g.lda, g.W, g.ldw, g.C, g.ldc = qr.data_ptr(), qr.stride(0), self.pq.data_ptr(), self.dsub, lut.data_ptr(), self.M * 256
+            g.M, g.N, g.K, g.batch1 = nq, 256, self.dsub, self.M
+            g.sA1, g.sW1, g.sC1 = self.dsub, 256 * self.dsub, 256
+            _lib.call_desc("gnnlm_gemm_nt", g)
+            bv, bi = val[q0:q0 + nq], idx[q0:q0 + nq]
+            # round 1: the best `dense` lists of every query, every score
+            ov = torch.empty(nq, dense * self.max_list, device=dev, dtype=torch.float32)
+            oi = torch.empty(nq, dense * self.max_list, device=dev, dtype=torch.int64)
+            self._scan(lut, pv, pi, 0, dense, out=(ov, oi))
+            ops.topk_merge(ov, bv, bi, ids=oi, largest=True, init=True)
+            if nprobe > dense:
+                # round 2: the other lists only emit scores above the query's k-th best so far
+                tau = torch.where(bi[:, k - 1] >= 0, bv[:, k - 1], torch.full_like(bv[:, k - 1], float("-inf"))).contiguous()
+                cv = torch.empty(nq, self.cand_cap, device=dev, dtype=torch.float32)
+                ci = torch.empty(nq, self.cand_cap, device=dev, dtype=torch.int64)
+                cc = torch.zeros(nq, device=dev, dtype=torch.int32)
+                self._scan(lut, pv, pi, dense, nprobe, tau=tau, cand=(cv, ci, cc))
+                self._overflow = cc.max() if getattr(self, "_overflow", None) is None else torch.maximum(self._overflow, cc.max())
+                ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=False, row_ncols=cc.clamp(max=self.cand_cap))
+        return val, idx
+
+    def check(self):
+        """Raise if a query had more round-2 survivors than candidate slots (its result may miss neighbours)."""
+        ov = getattr(self, "_overflow", None)
+        if ov is not None and int(ov.item()) > self.cand_cap:
+            raise RuntimeError(f"IVFPQIndex: {int(ov.item())} candidates for one query exceed cand_cap={self.cand_cap}; "
+                               "raise cand_cap or dense_probes")
+
+    def search(self, queries, k):
+        d, i = self.search_device(torch.as_tensor(np.asarray(queries)), k)
+        self.check()
+        return d.cpu().numpy(), i.cpu().numpy()

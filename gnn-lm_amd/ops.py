@@ -282,7 +282,7 @@ def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_sto
 
 
 def topk_merge(scores, best_val, best_id, col0=0, col_ids=None, col_scale=None, col_bias=None, alpha=1.0, largest=True,
-               init=False, row_ncols=None):
+               init=False, row_ncols=None, ids=None):
     """Fold the score chunk ``scores`` [n, ncols] into the running top-k state (``best_val`` f32 / ``best_id`` i64
     [n, k], best first): value of column c = col_bias[c] + alpha * col_scale[c] * scores[:, c], id = col_ids[c] or
     col0 + c.  In place; ``init=True`` treats the state as empty (first chunk)."""
@@ -302,6 +302,11 @@ def topk_merge(scores, best_val, best_id, col0=0, col_ids=None, col_scale=None, 
         d.col_bias = col_bias.data_ptr()
     if row_ncols is not None:
         d.row_ncols = row_ncols.data_ptr()
+    if ids is not None:                                  # per-row ids [n, ncols]
+        _dev(ids)
+        _dtype(ids, torch.int64, "ids")
+        assert ids.shape == scores.shape
+        d.ids, d.ld_ids = ids.data_ptr(), ids.stride(0)
     d.alpha, d.k, d.largest, d.init = alpha, best_val.shape[1], int(largest), int(init)
     d.best_val, d.best_id = best_val.data_ptr(), best_id.data_ptr()
     call_desc("gnnlm_topk_merge", d)

@@ -237,8 +237,31 @@ typedef struct gnnlm_topk {
     int32_t init;                         /* 1: the state is empty (first chunk), buffers need no initialisation */
     float* best_val;  int64_t* best_id;   /* [n, k] */
     const int32_t* row_ncols;             /* optional [n]: row r only has its first row_ncols[r] columns */
+    const int64_t* ids;  int64_t ld_ids;  /* optional per-row ids [n, ncols] (candidate lists of an IVF scan); overrides col0 / col_ids */
 } gnnlm_topk_t;
 int gnnlm_topk_merge(const gnnlm_topk_t* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * IVF-PQ scan with asymmetric distance computation (ADC), inner-product metric with residual codes: the
+ * search of the reference's kNN index `OPQ64_1024,IVF4096,PQ64`, nprobe 32 (faiss IndexIVFPQ, by_residual;
+ * gnnlm_scripts/wiki103/find_knn.sh:8-13, knn/knn_model.py:100) restated for the GPU:
+ *     score(q, x) = <q', c_list(x)> + sum_m lut[q][m][code_m(x)],   lut[q][m][c] = <q'_m, pq_centroid[m][c]>
+ * with q' the OPQ-rotated query.  The rotation, the coarse scores and the look-up tables are GEMMs
+ * (gnnlm_gemm_nt), the probe selection and the final k-selection are gnnlm_topk_merge; this entry point scans the
+ * probed lists.  A task = (query, probe slot); tasks come grouped by list so that concurrent workgroups read the
+ * same codes.  Dense mode (tau == NULL): every score of the list is written, for the first probes of a query.
+ * Filtered mode: only scores above tau[query] (its current k-th best) are appended to the query's candidate rows.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gnnlm_ivfpq_scan {
+    const uint8_t* codes;  const int64_t* ids;  const int64_t* list_off;   /* lists: codes [N, M], ids [N]; list l = [list_off[l], list_off[l+1]) */
+    int32_t M;                            /* 8-bit sub-quantizers, M % 16 == 0, M <= 128 */
+    const float* lut;  int64_t ld_lut;    /* [n, M*256] */
+    const int64_t* probe_list;  const float* probe_bias;  int32_t ld_probe;   /* [n, ld_probe]: probed lists (-1: none) and <q', centroid> */
+    const int32_t* task_q;  const int32_t* task_p;  int64_t n_tasks;
+    float* out_val;  int64_t* out_id;  int64_t ld_out;  int32_t p0, seg;      /* dense: column (p - p0) * seg + j, ids -1 beyond the list */
+    const float* tau;  float* cand_val;  int64_t* cand_id;  int32_t* cand_cnt;  int32_t cap;   /* filtered: rows of `cap` slots, cand_cnt[q] counts ALL survivors */
+} gnnlm_ivfpq_scan_t;
+int gnnlm_ivfpq_scan(const gnnlm_ivfpq_scan_t* desc, void* stream);
 
 /* out[0] += sum_i x[i] * (mask ? mask[i] != 0 : 1), accumulated in f64 (score_sum of
  * fairseq_cli/eval_lm.py:273; the reference accumulates in f32 on the CPU) */
