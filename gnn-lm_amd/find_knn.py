@@ -43,6 +43,9 @@ def get_parser():
 
 def open_index(args, device):
     index_file = os.path.join(dstore_path(args.data_dir, args.candidate_subset), "faiss_store.cosine")
+    if os.path.exists(index_file + ".gnnlm.npz"):                               # this package's IVF-PQ index: searched on the GPU
+        from .ivfpq import IVFPQIndex
+        return IVFPQIndex.load(index_file + ".gnnlm.npz", device=device, nprobe=args.nprobe)
     try:
         import faiss
         if os.path.exists(index_file):

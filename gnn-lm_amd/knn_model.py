@@ -118,7 +118,15 @@ class KNNModel(object):
         return "cosine" in self.index_file
 
     def setup_faiss(self):
-        """faiss index if faiss is importable, else an exact index over the keys (small stores)."""
+        """The index behind ``get_knns`` (knn_model.py:59-64,78-82), in this order: an IVF-PQ index in this package's
+        own format next to ``index_file`` (``<index_file>.gnnlm.npz``, written by ``python -m gnnlm_amd.run_index_build``:
+        searched on the GPU, the hot-path choice at datastore scale); a faiss index if faiss is importable; else an
+        exact index over the keys resident in HBM (chunked search, fine up to a few 10^7 keys)."""
+        own = self.index_file if self.index_file.endswith(".gnnlm.npz") else self.index_file + ".gnnlm.npz"
+        if os.path.exists(own):
+            from .ivfpq import IVFPQIndex
+            LOGGING.info("IVF-PQ index %s searched on %s", own, self.device)
+            return IVFPQIndex.load(own, device=self.device, nprobe=self.probe)
         try:
             import faiss
         except ImportError:

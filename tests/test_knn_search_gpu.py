@@ -149,3 +149,35 @@ def test_ivfpq_small_lists_and_padding(dev):
     assert np.array_equal(np.sort(np.where(i >= 0, i, 10 ** 9), 1), np.sort(np.where(i_ref >= 0, i_ref, 10 ** 9), 1))
     ok = i >= 0
     np.testing.assert_allclose(v[ok], v_ref[ok], rtol=2e-5, atol=2e-5)
+
+
+def test_knn_model_over_built_index(dev, tmp_path):
+    """run_index_build -> KNNModel(index_file=<the reference's path>) -> get_knn_prob: the whole kNN half of the eval path
+    with the search on the device (knn_model.py:87-101,179-217), against oracle search + oracle kNN prob on the same index."""
+    import json, os
+    from gnnlm_amd import run_index_build
+    from gnnlm_amd.ivfpq import IVFPQIndex
+    from gnnlm_amd.knn_model import KNNModel
+    from oracle import ivfpq as oivf
+    rs = np.random.RandomState(4)
+    N, d, V, n, k = 20000, 64, 50, 33, 64
+    centres = rs.randn(40, d).astype(np.float32)
+    keys = (centres[rs.randint(0, 40, N)] + 0.5 * rs.randn(N, d)).astype(np.float16)
+    vals = rs.randint(0, V, N).astype(np.int16)
+    dd = tmp_path / "train_dstore"
+    os.makedirs(dd)
+    keys.tofile(dd / "keys.npy"); vals.tofile(dd / "vals.npy")
+    json.dump({"dstore_size": N, "hidden_size": d, "vocab_size": V, "dstore_fp16": True, "val_size": 1}, open(dd / "info.json", "w"))
+    out = run_index_build.main(run_index_build.get_parser().parse_args(
+        ["--dstore-dir", str(dd), "--index-type", "OPQ16_64,IVF64,PQ16", "--metric", "cosine", "--nprobe", "8"]))
+    assert out.endswith("faiss_store.cosine.gnnlm.npz")
+    m = KNNModel(str(dd / "faiss_store.cosine"), str(dd), k=k, probe=8, no_load_keys=True, metric_type="do_not_recomp_ip", device=dev)
+    assert isinstance(m.index, IVFPQIndex) and m.cosine
+    q = (centres[rs.randint(0, 40, n)] + 0.5 * rs.randn(n, d)).astype(np.float32)
+    targets = rs.randint(0, V, n).astype(np.int64)
+    p, rec = m.get_knn_prob(torch.from_numpy(q).to(dev), targets=torch.from_numpy(targets).to(dev), t=1.0, return_recall=True)
+    arrs = [getattr(m.index, a).cpu().numpy() for a in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")]
+    v_ref, i_ref = oivf.search(q, *arrs, k=k, nprobe=8, cosine_queries=True)
+    p_ref, rec_ref = oknn.knn_target_prob(v_ref.astype(np.float32), i_ref, vals, targets, 1.0)
+    np.testing.assert_allclose(p.cpu().numpy(), p_ref.numpy(), rtol=2e-4, atol=1e-6)
+    assert np.abs(rec.cpu().numpy() - rec_ref.numpy()).max() <= 1              # a near-tie at the k-th place may swap one neighbour
