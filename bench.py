@@ -365,6 +365,27 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def knn_search(args, eng, batches, dev, step_ms):
+    """The kNN SEARCH the headline step leaves out (the reference runs it on the CPU with faiss, knn_model.py:100): the
+    step's queries (the HGT features of one batch) through the on-device IVF-PQ search over a synthetic index of the
+    reference's index shape (OPQ64_1024,IVF4096,PQ64, nprobe 32, k = --k) with as many keys as the store."""
+    from gnnlm_amd.synthetic import synthetic_ivfpq_index
+    idx = synthetic_ivfpq_index(args.n_store, eng.hgt.hidden_dim, 4096, 64, dev, nprobe=32)
+    q = eng.features(batches[0])
+    q = q / q.norm(dim=1, keepdim=True)                                   # knn_model.py:181-184 (cosine index)
+    idx.search_device(q[:1024], args.k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx.search_device(q, args.k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    idx.check()
+    n = q.shape[0]
+    return {"index": "synthetic OPQ64_1024,IVF4096,PQ64", "keys": args.n_store, "nprobe": 32, "k": args.k, "queries": n,
+            "ms_per_batch": round(dt * 1e3, 2), "queries_per_s": round(n / dt, 1),
+            "tokens_per_s_step_plus_search": round(n / (dt + step_ms / 1e3), 1)}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, written by
     tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same
@@ -571,11 +592,13 @@ def main():
                 dtr = ttr.item()
             replicated = {"tokens_per_s": round(args.steps * args.blocks * args.tokens_per_sample * world / dtr, 1),
                           "ms_per_step": round(dtr / args.steps * 1e3, 4)}
-    recipe = drv = None
+    recipe = drv = search = None
     if rank == 0 and world == 1 and fetcher is None and not args.small and args.extras:
         if args.layers == 1 and args.precision == "f32":
             recipe = recipe_l3(args, eng, batches, dev)
         drv = driver_path(args, eng, batches, dev)
+        if args.precision == "f32":
+            search = knn_search(args, eng, batches, dev, dt / args.steps * 1e3)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -634,6 +657,8 @@ def main():
             res["recipe_L3"] = recipe
         if drv is not None:
             res["driver_path"] = drv
+        if search is not None:
+            res["knn_search"] = search
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, cpu_model)
         print(json.dumps(res))

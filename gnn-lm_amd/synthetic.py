@@ -44,6 +44,22 @@ def device_codes(n_local, M, dev, seed):
     return codes
 
 
+def synthetic_ivfpq_index(N, d, nlist, M, dev, nprobe=32, seed=7, **kw):
+    """Shape-true, content-free IVF-PQ index of the reference's kNN index family (OPQ64_1024,IVF4096,PQ64 over the
+    103 M WikiText-103 keys: 6.6 GB of codes): uniform lists, random codes and centroids, a random rotation.  For
+    search-throughput measurements only (bench.py, tools/ivfpq_bench.py); a real index comes from run_index_build."""
+    from .ivfpq import IVFPQIndex
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    R = torch.linalg.qr(torch.randn(d, d, generator=g, device=dev, dtype=torch.float32))[0].contiguous()
+    coarse = (torch.randn(nlist, d, generator=g, device=dev) / d ** 0.5).contiguous()
+    pq = (torch.randn(M, 256, d // M, generator=g, device=dev) * 0.05).contiguous()
+    per = -(-N // nlist)
+    off = torch.clamp(torch.arange(nlist + 1, device=dev, dtype=torch.int64) * per, max=N)
+    return IVFPQIndex(R, coarse, pq, off, torch.arange(N, device=dev, dtype=torch.int64), device_codes(N, M, dev, seed),
+                      nprobe=nprobe, cosine=True, **kw)
+
+
 def make_codec(rs, M, dsub, d, opq=True):
     cen = (rs.randn(M, 256, dsub) * 0.5).astype(np.float32)
     dpq = M * dsub

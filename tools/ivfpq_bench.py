@@ -4,25 +4,13 @@ synthetic 103,227,021-key index (uniform lists, random codes / centroids: shape-
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gnnlm_amd.ivfpq import IVFPQIndex
-from gnnlm_amd.synthetic import device_codes
-
-
-def synthetic_index(N, d, nlist, M, dev, nprobe=32, **kw):
-    g = torch.Generator(device=dev); g.manual_seed(0)
-    R = torch.linalg.qr(torch.randn(d, d, generator=g, device=dev, dtype=torch.float32))[0].contiguous()
-    coarse = torch.randn(nlist, d, generator=g, device=dev) / d ** 0.5
-    pq = torch.randn(M, 256, d // M, generator=g, device=dev) * 0.05
-    per = -(-N // nlist)
-    off = torch.clamp(torch.arange(nlist + 1, device=dev, dtype=torch.int64) * per, max=N)
-    return IVFPQIndex(R, coarse.contiguous(), pq.contiguous(), off, torch.arange(N, device=dev, dtype=torch.int64),
-                      device_codes(N, M, dev, 7), nprobe=nprobe, cosine=True, **kw)
+from gnnlm_amd.synthetic import synthetic_ivfpq_index
 
 
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     N = int(os.environ.get("N", 103227021)); n = int(os.environ.get("NQ", 8192)); k = int(os.environ.get("K", 1024))
-    idx = synthetic_index(N, 1024, 4096, 64, dev, dense_probes=int(os.environ.get("DENSE", 4)))
+    idx = synthetic_ivfpq_index(N, 1024, 4096, 64, dev, dense_probes=int(os.environ.get("DENSE", 4)))
     q = torch.randn(n, 1024, device=dev); q = q / q.norm(dim=1, keepdim=True)
     from gnnlm_amd import _lib
     idx.search_device(q[:1024], k); torch.cuda.synchronize()
