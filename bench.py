@@ -333,7 +333,7 @@ def driver_path(args, eng, batches, dev):
                                   lmbda, vals=st.vals, n_store=st.n_store)
 
     tabs = {"n_tok": n, "d": eng.hgt.hidden_dim, "vocab": None, "n_store": st.n_store, "feats": b0.tgt_feats[:n],
-            "targets": b0.targets[:n].clamp(min=4), "nbrs": b0.ids[:n], "codes": st.codes}
+            "targets": b0.targets[:n].clamp(min=4), "nbrs": b0.ids[:n], "codes": st.codes, "no_pad": True}
     out = {}
     for name, max_tokens in (("one_block_per_batch", T), ("bench_batch", n)):
         a = eval_lm.get_parser().parse_args(

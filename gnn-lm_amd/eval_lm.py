@@ -118,8 +118,10 @@ def load_tables(args, device):
     nbrs = np.memmap(neighbor_path(data, split, args.gcn_k), mode="r", dtype=np.int64, shape=(n_tok, args.gcn_k))
     codes = np.load(quantized_feature_path(data, "train"), mmap_mode="r")                  # language_modeling.py:274-276
     up = lambda a: torch.from_numpy(np.array(a)).to(device)
+    tg = up(targets).long()
     return {"n_tok": n_tok, "d": d, "vocab": info.get("vocab_size"), "n_store": tinfo["dstore_size"],
-            "feats": up(feats), "targets": up(targets).long(), "nbrs": up(nbrs), "codes": up(codes)}
+            "feats": up(feats), "targets": tg, "nbrs": up(nbrs), "codes": up(codes),
+            "no_pad": not bool(tg.eq(_Dict().pad()).any())}           # one look at the split instead of one sync per hypothesis
 
 
 def main(args, tables=None, model=None):
@@ -187,6 +189,8 @@ def main(args, tables=None, model=None):
         sample = {"id": torch.arange(len(group)), "nsentences": len(group), "ntokens": len(group) * L,
                   "net_input": {"src_tokens": target, "src_lengths": torch.full((len(group),), L), "graph": graph},
                   "target": target, "start_indices": [s - c for c, s, _ in group]}
+        if tabs.get("no_pad") is not None:
+            sample["no_pad_in_target"] = tabs["no_pad"]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         hypos = scorer.generate([model], sample, knn_dstore=knn_dstore, temperature=args.temperature) if args.knnlm \

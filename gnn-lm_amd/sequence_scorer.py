@@ -59,20 +59,36 @@ class SequenceScorer(object):
         start_idxs = sample["start_indices"] if "start_indices" in sample else [0] * bsz
         kt = getattr(self.args, "knn_keytype", None)
         feat = decoder_out[1][kt] if kt in decoder_out[1] else decoder_out[1]["inner_states"][-1]
+        # strip_pad / the [mask] selections of the reference (:156-191) are boolean indexings: each one synchronises the
+        # stream (nonzero).  LM eval targets carry no padding (--sample-break-mode none), so ask ONCE per batch -- or not
+        # at all when the driver already knows (sample["no_pad_in_target"], set by eval_lm from the whole split) -- and
+        # take plain views; the general path below is the reference's, line by line.
+        no_pad = sample.get("no_pad_in_target")
+        if no_pad is None:
+            no_pad = not bool(sample["target"].eq(self.pad).any())
         hypos = []
         for i in range(bsz):
             s = int(start_idxs[i])
-            ref = strip_pad(sample["target"][i, s:], self.pad)
-            tgt_len = ref.numel()
-            p_i = probs[i][s:s + tgt_len]
-            mask = sample["target"][i, s:].ne(self.pad)
+            if no_pad:
+                ref = sample["target"][i, s:]
+                tgt_len = ref.numel()
+                p_i = probs[i][s:]
+                keys_i = feat[s:, i, :]
+                rec_i = recall[i, s:] if recall is not None else None
+            else:
+                ref = strip_pad(sample["target"][i, s:], self.pad)
+                tgt_len = ref.numel()
+                p_i = probs[i][s:s + tgt_len]
+                mask = sample["target"][i, s:].ne(self.pad)
+                keys_i = feat[s:, i, :][mask]
+                rec_i = recall[i, s:][mask] if recall is not None else None
             hypos.append([{
                 "tokens": ref,
                 "score": p_i.sum() / tgt_len,
                 "attention": None,
                 "alignment": None,
                 "positional_scores": p_i,
-                "dstore_keys": feat[s:, i, :][mask],
-                "knn_recall": recall[i, s:][mask] if recall is not None else None,
+                "dstore_keys": keys_i,
+                "knn_recall": rec_i,
             }])
         return hypos
