@@ -123,6 +123,9 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
 #ifndef GNNLM_STAB_CLK
 #define GNNLM_STAB_CLK 0
 #endif
+#ifndef GNNLM_STAB_CLKW
+#define GNNLM_STAB_CLKW 0   // the compute wave whose stamps are written
+#endif
 #if GNNLM_STAB_CLK
 #define STAB_CLK() clock64()
 #else
@@ -145,6 +148,24 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         __builtin_amdgcn_sched_barrier(0);                            \
     }
+// the same with the time of the phase's body (from t_), of the LDS drain and of the barrier accounted (CLK builds)
+#if GNNLM_STAB_CLK
+#define STAB_PHASE_T(t_, body_, wait_, bar_)                          \
+    {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const long long a_ = STAB_CLK();                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            \
+        const long long b_ = STAB_CLK();                              \
+        asm volatile("s_barrier" ::: "memory");                       \
+        const long long c_ = STAB_CLK();                              \
+        body_ += a_ - (t_); wait_ += b_ - a_; bar_ += c_ - b_; tend = c_; \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    }
+#else
+#define STAB_PHASE_T(t_, body_, wait_, bar_) STAB_PHASE()
+#endif
+    [[maybe_unused]] long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // pass 1: L body/wait/barrier, M body/wait/barrier; pass 2 likewise
+    [[maybe_unused]] long long tend = 0, gap[2] = {0, 0};
     [[maybe_unused]] const long long clk0 = STAB_CLK();
 
     // ---------------------------------------------------------------- phase 0: validity, code rows (zeros when invalid)
@@ -224,6 +245,12 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         for (int c = 0; c < NCH; ++c) {
             // ---------------- L(c)
             {
+                [[maybe_unused]] const long long tL = STAB_CLK();
+                if (GNNLM_STAB_CLK && c > 0) gap[0] += tL - tend;
+                // The look-up phase runs at raised priority: its VALU / LDS instructions compete for issue slots with the
+                // partner wave's MFMA stream, and the younger group (waves 4..7) loses that arbitration at equal priority
+                // (its look-up phases measured 1.6-2.0k cycles against 0.5-1.1k for the older group's).
+                __builtin_amdgcn_s_setprio(1);
                 const float* tb = tab + (c & 1) * TABF;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                          // the look-ups ARE the A operands
@@ -250,15 +277,12 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
                         code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS + MPC * (c + 1)]
                                             : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS + MPC * (c + 1));
                 }
-                STAB_PHASE()
+                __builtin_amdgcn_s_setprio(0);
+                STAB_PHASE_T(tL, tl[0], tl[1], tl[2])
             }
+            [[maybe_unused]] const long long tM = STAB_CLK();
+            if (GNNLM_STAB_CLK) gap[1] += tM - tend;
             // ---------------- M(c)
-#if GNNLM_STAB_CLK
-            if (c == 5 && blockIdx.x < 256 && lane == 0 && (wave == 0 || wave == 4) && p.has_nb)
-                reinterpret_cast<unsigned*>(p.has_nb)[blockIdx.x * 8 + 4 + (wave >> 2)] = (unsigned)(STAB_CLK() - clk0);
-            if (c == 6 && blockIdx.x < 256 && lane == 0 && wave == 0 && p.has_nb)
-                reinterpret_cast<unsigned*>(p.has_nb)[blockIdx.x * 8 + 6] = (unsigned)(STAB_CLK() - clk0);
-#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (!STAB_OFF(1)) {
@@ -274,12 +298,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
                     asm volatile("" :: "v"(xa[q].x), "v"(xa[q].w), "v"(xb[q].x), "v"(xb[q].w), "v"(ua.x), "v"(ub.w));
                 }
             }
-#if GNNLM_STAB_CLK
-            __builtin_amdgcn_sched_barrier(0);
-            if (c == 5 && blockIdx.x < 256 && lane == 0 && wave == 0 && p.has_nb)
-                reinterpret_cast<unsigned*>(p.has_nb)[blockIdx.x * 8 + 7] = (unsigned)(STAB_CLK() - clk0);
-#endif
-            STAB_PHASE()
+            STAB_PHASE_T(tM, tl[3], tl[4], tl[5])
         }
         if (!grp) STAB_PHASE()                                         // A finished one phase early
         __syncthreads();
@@ -352,6 +371,8 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         if (grp) STAB_PHASE()                                          // B starts one phase late
         for (int c = 0; c < NCH; ++c) {
             // ---------------- L(c): look-ups of chunk c; the partial sums of chunk c - 1 meet and leave
+            [[maybe_unused]] const long long tL = STAB_CLK();
+            __builtin_amdgcn_s_setprio(1);
             if (c > 0) STAB_ZSTORE(c - 1)
             {
                 const unsigned sb = lbase + (c & 1) * (TABF * 4);
@@ -366,42 +387,56 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
                     for (int ks = 0; ks < 16; ++ks)
                         w[ks] = reinterpret_cast<const uint32_t*>(cbase + 4 * ks * MS + MPC * (c + 1))[widx];
                 }
-                STAB_PHASE()
+                __builtin_amdgcn_s_setprio(0);
+                STAB_PHASE_T(tL, tl[6], tl[7], tl[8])
             }
-            // ---------------- M(c)
+            [[maybe_unused]] const long long tM = STAB_CLK();
+            // ---------------- M(c): four accumulator chains -- in its MFMA phase a wave has the matrix pipe to itself, and a
+            // dependent 16x16x4 MFMA can only issue 40 cycles after its predecessor (32 for an independent one): with two
+            // chains every MFMA waited 8 cycles (1.6k cycles per phase measured against 1.2k in pass 1)
             z0 = f32x4{0.f, 0.f, 0.f, 0.f};
             z1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                if (!STAB_OFF(2)) {
-                    z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[ks].x, z0, 0, 0, 0);
-                    z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[ks].y, z1, 0, 0, 0);
-                } else {
-                    asm volatile("" :: "v"(b[ks].x), "v"(b[ks].y));
+                for (int ks = 0; ks < 16; ks += 2) {
+                    if (!STAB_OFF(2)) {
+                        z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[ks].x, z0, 0, 0, 0);
+                        z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[ks].y, z1, 0, 0, 0);
+                        y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks + 1], b[ks + 1].x, y0, 0, 0, 0);
+                        y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks + 1], b[ks + 1].y, y1, 0, 0, 0);
+                    } else {
+                        asm volatile("" :: "v"(b[ks].x), "v"(b[ks].y), "v"(b[ks + 1].x), "v"(b[ks + 1].y));
+                    }
                 }
+                z0 += y0;
+                z1 += y1;
             }
             // C layout: z<ct>[rr] = Z[head 4 g + rr][dim of column n16 of tile ct]; heads 8..15 (g >= 2) are padding
             if (kh == 1 && g < 2) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) { zb[32 * rr] = z0[rr]; zb[128 + 32 * rr] = z1[rr]; }
             }
-            STAB_PHASE()
+            STAB_PHASE_T(tM, tl[9], tl[10], tl[11])
         }
         STAB_ZSTORE(NCH - 1)                                           // the last chunk's sums
 #undef STAB_ZSTORE
         if (!grp) STAB_PHASE()                                         // A finished one phase early
     }
 #if GNNLM_STAB_CLK
-    if (blockIdx.x < 256 && tid == 0 && p.has_nb) {   // T >= 2048
+    if (blockIdx.x < 256 && tid == 64 * GNNLM_STAB_CLKW && p.has_nb) {   // T >= 4096
         const long long clk4 = STAB_CLK();
-        unsigned* o = reinterpret_cast<unsigned*>(p.has_nb) + blockIdx.x * 8;
+        unsigned* o = reinterpret_cast<unsigned*>(p.has_nb) + blockIdx.x * 16;
         o[0] = (unsigned)(clk1 - clk0); o[1] = (unsigned)(clk2 - clk1); o[2] = (unsigned)(clk3 - clk2); o[3] = (unsigned)(clk4 - clk3);
+        for (int e = 0; e < 10; ++e) o[4 + e] = (unsigned)tl[e];
+        o[14] = (unsigned)gap[0]; o[15] = (unsigned)gap[1];
     }
 #endif
 #undef STAB_DMA
 #undef STAB_LOADER_SWEEP
 #undef STAB_DMA_PIECES
 #undef STAB_PHASE
+#undef STAB_PHASE_T
 #undef STAB_LAND
 #undef STAB_CLK
 }

@@ -14,8 +14,9 @@ ids = torch.randint(0, N, (T, kg), generator=g, device=dev)
 for _ in range(3):
     Z, has = ops.star_attn(U, ids, codes=codes, centroids=cen)
 torch.cuda.synchronize()
-c = has.view(torch.int32)[: 256 * 8].view(256, 8).double().cpu()
-names = ["staging", "pass1", "softmax", "pass2", "A_M5_start", "B_M5_start", "A_M6_start", "A_M5_mfma_end"]
+c = has.view(torch.int32)[: 256 * 16].view(256, 16).double().cpu()
+names = ["staging", "pass1", "softmax", "pass2"] + [f"p{p_}_{ph}_{w}" for p_ in (1, 2) for ph in ("L", "M") for w in ("body", "ldswait", "barrier")]
+names[14] = "p1_gap_M_to_L"; names[15] = "p1_gap_L_to_M"
 for i, n in enumerate(names):
     print(f"{n:12s} mean {c[:, i].mean():10.0f}  min {c[:, i].min():10.0f}  max {c[:, i].max():10.0f}")
 print("total", c[:, :4].sum(1).mean())
