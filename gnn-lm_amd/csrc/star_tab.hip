@@ -74,7 +74,9 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     const Carve cv = carve(M);
     float* tab = reinterpret_cast<float*>(smem + cv.tab);              // [2][TABF]
     float* sc = reinterpret_cast<float*>(smem + cv.sc);                // [TPW][HB][SCS] scores -> alphas
-    float* zpart = reinterpret_cast<float*>(smem + cv.zpart);          // [TPW][2][2 tiles][4][32]
+    // 8 KiB that serve both sweeps: pass 1 [2 buffers][TPW][64 slots of 16 B] the chunk's U rows in MFMA operand order,
+    // pass 2 [2 neighbour halves][TPW][HB][32] the chunk's partial sums on their way out
+    float* zpart = reinterpret_cast<float*>(smem + cv.zpart);
     unsigned char* okf = smem + cv.okf;                                // [TPW][KGM]
     unsigned char* lcodes = smem + cv.lcodes;                          // [TPW][KGM][MS]
 
@@ -107,15 +109,26 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         }                                                                                            \
     }
 #define STAB_DMA(c_, b_) STAB_DMA_PIECES(c_, b_, (wave - 8) * 8, 8)    /* the four loader waves, 8 pieces each */
+    // one DMA instruction: 16 B per lane from src_ (a per-lane pointer) to LDS bytes [dst_, dst_ + 1024) in lane order
+#define STAB_DMA_ONE(src_, dst_)                                                                     \
+    {                                                                                                \
+        unsigned keep_;                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                              \
+    }
     // Loader waves 8..11 own the table DMA.  Issuing a 1-KiB LDS-DMA costs the issuing wave ~100-150 cycles here; with
     // the compute waves issuing their own (4 or 8 per chunk) that was the longest item of their look-up phase (1.76k
     // cycles per phase measured against 1.0k of MFMAs).  Global phase P: A's L(c) = 2c, B's L(c) = 2c + 1; chunk c + 1
     // replaces chunk c - 1 (last read in phase 2c - 1): issued in phase 2c, landed by the end of phase 2c + 1.
-#define STAB_LOADER_SWEEP()                                                                          \
+#define STAB_LOADER_SWEEP(extra_even_, extra_any_)                                                   \
     for (int P = 0; P <= 2 * NCH; ++P) {                                                             \
         const int c1 = (P >> 1) + 1;                                                                 \
-        if (!(P & 1) && c1 < NCH && !STAB_OFF(8)) STAB_DMA(c1, c1 & 1)                        \
+        if (!(P & 1) && c1 < NCH && !STAB_OFF(8)) {                                                  \
+            STAB_DMA(c1, c1 & 1)                                                                     \
+            extra_even_                                                                              \
+        }                                                                                            \
         if (P & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
+        extra_any_                                                                                   \
         STAB_PHASE()                                                                                 \
     }
 // -DGNNLM_STAB_CLK=1: cycle stamps of wave 0 of the first 256 workgroups, written over has_nb (a timing build, wrong has_nb):
@@ -193,16 +206,45 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     if (wave >= 8) {
         // ============================================================ loader waves: the table DMA of both sweeps, and
         // every barrier of the compute path below, in the same order
+        // No compute wave issues a vector-memory instruction inside the sweeps: its U operands arrive in LDS and its sums
+        // leave through LDS, both moved by these waves.  (With the U loads and Z stores in the compute waves each of
+        // them queued behind the table DMA at the texture unit, 64 B per clock per CU, and stalled its wave at issue:
+        // switching off the U loads / the Z stores / the DMA saved 102 / 81 / 96 us of 967 per 8192 tokens.)
+        const int lw = wave - 8;                                        // U: loader wave lw moves token lw's rows
+        const float* usrc;
+        {
+            const int hh = lane >> 5, ab = (lane >> 4) & 1, dq_ = (lane >> 2) & 3, li_ = lane & 3;
+            const int lo_ = DSUB == 8 ? 4 * (dq_ & 1) : 0;
+            usrc = p.U + ((int64_t)min(tok0 + lw, p.T - 1) * H + h0 + min(4 * hh + li_, H - 1 - h0)) * D + 8 * dq_ + (ab ? 4 - lo_ : lo_);
+        }
+        const unsigned u_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)zpart) + lw * 1024;
+#define STAB_DMA_U(c_) if (!STAB_OFF(32)) STAB_DMA_ONE(usrc + (c_) * CD, u_lds + ((c_) & 1) * 4096)
         STAB_DMA(0, 0)
+        STAB_DMA_U(0)
         STAB_LAND();
         __syncthreads();                // codes staged, chunk 0 landed
-        STAB_LOADER_SWEEP()
+        STAB_LOADER_SWEEP(STAB_DMA_U(c1), )
+#undef STAB_DMA_U
         __syncthreads();                // end of pass 1
         STAB_DMA(0, 0)
         __syncthreads();                // scores written
         STAB_LAND();
         __syncthreads();                // alphas written, chunk 0 landed
-        STAB_LOADER_SWEEP()
+        // Z: in phase P the sums of chunk (P - 2) / 2 of tokens 0, 1 (P even) or of chunk (P - 3) / 2 of tokens 2, 3 (P odd)
+        // are complete (written one phase earlier): 128 lanes add the two neighbour halves and store 16 B each
+        const int ze = lw * 32 + (lane & 31);                           // (token of the pair, head, 4-dim group)
+        const int zt = ze >> 6, zh = (ze >> 3) & 7, zq = ze & 7;
+#define STAB_ZOUT(tt_, c_)                                                                           \
+    if (lane < 32 && tok0 + (tt_) < p.T && h0 + zh < H && !STAB_OFF(64)) {                           \
+        const float* z_ = zpart + ((tt_) * HB + zh) * CD + 4 * zq;                                   \
+        const float4 a_ = *reinterpret_cast<const float4*>(z_);                                      \
+        const float4 b_ = *reinterpret_cast<const float4*>(z_ + TPW * HB * CD);                      \
+        *reinterpret_cast<float4*>(p.Z + ((int64_t)(tok0 + (tt_)) * H + h0 + zh) * D + (c_) * CD + 4 * zq) = \
+            make_float4(a_.x + b_.x, a_.y + b_.y, a_.z + b_.z, a_.w + b_.w);                         \
+    }
+        STAB_LOADER_SWEEP(, if (P >= 2) STAB_ZOUT(2 * (P & 1) + zt, (P - 2 - (P & 1)) >> 1))
+        STAB_ZOUT(2 + zt, NCH - 1)
+#undef STAB_ZOUT
         return;
     }
 
@@ -225,16 +267,18 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     {
         // lane (n16, g) carries U[head n16 & 7][chunk dims of k slot g]: the 8 dims of sub-quantizer 4c + g (dsub 8; odd
         // g with the two halves swapped, see the header) or of the pair 8c + 2g, 8c + 2g + 1 (dsub 4)
-        const float* Ur = p.U + ((int64_t)i_tok * H + h0 + min(n16 & 7, H - 1 - h0)) * D + 8 * g;
-        const int lo = DSUB == 8 ? 4 * (g & 1) : 0, hi = 4 - lo;
-        f32x4 acc[4];
+        const int li = lane & 3, dq = (lane >> 2) & 3, ng = lane >> 4;
+        // U[head 4 hh + li][the 8 dims of sub-quantizer dq] as two float4 (halves in this lane's look-up order), from LDS
+        const float* ul = zpart + t * 256 + (dq * 4 + li) * 4;
+        const int lo = DSUB == 8 ? 4 * (dq & 1) : 0, hi = 4 - lo;
+        f32x4 acc[4][2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // code bytes of this lane: neighbour 64 half + 16 q + n16, sub-quantizer(s) of k slot g (padding rows are zeros)
-        const unsigned char* crow = lcodes + (t * KGM + 64 * half + n16) * MS + (DSUB == 8 ? g : 2 * g);
+        for (int q = 0; q < 4; ++q) acc[q][0] = acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // code bytes of this lane: neighbour 64 half + 16 q + 4 ng + li, sub-quantizer(s) dq of the chunk (padding rows are zeros)
+        const unsigned char* crow = lcodes + (t * KGM + 64 * half + 4 * ng + li) * MS + (DSUB == 8 ? dq : 2 * dq);
         unsigned code[4];
         float4 xa[4], xb[4];
-        float4 ua = *reinterpret_cast<const float4*>(Ur + lo), ub = *reinterpret_cast<const float4*>(Ur + hi), ua_n = ua, ub_n = ub;
+        float4 ua[2], ub[2];
         STAB_LAND();
         __syncthreads();                                               // codes staged, chunk 0 landed
         clk1 = STAB_CLK();
@@ -258,20 +302,20 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
                         xa[q] = make_float4(1.f, 2.f, 3.f, (float)code[q]);
                         xb[q] = xa[q];
                     } else if constexpr (DSUB == 8) {
-                        const float* r_ = tb + (g * 256 + (STAB_OFF(4) ? 0u : code[q])) * 8;
+                        const float* r_ = tb + (dq * 256 + (STAB_OFF(4) ? 0u : code[q])) * 8;
                         xa[q] = *reinterpret_cast<const float4*>(r_ + lo);
                         xb[q] = *reinterpret_cast<const float4*>(r_ + hi);
                     } else {
-                        xa[q] = *reinterpret_cast<const float4*>(tb + ((2 * g) * 256 + (STAB_OFF(4) ? 0u : (code[q] & 255u))) * 4);
-                        xb[q] = *reinterpret_cast<const float4*>(tb + ((2 * g + 1) * 256 + (STAB_OFF(4) ? 0u : (code[q] >> 8))) * 4);
+                        xa[q] = *reinterpret_cast<const float4*>(tb + ((2 * dq) * 256 + (STAB_OFF(4) ? 0u : (code[q] & 255u))) * 4);
+                        xb[q] = *reinterpret_cast<const float4*>(tb + ((2 * dq + 1) * 256 + (STAB_OFF(4) ? 0u : (code[q] >> 8))) * 4);
                     }
                 }
-                ua = ua_n; ub = ub_n;
+                {
+                    const float* u_ = ul + (c & 1) * 1024;
+                    ua[0] = *reinterpret_cast<const float4*>(u_);       ub[0] = *reinterpret_cast<const float4*>(u_ + 64);
+                    ua[1] = *reinterpret_cast<const float4*>(u_ + 128); ub[1] = *reinterpret_cast<const float4*>(u_ + 192);
+                }
                 if (c + 1 < NCH) {
-                    if (!STAB_OFF(32)) {
-                        ua_n = *reinterpret_cast<const float4*>(Ur + (c + 1) * CD + lo);
-                        ub_n = *reinterpret_cast<const float4*>(Ur + (c + 1) * CD + hi);
-                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS + MPC * (c + 1)]
@@ -283,35 +327,39 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
             [[maybe_unused]] const long long tM = STAB_CLK();
             if (GNNLM_STAB_CLK) gap[1] += tM - tend;
             // ---------------- M(c)
+            if (!STAB_OFF(1)) {
+#define STAB_P1_STEP(xv_, uv_, e_)                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                  \
+        acc[q][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv_[q].e_, uv_[0].e_, acc[q][0], 0, 0, 0);                    \
+        acc[q][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv_[q].e_, uv_[1].e_, acc[q][1], 0, 0, 0);                    \
+    }
+                STAB_P1_STEP(xa, ua, x) STAB_P1_STEP(xa, ua, y) STAB_P1_STEP(xa, ua, z) STAB_P1_STEP(xa, ua, w)
+                STAB_P1_STEP(xb, ub, x) STAB_P1_STEP(xb, ub, y) STAB_P1_STEP(xb, ub, z) STAB_P1_STEP(xb, ub, w)
+#undef STAB_P1_STEP
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!STAB_OFF(1)) {
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].x, ua.x, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].y, ua.y, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].z, ua.z, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q].w, ua.w, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].x, ub.x, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].y, ub.y, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].z, ub.z, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q].w, ub.w, acc[q], 0, 0, 0);
-                } else {
-                    asm volatile("" :: "v"(xa[q].x), "v"(xa[q].w), "v"(xb[q].x), "v"(xb[q].w), "v"(ua.x), "v"(ub.w));
-                }
+                for (int q = 0; q < 4; ++q)
+                    asm volatile("" :: "v"(xa[q].x), "v"(xa[q].w), "v"(xb[q].x), "v"(xb[q].w), "v"(ua[0].x), "v"(ub[1].w));
             }
             STAB_PHASE_T(tM, tl[3], tl[4], tl[5])
         }
         if (!grp) STAB_PHASE()                                         // A finished one phase early
         __syncthreads();
         clk2 = STAB_CLK();
-        // C layout: acc[q][rr] = S[neighbour 64 half + 16 q + 4 g + rr][head n16]
-        if (n16 < HB) {
+        // C layout of the 16 blocks: acc[q][hh][rr] of lane (ng, dq, li) = the part of S[neighbour 64 half + 16 q + 4 ng + rr]
+        // [head 4 hh + li] that comes from the dims of sub-quantizer dq: the four dq lanes meet, dq = 0 writes
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t okw = *reinterpret_cast<const uint32_t*>(okf + t * KGM + 64 * half + 16 * q + 4 * g);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t okw = *reinterpret_cast<const uint32_t*>(okf + t * KGM + 64 * half + 16 * q + 4 * ng);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const int j = 64 * half + 16 * q + 4 * g + rr;
-                    sc[(t * HB + n16) * SCS + j] = ((okw >> (8 * rr)) & 1u) ? acc[q][rr] : -INFINITY;
+                    float v = acc[q][hh][rr];
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    const int j = 64 * half + 16 * q + 4 * ng + rr;
+                    if (dq == 0) sc[(t * HB + 4 * hh + li) * SCS + j] = ((okw >> (8 * rr)) & 1u) ? v : -INFINITY;
                 }
             }
         }
@@ -352,7 +400,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         const unsigned shift = 8 * (mloc & 3);
         const int widx = mloc >> 2;
         const unsigned char* cbase = lcodes + (t * KGM + 64 * kh + g) * MS;
-        float* zb = zpart + t * 512 + lane;                 // [2 tiles][4][32] partial sums of the kh = 1 wave
+        float* zb = zpart + ((kh * TPW + t) * HB + 4 * g) * CD + 2 * n16;   // this lane's dim pair of heads 4 g .. 4 g + 3
         uint32_t w[16];                 // code words of this lane's 16 neighbours for the chunk whose look-ups come next
         f32x2 b[16];
         f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
@@ -360,20 +408,11 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         for (int ks = 0; ks < 16; ++ks) w[ks] = reinterpret_cast<const uint32_t*>(cbase + 4 * ks * MS)[widx];
         // (parking the chunk's 8 x 32 sums in LDS to leave with one 16-B store per lane instead of four 8-B stores
         //  measured slower: 982 vs 962 us per 8192 tokens)
-        float* zo = p.Z + ((int64_t)i_tok * H + h0 + 4 * g) * D + DSUB * mloc + 2 * dp;
-#define STAB_ZSTORE(c_)                                                                              \
-    if (kh == 0 && g < 2 && live && !STAB_OFF(64)) {                                                 \
-        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                            \
-            if (h0 + 4 * g + rr < H)                                                                 \
-                *reinterpret_cast<float2*>(zo + (int64_t)rr * D + (c_) * CD) =                       \
-                    make_float2(z0[rr] + zb[32 * rr], z1[rr] + zb[128 + 32 * rr]);                   \
-    }
         if (grp) STAB_PHASE()                                          // B starts one phase late
         for (int c = 0; c < NCH; ++c) {
             // ---------------- L(c): look-ups of chunk c; the partial sums of chunk c - 1 meet and leave
             [[maybe_unused]] const long long tL = STAB_CLK();
             __builtin_amdgcn_s_setprio(1);
-            if (c > 0) STAB_ZSTORE(c - 1)
             {
                 const unsigned sb = lbase + (c & 1) * (TABF * 4);
 #pragma unroll
@@ -412,15 +451,14 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
                 z0 += y0;
                 z1 += y1;
             }
-            // C layout: z<ct>[rr] = Z[head 4 g + rr][dim of column n16 of tile ct]; heads 8..15 (g >= 2) are padding
-            if (kh == 1 && g < 2) {
+            // C layout: z<ct>[rr] = Z[head 4 g + rr][dim 2 n16 + ct]; heads 8..15 (g >= 2) are padding.  The loader waves add
+            // the two neighbour halves and store them in the next phase (see STAB_ZOUT).
+            if (g < 2) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) { zb[32 * rr] = z0[rr]; zb[128 + 32 * rr] = z1[rr]; }
+                for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<f32x2*>(zb + CD * rr) = f32x2{z0[rr], z1[rr]};
             }
             STAB_PHASE_T(tM, tl[9], tl[10], tl[11])
         }
-        STAB_ZSTORE(NCH - 1)                                           // the last chunk's sums
-#undef STAB_ZSTORE
         if (!grp) STAB_PHASE()                                         // A finished one phase early
     }
 #if GNNLM_STAB_CLK
