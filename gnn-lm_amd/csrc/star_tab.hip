@@ -42,6 +42,9 @@ namespace {
 #endif                       //   1 pass-1 MFMAs, 2 pass-2 MFMAs, 4 bank conflicts (every look-up reads row 0), 8 the table DMA,
                              //   16 code staging, 32 U loads in the sweep, 64 Z stores, 128 the table look-ups themselves
 #define STAB_OFF(bit_) ((GNNLM_STAB_OFF & (bit_)) != 0)
+#ifndef GNNLM_STAB_CLK
+#define GNNLM_STAB_CLK 0     // 1: cycle stamps of waves 0 and 4 of the first 256 workgroups written over has_nb (tools/star_clk.py)
+#endif
 
 constexpr int TPW = 4;                  // tokens per workgroup
 constexpr int KGM = 128;                // neighbours per token (padded)
@@ -52,14 +55,14 @@ constexpr int SCS = KGM + 4;            // score row stride: the heads of a toke
 constexpr int NTHREADS = 768;           // 8 compute waves (two per token) + 4 loader waves (table DMA only)
 
 struct Carve {
-    int tab, sc, zpart, okf, lcodes, total;     // byte offsets
+    int tab, sc, ubuf, okf, lcodes, total;      // byte offsets
 };
 __host__ __device__ inline Carve carve(int M) {
     Carve c;
     c.tab = 0;
     c.sc = c.tab + 2 * TABF * 4;
-    c.zpart = c.sc + TPW * HB * SCS * 4;
-    c.okf = c.zpart + TPW * 2 * 256 * 4;
+    c.ubuf = c.sc + TPW * HB * SCS * 4;
+    c.okf = c.ubuf + 2 * TPW * 1024;
     c.lcodes = c.okf + TPW * KGM;
     c.total = c.lcodes + ((TPW * KGM * (M + 4) + 15) & ~15);
     return c;
@@ -73,115 +76,50 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     const int MS = M + 4;                       // code row stride (bytes): rows of a tile sit on different banks
     const Carve cv = carve(M);
     float* tab = reinterpret_cast<float*>(smem + cv.tab);              // [2][TABF]
-    float* sc = reinterpret_cast<float*>(smem + cv.sc);                // [TPW][HB][SCS] scores -> alphas
-    // 8 KiB that serve both sweeps: pass 1 [2 buffers][TPW][64 slots of 16 B] the chunk's U rows in MFMA operand order,
-    // pass 2 [2 neighbour halves][TPW][HB][32] the chunk's partial sums on their way out
-    float* zpart = reinterpret_cast<float*>(smem + cv.zpart);
+    float* sc = reinterpret_cast<float*>(smem + cv.sc);                // pass 1 -> softmax: [TPW][HB][SCS] scores -> alphas
+    float* zbuf = sc;                                                  // pass 2: [2 buffers][2 neighbour halves][TPW][HB][CD] sums on their way out
+    float* ubuf = reinterpret_cast<float*>(smem + cv.ubuf);            // pass 1: [2 buffers][TPW][64 slots of 16 B] U rows in MFMA operand order
     unsigned char* okf = smem + cv.okf;                                // [TPW][KGM]
     unsigned char* lcodes = smem + cv.lcodes;                          // [TPW][KGM][MS]
+    static_assert(2 * 2 * TPW * HB * CD <= TPW * HB * SCS, "the outgoing sums reuse the score rows");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = wave >> 1, half = wave & 1;                          // token of this wave, neighbour half
-    const int grp = wave >> 2;                                         // ping-pong group (see the sweeps)
     const int n16 = lane & 15, g = lane >> 4;
     const int tok0 = blockIdx.x * TPW;
     const int i_tok = min(tok0 + t, p.T - 1);                          // tail workgroups recompute the last token
     const bool live = tok0 + t < p.T;
 
-    // ---------------------------------------------------------------- table chunk c -> LDS buffer b (32 KiB, linear)
-    // The DMA is issued from inline asm on purpose: hipcc treats a __builtin_amdgcn_global_load_lds in flight as a
-    // possible writer of EVERY LDS address and puts s_waitcnt vmcnt(0) in front of the table reads of the OTHER
-    // buffer (seen in the ISA of a first version of this kernel: the DMA of chunk c + 1 was drained before the first
-    // look-up of chunk c).  The asm loads are invisible to its counters; the kernel waits for them itself
-    // (STAB_LAND before the chunk barrier).  M0 = LDS byte address of the wave's 1-KiB piece.
-    const float* cen = p.centroids;
-    const unsigned tab_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)tab);
-    // pieces [p0_, p0_ + n_) of chunk c_ (32 pieces of 1 KiB) -> buffer b_
-#define STAB_DMA_PIECES(c_, b_, p0_, n_)                                                             \
-    {                                                                                                \
-        const float* src_ = cen + (int64_t)(c_) * TABF + (p0_) * 256 + lane * 4;                    \
-        const unsigned dst_ = tab_lds + (b_) * (TABF * 4) + (p0_) * 1024;                           \
-        _Pragma("unroll") for (int q = 0; q < (n_); ++q) {                                          \
-            unsigned keep_;                                                                          \
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                         : "=&s"(keep_) : "v"(src_ + q * 256), "s"(dst_ + q * 1024) : "memory");    \
-        }                                                                                            \
-    }
-#define STAB_DMA(c_, b_) STAB_DMA_PIECES(c_, b_, (wave - 8) * 8, 8)    /* the four loader waves, 8 pieces each */
-    // one DMA instruction: 16 B per lane from src_ (a per-lane pointer) to LDS bytes [dst_, dst_ + 1024) in lane order
+    // ---------------------------------------------------------------- LDS-DMA (global_load_lds_dwordx4: 16 B per lane, 1 KiB per
+    // instruction, lane order).  Issued from inline asm on purpose: hipcc treats a __builtin_amdgcn_global_load_lds in
+    // flight as a possible writer of EVERY LDS address and puts s_waitcnt vmcnt(0) in front of the table reads of the
+    // OTHER buffer (seen in the ISA of a first version of this kernel).  The asm loads are invisible to its counters;
+    // the loader waves wait for them themselves (vmcnt(0) before the chunk barrier).  M0 = LDS byte address.
 #define STAB_DMA_ONE(src_, dst_)                                                                     \
     {                                                                                                \
         unsigned keep_;                                                                              \
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
                      : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                              \
     }
-    // Loader waves 8..11 own the table DMA.  Issuing a 1-KiB LDS-DMA costs the issuing wave ~100-150 cycles here; with
-    // the compute waves issuing their own (4 or 8 per chunk) that was the longest item of their look-up phase (1.76k
-    // cycles per phase measured against 1.0k of MFMAs).  Global phase P: A's L(c) = 2c, B's L(c) = 2c + 1; chunk c + 1
-    // replaces chunk c - 1 (last read in phase 2c - 1): issued in phase 2c, landed by the end of phase 2c + 1.
-#define STAB_LOADER_SWEEP(extra_even_, extra_any_)                                                   \
-    for (int P = 0; P <= 2 * NCH; ++P) {                                                             \
-        const int c1 = (P >> 1) + 1;                                                                 \
-        if (!(P & 1) && c1 < NCH && !STAB_OFF(8)) {                                                  \
-            STAB_DMA(c1, c1 & 1)                                                                     \
-            extra_even_                                                                              \
-        }                                                                                            \
-        if (P & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
-        extra_any_                                                                                   \
-        STAB_PHASE()                                                                                 \
-    }
-// -DGNNLM_STAB_CLK=1: cycle stamps of wave 0 of the first 256 workgroups, written over has_nb (a timing build, wrong has_nb):
-// [0] staging, [1] pass 1, [2] softmax, [3] pass 2
-#ifndef GNNLM_STAB_CLK
-#define GNNLM_STAB_CLK 0
-#endif
-#ifndef GNNLM_STAB_CLKW
-#define GNNLM_STAB_CLKW 0   // the compute wave whose stamps are written
-#endif
 #if GNNLM_STAB_CLK
 #define STAB_CLK() clock64()
 #else
 #define STAB_CLK() 0ll
 #endif
-// the sched_barrier keeps the chunk's MFMAs (register-only, free to move for the compiler) ABOVE the wait: the DMA
-// of the next chunk then flies under them instead of being waited for first
-#define STAB_LAND()                                   \
-    {                                                 \
-        __builtin_amdgcn_sched_barrier(0);            \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-    }
-// Phase barrier of the ping-pong: LDS traffic of this wave done, then s_barrier -- and NOTHING else: __syncthreads()
-// would also drain the vector-memory counter, i.e. wait in every phase for the U loads / Z stores / DMA that are
-// meant to fly across phases (a first ping-pong version did, and every phase cost a memory round trip: 1.42 ms).
-// The "memory" clobber keeps the compiler's loads and stores on their side; MFMAs are pinned by the sched_barriers.
-#define STAB_PHASE()                                                  \
+    // Chunk barrier: LDS traffic of this wave done, then s_barrier -- and nothing else (__syncthreads() would also drain
+    // the vector-memory counter).  The "memory" clobber keeps the compiler's loads and stores on their side, the
+    // sched_barriers pin the MFMAs (register-only, otherwise free to move).
+#define STAB_SYNC()                                                   \
     {                                                                 \
         __builtin_amdgcn_sched_barrier(0);                            \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         __builtin_amdgcn_sched_barrier(0);                            \
     }
-// the same with the time of the phase's body (from t_), of the LDS drain and of the barrier accounted (CLK builds)
-#if GNNLM_STAB_CLK
-#define STAB_PHASE_T(t_, body_, wait_, bar_)                          \
-    {                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                            \
-        const long long a_ = STAB_CLK();                              \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            \
-        const long long b_ = STAB_CLK();                              \
-        asm volatile("s_barrier" ::: "memory");                       \
-        const long long c_ = STAB_CLK();                              \
-        body_ += a_ - (t_); wait_ += b_ - a_; bar_ += c_ - b_; tend = c_; \
-        __builtin_amdgcn_sched_barrier(0);                            \
-    }
-#else
-#define STAB_PHASE_T(t_, body_, wait_, bar_) STAB_PHASE()
-#endif
-    [[maybe_unused]] long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // pass 1: L body/wait/barrier, M body/wait/barrier; pass 2 likewise
-    [[maybe_unused]] long long tend = 0, gap[2] = {0, 0};
+#define STAB_PIN() __builtin_amdgcn_sched_barrier(0)
     [[maybe_unused]] const long long clk0 = STAB_CLK();
 
-    // ---------------------------------------------------------------- phase 0: validity, code rows (zeros when invalid)
+    // ---------------------------------------------------------------- staging: validity, code rows (zeros when invalid)
     for (int e = tid; e < TPW * KGM; e += NTHREADS) {
         const int tt = e >> 7, j = e & (KGM - 1);
         const int i = min(tok0 + tt, p.T - 1);
@@ -189,87 +127,152 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     }
     __syncthreads();
     {
-        const int per_row = M >> 4;
-        for (int e = tid; e < TPW * KGM * per_row; e += NTHREADS) {
-            const int row = e / per_row, part = e - row * per_row;
-            const int tt = row >> 7, j = row & (KGM - 1);
-            const int i = min(tok0 + tt, p.T - 1);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (okf[row] && !STAB_OFF(16)) {
-                const int64_t lrow = star_code_row(p, i, j, p.ids[(int64_t)i * kg + j]);
-                v = *reinterpret_cast<const uint4*>(p.codes + lrow * M + 16 * part);
+        // six 16-B pieces per thread and round, the loads of a round in flight together (one piece after the other paid two
+        // memory round trips per piece: 20k cycles of staging per workgroup)
+        constexpr int RB = 6;
+        const int per_row = M >> 4, n_items = TPW * KGM * per_row;
+        for (int e0 = 0; e0 < n_items; e0 += RB * NTHREADS) {
+            int64_t src[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int e = e0 + r * NTHREADS + tid;
+                src[r] = -1;
+                if (e < n_items) {
+                    const int row = e / per_row, part = e - row * per_row;
+                    const int tt = row >> 7, j = row & (KGM - 1);
+                    const int i = min(tok0 + tt, p.T - 1);
+                    if (okf[row] && !STAB_OFF(16)) src[r] = star_code_row(p, i, j, p.ids[(int64_t)i * kg + j]) * M + 16 * part;
+                }
             }
-            uint32_t* dst = reinterpret_cast<uint32_t*>(lcodes + row * MS + 16 * part);
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            uint4 v[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) v[r] = src[r] >= 0 ? *reinterpret_cast<const uint4*>(p.codes + src[r]) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int e = e0 + r * NTHREADS + tid;
+                if (e < n_items) {
+                    const int row = e / per_row, part = e - row * per_row;
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(lcodes + row * MS + 16 * part);
+                    dst[0] = v[r].x; dst[1] = v[r].y; dst[2] = v[r].z; dst[3] = v[r].w;
+                }
+            }
         }
     }
+
+    // Both sweeps have the same skeleton.  Chunk k of the table lives in buffer k & 1.  Iteration c of a compute wave issues
+    // the MFMAs of chunk c from registers, INTERLEAVED with the look-ups of chunk c + 1 into a second register set, then the
+    // chunk barrier E(c).  After E(k - 1) nobody reads buffer k & 1 any more (its look-ups were waited for before the
+    // barrier): the loader waves refill it with chunk k + 2 during iteration k and wait for the DMA before E(k).
+    //   Why not a ping-pong of two wave groups (one on the matrix pipe while its SIMD partner does its look-ups; an earlier
+    // version of this file): cycle stamps showed that a wave makes NO progress while its partner on the SIMD streams
+    // MFMAs back to back -- the look-up phase of group B started when the last MFMA of group A had issued and vice versa,
+    // the per-chunk period was the SUM of both groups' MFMA and look-up times (850-960 us per 8192 tokens).  Within one
+    // wave an LDS read or a VALU instruction issues in the shadow of the wave's own previous MFMA, so the overlap has to
+    // be built inside each wave.
+    //   No compute wave issues a vector-memory instruction inside the sweeps: U arrives in LDS and Z leaves through LDS,
+    // both moved by the loader waves (with U loads and Z stores in the compute waves each of them queued behind the table
+    // DMA at the texture unit and stalled its wave at issue: 102 + 81 us of 967).
     if (wave >= 8) {
-        // ============================================================ loader waves: the table DMA of both sweeps, and
-        // every barrier of the compute path below, in the same order
-        // No compute wave issues a vector-memory instruction inside the sweeps: its U operands arrive in LDS and its sums
-        // leave through LDS, both moved by these waves.  (With the U loads and Z stores in the compute waves each of
-        // them queued behind the table DMA at the texture unit, 64 B per clock per CU, and stalled its wave at issue:
-        // switching off the U loads / the Z stores / the DMA saved 102 / 81 / 96 us of 967 per 8192 tokens.)
-        const int lw = wave - 8;                                        // U: loader wave lw moves token lw's rows
+        // ============================================================ loader waves 8..11
+        const int lw = wave - 8;
+        __builtin_amdgcn_s_setprio(3);     // few instructions, all on the critical path of the next chunk: never queue behind the MFMA streams
+        const unsigned tab_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)tab) + lw * 8192;
+        const float* tsrc = p.centroids + lw * 2048 + lane * 4;          // wave lw moves pieces 8 lw .. 8 lw + 7 of a chunk
+#define STAB_DMA_TAB(c_)                                                                             \
+    if (!STAB_OFF(8)) {                                                                              \
+        const float* s_ = tsrc + (int64_t)(c_) * TABF;                                               \
+        const unsigned d_ = tab_lds + ((c_) & 1) * (TABF * 4);                                       \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) STAB_DMA_ONE(s_ + q * 256, d_ + q * 1024)     \
+    }
+        // U: wave lw moves token lw's rows of the chunk; lane = slot (hh, ab, dq, li): 16 B of head 4 hh + li, sub-quantizer
+        // dq, first (ab = 0) or second half in the order the lane group of dq reads its centroid rows (see pass 1)
         const float* usrc;
         {
             const int hh = lane >> 5, ab = (lane >> 4) & 1, dq_ = (lane >> 2) & 3, li_ = lane & 3;
             const int lo_ = DSUB == 8 ? 4 * (dq_ & 1) : 0;
             usrc = p.U + ((int64_t)min(tok0 + lw, p.T - 1) * H + h0 + min(4 * hh + li_, H - 1 - h0)) * D + 8 * dq_ + (ab ? 4 - lo_ : lo_);
         }
-        const unsigned u_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)zpart) + lw * 1024;
+        const unsigned u_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)ubuf) + lw * 1024;
 #define STAB_DMA_U(c_) if (!STAB_OFF(32)) STAB_DMA_ONE(usrc + (c_) * CD, u_lds + ((c_) & 1) * 4096)
-        STAB_DMA(0, 0)
-        STAB_DMA_U(0)
+#define STAB_LAND() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+        STAB_DMA_TAB(0) STAB_DMA_U(0)
+        if (NCH > 1) { STAB_DMA_TAB(1) STAB_DMA_U(1) }
         STAB_LAND();
-        __syncthreads();                // codes staged, chunk 0 landed
-        STAB_LOADER_SWEEP(STAB_DMA_U(c1), )
-#undef STAB_DMA_U
-        __syncthreads();                // end of pass 1
-        STAB_DMA(0, 0)
+        __syncthreads();                // codes staged, chunks 0 and 1 landed
+        STAB_SYNC()                     // E(-1)
+        [[maybe_unused]] long long lt[6] = {0, 0, 0, 0, 0, 0};      // CLK builds: cycles issuing / landing / at the barrier, per sweep
+        // Pass 1 has a second barrier H(k) inside iteration k, behind the look-ups of chunk k + 1: from there on buffer
+        // (k + 1) & 1 is free, and chunk k + 3 has until E(k + 1) to arrive -- about 1.5 iterations instead of one.  (Issuing
+        // a chunk's nine DMA instructions costs a loader wave 0.4-1.3k cycles next to the MFMA streams, its landing
+        // another 1.1k: with issue and landing inside ONE iteration the sweep ran at 2.8k cycles per chunk, DMA-bound.)
+        if (NCH > 2) { STAB_DMA_TAB(2) STAB_DMA_U(2) }
+        for (int k = 0; k < NCH; ++k) {
+            STAB_SYNC()                 // H(k)
+            [[maybe_unused]] const long long a_ = STAB_CLK();
+            if (k + 3 < NCH) {
+                STAB_DMA_TAB(k + 3) STAB_DMA_U(k + 3)
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");    // chunk k + 2 has landed (loads return in order)
+            } else {
+                STAB_LAND();
+            }
+            [[maybe_unused]] const long long c_ = STAB_CLK();
+            STAB_SYNC()                 // E(k)
+            if (GNNLM_STAB_CLK) { lt[1] += c_ - a_; lt[2] += STAB_CLK() - c_; }
+        }
+        STAB_DMA_TAB(0)
+        if (NCH > 1) STAB_DMA_TAB(1)
         __syncthreads();                // scores written
         STAB_LAND();
-        __syncthreads();                // alphas written, chunk 0 landed
-        // Z: in phase P the sums of chunk (P - 2) / 2 of tokens 0, 1 (P even) or of chunk (P - 3) / 2 of tokens 2, 3 (P odd)
-        // are complete (written one phase earlier): 128 lanes add the two neighbour halves and store 16 B each
-        const int ze = lw * 32 + (lane & 31);                           // (token of the pair, head, 4-dim group)
-        const int zt = ze >> 6, zh = (ze >> 3) & 7, zq = ze & 7;
-#define STAB_ZOUT(tt_, c_)                                                                           \
-    if (lane < 32 && tok0 + (tt_) < p.T && h0 + zh < H && !STAB_OFF(64)) {                           \
-        const float* z_ = zpart + ((tt_) * HB + zh) * CD + 4 * zq;                                   \
+        __syncthreads();                // alphas written, chunks 0 and 1 landed
+        // Z: wave lw adds the two neighbour halves of token lw's sums of a chunk and stores 16 B per lane
+        const int zh = lane >> 3, zq = lane & 7;
+        const bool zlive = tok0 + lw < p.T && h0 + zh < H && !STAB_OFF(64);
+        const float* zsrc = zbuf + (lw * HB + zh) * CD + 4 * zq;
+        float* zdst = p.Z + ((int64_t)min(tok0 + lw, p.T - 1) * H + h0 + min(zh, H - 1 - h0)) * D + 4 * zq;
+#define STAB_ZOUT(c_)                                                                                \
+    if (zlive) {                                                                                     \
+        const float* z_ = zsrc + ((c_) & 1) * (2 * TPW * HB * CD);                                   \
         const float4 a_ = *reinterpret_cast<const float4*>(z_);                                      \
         const float4 b_ = *reinterpret_cast<const float4*>(z_ + TPW * HB * CD);                      \
-        *reinterpret_cast<float4*>(p.Z + ((int64_t)(tok0 + (tt_)) * H + h0 + zh) * D + (c_) * CD + 4 * zq) = \
-            make_float4(a_.x + b_.x, a_.y + b_.y, a_.z + b_.z, a_.w + b_.w);                         \
+        *reinterpret_cast<float4*>(zdst + (c_) * CD) = make_float4(a_.x + b_.x, a_.y + b_.y, a_.z + b_.z, a_.w + b_.w); \
     }
-        STAB_LOADER_SWEEP(, if (P >= 2) STAB_ZOUT(2 * (P & 1) + zt, (P - 2 - (P & 1)) >> 1))
-        STAB_ZOUT(2 + zt, NCH - 1)
+        STAB_SYNC()                     // E(-1)
+        for (int k = 0; k < NCH; ++k) {
+            [[maybe_unused]] const long long a_ = STAB_CLK();
+            if (k > 0) STAB_ZOUT(k - 1)
+            if (k + 2 < NCH) STAB_DMA_TAB(k + 2)
+            [[maybe_unused]] const long long b_ = STAB_CLK();
+            STAB_LAND();                // (also the Z store: issued first, so its round trip is under the DMA's)
+            [[maybe_unused]] const long long c_ = STAB_CLK();
+            STAB_SYNC()                 // E(k)
+            if (GNNLM_STAB_CLK) { lt[3] += b_ - a_; lt[4] += c_ - b_; lt[5] += STAB_CLK() - c_; }
+        }
+        STAB_ZOUT(NCH - 1)
+#if GNNLM_STAB_CLK
+        if (blockIdx.x < 256 && tid == 512 && p.has_nb) {
+            unsigned* o = reinterpret_cast<unsigned*>(p.has_nb) + blockIdx.x * 32 + 8;
+            for (int e = 0; e < 6; ++e) o[e] = (unsigned)lt[e];
+        }
+#endif
 #undef STAB_ZOUT
+#undef STAB_DMA_U
+#undef STAB_DMA_TAB
+#undef STAB_LAND
         return;
     }
 
-    // Both sweeps run as a PING-PONG between the two halves of the workgroup.  Waves w and w + 4 share a SIMD (the
-    // dispatcher deals a workgroup's waves round the SIMDs; measured with tools/probes/mfma_16x16x4.hip), group A =
-    // waves 0..3 (tokens 0, 1), group B = waves 4..7 (tokens 2, 3).  Every chunk c is two phases per group,
-    //     L(c): the look-ups of chunk c into registers, barrier
-    //     M(c): the 32 MFMAs of chunk c, barrier
-    // and B runs one phase behind A, so on every SIMD one wave is on the matrix pipe while its partner is on the LDS /
-    // DMA path.  Why: with all eight waves in the same phase (first versions of this kernel, 1.0 ms per 8192 tokens)
-    // the burst of look-ups and DMA issues of a step and its MFMAs never overlapped -- in-kernel cycle stamps
-    // (-DGNNLM_STAB_CLK=1) showed ~1000 cycles of look-up latency + ~1000 cycles of MFMAs at full rate + ~1400 cycles
-    // waiting for the slower waves per step, against 2048 cycles of MFMA issue per SIMD; software pipelining inside a
-    // wave cannot fix that (in-order issue, 15 LDS operations in flight per wave).
-    // Table buffer c & 1 is read in L(c): by A in phase 2c, by B in phase 2c + 1; the loader waves refill it with chunk
-    // c + 2 in phases 2c + 2 / 2c + 3 (STAB_LOADER_SWEEP).
     [[maybe_unused]] long long clk1 = 0, clk2 = 0, clk3 = 0;
-
-    // ================================================================ pass 1: S[128 nb x 16 (8 real) heads] = X U^T
+    // ================================================================ pass 1: S[128 nb x 8 heads] = X U^T on v_mfma_f32_4x4x1 (16 blocks)
+    // Block b = lane / 4 of an MFMA is (neighbour group ng = b / 4, sub-quantizer dq = b % 4 of the chunk); lane li = lane % 4
+    // of the block supplies, for k step e, A = X[neighbour 4 ng + li][dim e of sub-quantizer dq] and B = U[head li (+ 4)][same dim]:
+    // the block accumulates the 4 x 4 tile S[4 neighbours][4 heads] restricted to its sub-quantizer's dims.  All 16 columns
+    // of the operand are real work (on the 16x16x4 shape the 8 heads filled half of the 16 columns: twice the MFMA time).
+    // The lane's A operands of a chunk ARE its look-up: the 32-B centroid row of (neighbour, sub-quantizer), two
+    // ds_read_b128; odd dq read the two halves in the other order so that a 16-lane read group spreads over all 16 slots
+    // of the bank window (the U side is stored by the loader in the same order).
     {
-        // lane (n16, g) carries U[head n16 & 7][chunk dims of k slot g]: the 8 dims of sub-quantizer 4c + g (dsub 8; odd
-        // g with the two halves swapped, see the header) or of the pair 8c + 2g, 8c + 2g + 1 (dsub 4)
         const int li = lane & 3, dq = (lane >> 2) & 3, ng = lane >> 4;
-        // U[head 4 hh + li][the 8 dims of sub-quantizer dq] as two float4 (halves in this lane's look-up order), from LDS
-        const float* ul = zpart + t * 256 + (dq * 4 + li) * 4;
+        const float* ul = ubuf + t * 256 + (dq * 4 + li) * 4;
         const int lo = DSUB == 8 ? 4 * (dq & 1) : 0, hi = 4 - lo;
         f32x4 acc[4][2];
 #pragma unroll
@@ -277,74 +280,74 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         // code bytes of this lane: neighbour 64 half + 16 q + 4 ng + li, sub-quantizer(s) dq of the chunk (padding rows are zeros)
         const unsigned char* crow = lcodes + (t * KGM + 64 * half + 4 * ng + li) * MS + (DSUB == 8 ? dq : 2 * dq);
         unsigned code[4];
-        float4 xa[4], xb[4];
-        float4 ua[2], ub[2];
-        STAB_LAND();
-        __syncthreads();                                               // codes staged, chunk 0 landed
+        float4 xa[2][4], xb[2][4], ua[2][2], ub[2][2];
+        __syncthreads();                                               // codes staged, chunks 0 and 1 landed
         clk1 = STAB_CLK();
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS] : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS);
-        if (grp) STAB_PHASE()                                          // B starts one phase late
-        for (int c = 0; c < NCH; ++c) {
-            // ---------------- L(c)
-            {
-                [[maybe_unused]] const long long tL = STAB_CLK();
-                if (GNNLM_STAB_CLK && c > 0) gap[0] += tL - tend;
-                // The look-up phase runs at raised priority: its VALU / LDS instructions compete for issue slots with the
-                // partner wave's MFMA stream, and the younger group (waves 4..7) loses that arbitration at equal priority
-                // (its look-up phases measured 1.6-2.0k cycles against 0.5-1.1k for the older group's).
-                __builtin_amdgcn_s_setprio(1);
-                const float* tb = tab + (c & 1) * TABF;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {                          // the look-ups ARE the A operands
-                    if (STAB_OFF(128)) {
-                        xa[q] = make_float4(1.f, 2.f, 3.f, (float)code[q]);
-                        xb[q] = xa[q];
-                    } else if constexpr (DSUB == 8) {
-                        const float* r_ = tb + (dq * 256 + (STAB_OFF(4) ? 0u : code[q])) * 8;
-                        xa[q] = *reinterpret_cast<const float4*>(r_ + lo);
-                        xb[q] = *reinterpret_cast<const float4*>(r_ + hi);
-                    } else {
-                        xa[q] = *reinterpret_cast<const float4*>(tb + ((2 * dq) * 256 + (STAB_OFF(4) ? 0u : (code[q] & 255u))) * 4);
-                        xb[q] = *reinterpret_cast<const float4*>(tb + ((2 * dq + 1) * 256 + (STAB_OFF(4) ? 0u : (code[q] >> 8))) * 4);
-                    }
-                }
-                {
-                    const float* u_ = ul + (c & 1) * 1024;
-                    ua[0] = *reinterpret_cast<const float4*>(u_);       ub[0] = *reinterpret_cast<const float4*>(u_ + 64);
-                    ua[1] = *reinterpret_cast<const float4*>(u_ + 128); ub[1] = *reinterpret_cast<const float4*>(u_ + 192);
-                }
-                if (c + 1 < NCH) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS + MPC * (c + 1)]
-                                            : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS + MPC * (c + 1));
-                }
-                __builtin_amdgcn_s_setprio(0);
-                STAB_PHASE_T(tL, tl[0], tl[1], tl[2])
-            }
-            [[maybe_unused]] const long long tM = STAB_CLK();
-            if (GNNLM_STAB_CLK) gap[1] += tM - tend;
-            // ---------------- M(c)
-            if (!STAB_OFF(1)) {
-#define STAB_P1_STEP(xv_, uv_, e_)                                                                                   \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                  \
-        acc[q][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv_[q].e_, uv_[0].e_, acc[q][0], 0, 0, 0);                    \
-        acc[q][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv_[q].e_, uv_[1].e_, acc[q][1], 0, 0, 0);                    \
+#define STAB_CODES(c_)                                                                               \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                    \
+        code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS + MPC * (c_)]                               \
+                            : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS + MPC * (c_));
+        // look-up of tile q_ of the chunk in table buffer tb_ into register set s_
+#define STAB_LOOK(s_, q_, tb_)                                                                       \
+    if (STAB_OFF(128)) {                                                                             \
+        xa[s_][q_] = make_float4(1.f, 2.f, 3.f, (float)code[q_]); xb[s_][q_] = xa[s_][q_];           \
+    } else if constexpr (DSUB == 8) {                                                                \
+        const float* r_ = (tb_) + (dq * 256 + (STAB_OFF(4) ? 0u : code[q_])) * 8;                   \
+        xa[s_][q_] = *reinterpret_cast<const float4*>(r_ + lo);                                      \
+        xb[s_][q_] = *reinterpret_cast<const float4*>(r_ + hi);                                      \
+    } else {                                                                                         \
+        xa[s_][q_] = *reinterpret_cast<const float4*>((tb_) + ((2 * dq) * 256 + (STAB_OFF(4) ? 0u : (code[q_] & 255u))) * 4);     \
+        xb[s_][q_] = *reinterpret_cast<const float4*>((tb_) + ((2 * dq + 1) * 256 + (STAB_OFF(4) ? 0u : (code[q_] >> 8))) * 4);   \
     }
-                STAB_P1_STEP(xa, ua, x) STAB_P1_STEP(xa, ua, y) STAB_P1_STEP(xa, ua, z) STAB_P1_STEP(xa, ua, w)
-                STAB_P1_STEP(xb, ub, x) STAB_P1_STEP(xb, ub, y) STAB_P1_STEP(xb, ub, z) STAB_P1_STEP(xb, ub, w)
-#undef STAB_P1_STEP
-            } else {
+#define STAB_ULOOK(s_, u_)                                                                           \
+    ua[s_][0] = *reinterpret_cast<const float4*>(u_);       ub[s_][0] = *reinterpret_cast<const float4*>((u_) + 64);  \
+    ua[s_][1] = *reinterpret_cast<const float4*>((u_) + 128); ub[s_][1] = *reinterpret_cast<const float4*>((u_) + 192);
+        // 8 MFMAs: k step e_ of the halves xv_ / uv_ of register set s_, all four tiles, both head groups
+#define STAB_P1_STEP(s_, xv_, uv_, e_)                                                               \
+    if (!STAB_OFF(1)) {                                                                              \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                              \
+            acc[q][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv_[s_][q].e_, uv_[s_][0].e_, acc[q][0], 0, 0, 0); \
+            acc[q][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv_[s_][q].e_, uv_[s_][1].e_, acc[q][1], 0, 0, 0); \
+        }                                                                                            \
+    } else {                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) asm volatile("" :: "v"(xv_[s_][q].e_), "v"(uv_[s_][0].e_), "v"(uv_[s_][1].e_)); \
+    }
+        // iteration c_: MFMAs of chunk c_ from set cur_, look-ups of chunk c_ + 1 into set nxt_ (the last iteration looks up a
+        // buffer nobody refills: harmless), code bytes of chunk c_ + 2
+#define STAB_P1_ITER(c_, cur_, nxt_)                                                                 \
+    {                                                                                                \
+        const float* tb_ = tab + (((c_) + 1) & 1) * TABF;                                            \
+        const float* u_ = ul + (((c_) + 1) & 1) * 1024;                                              \
+        const int c2_ = min((c_) + 2, NCH - 1);                                                      \
+        STAB_P1_STEP(cur_, xa, ua, x) STAB_PIN(); STAB_LOOK(nxt_, 0, tb_) STAB_LOOK(nxt_, 1, tb_) STAB_PIN(); \
+        STAB_P1_STEP(cur_, xa, ua, y) STAB_PIN(); STAB_LOOK(nxt_, 2, tb_) STAB_LOOK(nxt_, 3, tb_) STAB_PIN(); \
+        STAB_P1_STEP(cur_, xa, ua, z) STAB_PIN(); STAB_ULOOK(nxt_, u_) STAB_PIN();                   \
+        STAB_P1_STEP(cur_, xa, ua, w)                                                                \
+        STAB_P1_STEP(cur_, xb, ub, x)                                                                \
+        STAB_SYNC()                 /* H(c_): nobody reads buffer (c_ + 1) & 1 any more */           \
+        STAB_P1_STEP(cur_, xb, ub, y) STAB_PIN(); STAB_CODES(c2_) STAB_PIN();                        \
+        STAB_P1_STEP(cur_, xb, ub, z)                                                                \
+        STAB_P1_STEP(cur_, xb, ub, w)                                                                \
+        STAB_SYNC()                 /* E(c_) */                                                      \
+    }
+        STAB_CODES(0)
+        {
+            const float* tb_ = tab;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    asm volatile("" :: "v"(xa[q].x), "v"(xa[q].w), "v"(xb[q].x), "v"(xb[q].w), "v"(ua[0].x), "v"(ub[1].w));
-            }
-            STAB_PHASE_T(tM, tl[3], tl[4], tl[5])
+            for (int q = 0; q < 4; ++q) { STAB_LOOK(0, q, tb_) }
+            STAB_ULOOK(0, ul)
         }
-        if (!grp) STAB_PHASE()                                         // A finished one phase early
-        __syncthreads();
+        STAB_CODES(min(1, NCH - 1))
+        STAB_SYNC()                                                    // E(-1)
+        for (int c = 0; c < NCH; c += 2) {
+            STAB_P1_ITER(c, 0, 1)
+            if (c + 1 < NCH) STAB_P1_ITER(c + 1, 1, 0)
+        }
+#undef STAB_P1_ITER
+#undef STAB_P1_STEP
+#undef STAB_ULOOK
+#undef STAB_LOOK
+#undef STAB_CODES
         clk2 = STAB_CLK();
         // C layout of the 16 blocks: acc[q][hh][rr] of lane (ng, dq, li) = the part of S[neighbour 64 half + 16 q + 4 ng + rr]
         // [head 4 hh + li] that comes from the dims of sub-quantizer dq: the four dq lanes meet, dq = 0 writes
@@ -366,116 +369,112 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     }
     __syncthreads();
     // ---------------------------------------------------------------- softmax over the neighbours: wave (t, half) -> heads 4 half ..
+    float a_reg[16];
+    {
+        float al[4][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float* row = sc + (t * HB + 4 * half + q) * SCS;
-        const float v0 = row[lane], v1 = row[64 + lane];
-        const float mx = wave_max(fmaxf(v0, v1));
-        const float e0 = v0 == -INFINITY ? 0.f : expf(v0 - mx), e1 = v1 == -INFINITY ? 0.f : expf(v1 - mx);
-        const float sum = wave_sum(e0 + e1);
-        const float inv = sum > 0.f ? 1.f / sum : 0.f;
-        row[lane] = e0 * inv;
-        row[64 + lane] = e1 * inv;
-        if (q == 0 && half == 0 && h0 == 0 && lane == 0 && p.has_nb && live && !GNNLM_STAB_CLK) p.has_nb[i_tok] = sum > 0.f ? 1.f : 0.f;
+        for (int q = 0; q < 4; ++q) {
+            float* row = sc + (t * HB + 4 * half + q) * SCS;
+            const float v0 = row[lane], v1 = row[64 + lane];
+            const float mx = wave_max(fmaxf(v0, v1));
+            const float e0 = v0 == -INFINITY ? 0.f : expf(v0 - mx), e1 = v1 == -INFINITY ? 0.f : expf(v1 - mx);
+            const float sum = wave_sum(e0 + e1);
+            const float inv = sum > 0.f ? 1.f / sum : 0.f;
+            al[q][0] = e0 * inv;
+            al[q][1] = e1 * inv;
+            if (q == 0 && half == 0 && h0 == 0 && lane == 0 && p.has_nb && live && !GNNLM_STAB_CLK) p.has_nb[i_tok] = sum > 0.f ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* row = sc + (t * HB + 4 * half + q) * SCS;
+            row[lane] = al[q][0];
+            row[64 + lane] = al[q][1];
+        }
     }
-    STAB_LAND();
-    __syncthreads();                    // alphas written, chunk 0 landed
+    __syncthreads();                    // alphas written, chunks 0 and 1 landed
     clk3 = STAB_CLK();
 
     // ================================================================ pass 2: Z[16 (8 real) heads x 32 dims] = alpha^T X per chunk
     {
         const int kh = half;
         // k step ks, lane group g  <->  neighbour j = 64 kh + 4 ks + g (alpha = 0 and code row = zeros for padding)
-        float a_reg[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) a_reg[ks] = n16 < HB ? sc[(t * HB + n16) * SCS + 64 * kh + 4 * ks + g] : 0.f;
         // The two 16-column MFMA tiles of a chunk take the EVEN and the ODD dims: column n of tile ct is dim
-        // DSUB * mloc + 2 * dp + ct with mloc = n / (DSUB / 2), dp = n % (DSUB / 2).  A lane's two B operands are then
-        // neighbours in one centroid row: ONE ds_read_b64 and one code byte per k step feed both MFMAs (a first version
-        // gave tile ct the dims 16 ct .. 16 ct + 15: two ds_read_b32 from two rows, twice the look-ups and twice the
-        // address arithmetic; the LDS, not the matrix pipe, set the pace of this pass).
+        // DSUB * mloc + 2 * dp + ct = 2 n + ct with mloc = n / (DSUB / 2), dp = n % (DSUB / 2).  A lane's two B operands are
+        // then neighbours in one centroid row: ONE ds_read_b64 and one code byte per k step feed both MFMAs.
         constexpr unsigned ROWSH = DSUB == 8 ? 5 : 4;      // log2 of a centroid row in bytes
         const int mloc = n16 / (DSUB / 2), dp = n16 % (DSUB / 2);
         const unsigned lbase = (unsigned)(uintptr_t)(lds_void_t*)tab + (mloc * 256 * DSUB + 2 * dp) * 4;   // (row 0, dim pair) in buffer 0
         const unsigned shift = 8 * (mloc & 3);
         const int widx = mloc >> 2;
         const unsigned char* cbase = lcodes + (t * KGM + 64 * kh + g) * MS;
-        float* zb = zpart + ((kh * TPW + t) * HB + 4 * g) * CD + 2 * n16;   // this lane's dim pair of heads 4 g .. 4 g + 3
+        float* zb = zbuf + ((kh * TPW + t) * HB + 4 * g) * CD + 2 * n16;     // this lane's dim pair of heads 4 g .. 4 g + 3
         uint32_t w[16];                 // code words of this lane's 16 neighbours for the chunk whose look-ups come next
-        f32x2 b[16];
-        f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+        f32x2 b[2][16];
+#define STAB_W(ks_, c_) w[ks_] = reinterpret_cast<const uint32_t*>(cbase + 4 * (ks_) * MS + MPC * (c_))[widx];
+#define STAB_BLOOK(s_, ks_, sb_)                                                                     \
+    {                                                                                                \
+        const unsigned cc_ = STAB_OFF(4) ? 0u : __builtin_amdgcn_ubfe(w[ks_], shift, 8u);            \
+        if (STAB_OFF(128)) b[s_][ks_] = f32x2{(float)cc_, 1.f};                                      \
+        else b[s_][ks_] = *(lds_cfloat2_t*)(uintptr_t)((cc_ << ROWSH) + (sb_));                      \
+    }
+        // iteration c_: per k step the look-up of chunk c_ + 1 (the B operands ARE the look-ups), the code word of chunk
+        // c_ + 2 into the register just consumed, two MFMAs of chunk c_; four accumulator chains
+#define STAB_P2_ITER(c_, cur_, nxt_)                                                                 \
+    {                                                                                                \
+        const unsigned sb_ = lbase + (((c_) + 1) & 1) * (TABF * 4);                                  \
+        const int c2_ = min((c_) + 2, NCH - 1);                                                      \
+        f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0, y0 = z0, y1 = z0;                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 16; ks += 2) {                                      \
+            STAB_BLOOK(nxt_, ks, sb_) STAB_W(ks, c2_)                                                \
+            if (!STAB_OFF(2)) {                                                                      \
+                z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[cur_][ks].x, z0, 0, 0, 0);    \
+                z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[cur_][ks].y, z1, 0, 0, 0);    \
+            } else asm volatile("" :: "v"(b[cur_][ks].x), "v"(b[cur_][ks].y));                        \
+            STAB_PIN();                                                                              \
+            STAB_BLOOK(nxt_, ks + 1, sb_) STAB_W(ks + 1, c2_)                                        \
+            if (!STAB_OFF(2)) {                                                                      \
+                y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks + 1], b[cur_][ks + 1].x, y0, 0, 0, 0); \
+                y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks + 1], b[cur_][ks + 1].y, y1, 0, 0, 0); \
+            } else asm volatile("" :: "v"(b[cur_][ks + 1].x), "v"(b[cur_][ks + 1].y));                \
+            STAB_PIN();                                                                              \
+        }                                                                                            \
+        z0 += y0; z1 += y1;                                                                          \
+        /* C layout: z<ct>[rr] = Z[head 4 g + rr][dim 2 n16 + ct]; heads 8..15 (g >= 2) are padding.  The loader waves add */ \
+        /* the two neighbour halves and store them during the next iteration. */                   \
+        if (g < 2) {                                                                                 \
+            float* zo_ = zb + ((c_) & 1) * (2 * TPW * HB * CD);                                      \
+            _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<f32x2*>(zo_ + CD * rr) = f32x2{z0[rr], z1[rr]}; \
+        }                                                                                            \
+        STAB_SYNC()                                                                                  \
+    }
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) w[ks] = reinterpret_cast<const uint32_t*>(cbase + 4 * ks * MS)[widx];
-        // (parking the chunk's 8 x 32 sums in LDS to leave with one 16-B store per lane instead of four 8-B stores
-        //  measured slower: 982 vs 962 us per 8192 tokens)
-        if (grp) STAB_PHASE()                                          // B starts one phase late
-        for (int c = 0; c < NCH; ++c) {
-            // ---------------- L(c): look-ups of chunk c; the partial sums of chunk c - 1 meet and leave
-            [[maybe_unused]] const long long tL = STAB_CLK();
-            __builtin_amdgcn_s_setprio(1);
-            {
-                const unsigned sb = lbase + (c & 1) * (TABF * 4);
+        for (int ks = 0; ks < 16; ++ks) STAB_W(ks, 0)
+        {
+            const unsigned sb_ = lbase;
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {                      // the look-ups ARE the B operands
-                    const unsigned cc = STAB_OFF(4) ? 0u : __builtin_amdgcn_ubfe(w[ks], shift, 8u);
-                    if (STAB_OFF(128)) b[ks] = f32x2{(float)cc, 1.f};
-                    else b[ks] = *(lds_cfloat2_t*)(uintptr_t)((cc << ROWSH) + sb);
-                }
-                if (c + 1 < NCH) {
-#pragma unroll
-                    for (int ks = 0; ks < 16; ++ks)
-                        w[ks] = reinterpret_cast<const uint32_t*>(cbase + 4 * ks * MS + MPC * (c + 1))[widx];
-                }
-                __builtin_amdgcn_s_setprio(0);
-                STAB_PHASE_T(tL, tl[6], tl[7], tl[8])
-            }
-            [[maybe_unused]] const long long tM = STAB_CLK();
-            // ---------------- M(c): four accumulator chains -- in its MFMA phase a wave has the matrix pipe to itself, and a
-            // dependent 16x16x4 MFMA can only issue 40 cycles after its predecessor (32 for an independent one): with two
-            // chains every MFMA waited 8 cycles (1.6k cycles per phase measured against 1.2k in pass 1)
-            z0 = f32x4{0.f, 0.f, 0.f, 0.f};
-            z1 = f32x4{0.f, 0.f, 0.f, 0.f};
-            {
-                f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 16; ks += 2) {
-                    if (!STAB_OFF(2)) {
-                        z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[ks].x, z0, 0, 0, 0);
-                        z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[ks].y, z1, 0, 0, 0);
-                        y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks + 1], b[ks + 1].x, y0, 0, 0, 0);
-                        y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks + 1], b[ks + 1].y, y1, 0, 0, 0);
-                    } else {
-                        asm volatile("" :: "v"(b[ks].x), "v"(b[ks].y), "v"(b[ks + 1].x), "v"(b[ks + 1].y));
-                    }
-                }
-                z0 += y0;
-                z1 += y1;
-            }
-            // C layout: z<ct>[rr] = Z[head 4 g + rr][dim 2 n16 + ct]; heads 8..15 (g >= 2) are padding.  The loader waves add
-            // the two neighbour halves and store them in the next phase (see STAB_ZOUT).
-            if (g < 2) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<f32x2*>(zb + CD * rr) = f32x2{z0[rr], z1[rr]};
-            }
-            STAB_PHASE_T(tM, tl[9], tl[10], tl[11])
+            for (int ks = 0; ks < 16; ++ks) { STAB_BLOOK(0, ks, sb_) STAB_W(ks, min(1, NCH - 1)) }
         }
-        if (!grp) STAB_PHASE()                                         // A finished one phase early
+        STAB_SYNC()                                                    // E(-1): everybody has its alphas, the score rows may go
+        for (int c = 0; c < NCH; c += 2) {
+            STAB_P2_ITER(c, 0, 1)
+            if (c + 1 < NCH) STAB_P2_ITER(c + 1, 1, 0)
+        }
+#undef STAB_P2_ITER
+#undef STAB_BLOOK
+#undef STAB_W
     }
 #if GNNLM_STAB_CLK
-    if (blockIdx.x < 256 && tid == 64 * GNNLM_STAB_CLKW && p.has_nb) {   // T >= 4096
+    if (blockIdx.x < 256 && (tid == 0 || tid == 256) && p.has_nb) {   // T >= 8192: waves 0 and 4
         const long long clk4 = STAB_CLK();
-        unsigned* o = reinterpret_cast<unsigned*>(p.has_nb) + blockIdx.x * 16;
-        o[0] = (unsigned)(clk1 - clk0); o[1] = (unsigned)(clk2 - clk1); o[2] = (unsigned)(clk3 - clk2); o[3] = (unsigned)(clk4 - clk3);
-        for (int e = 0; e < 10; ++e) o[4 + e] = (unsigned)tl[e];
-        o[14] = (unsigned)gap[0]; o[15] = (unsigned)gap[1];
+        unsigned* o = reinterpret_cast<unsigned*>(p.has_nb) + blockIdx.x * 32 + (tid ? 16 : 0);
+        o[0] = (unsigned)clk0; o[1] = (unsigned)clk1; o[2] = (unsigned)clk2; o[3] = (unsigned)clk3; o[4] = (unsigned)clk4;
     }
 #endif
-#undef STAB_DMA
-#undef STAB_LOADER_SWEEP
-#undef STAB_DMA_PIECES
-#undef STAB_PHASE
-#undef STAB_PHASE_T
-#undef STAB_LAND
+#undef STAB_DMA_ONE
+#undef STAB_SYNC
+#undef STAB_PIN
 #undef STAB_CLK
 }
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Cycle breakdown of star_attn_tab_kernel from a -DGNNLM_STAB_EXP=9 build (GNNLM_LIB=.../libstab9.so)."""
+"""Cycle stamps of star_attn_tab_kernel from a -DGNNLM_STAB_CLK=1 build (GNNLM_LIB=gnn-lm_amd/build/exp/lib<name>.so):
+section lengths per workgroup for waves 0 and 4."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,9 +15,12 @@ ids = torch.randint(0, N, (T, kg), generator=g, device=dev)
 for _ in range(3):
     Z, has = ops.star_attn(U, ids, codes=codes, centroids=cen)
 torch.cuda.synchronize()
-c = has.view(torch.int32)[: 256 * 16].view(256, 16).double().cpu()
-names = ["staging", "pass1", "softmax", "pass2"] + [f"p{p_}_{ph}_{w}" for p_ in (1, 2) for ph in ("L", "M") for w in ("body", "ldswait", "barrier")]
-names[14] = "p1_gap_M_to_L"; names[15] = "p1_gap_L_to_M"
-for i, n in enumerate(names):
-    print(f"{n:12s} mean {c[:, i].mean():10.0f}  min {c[:, i].min():10.0f}  max {c[:, i].max():10.0f}")
-print("total", c[:, :4].sum(1).mean())
+c = has.view(torch.int32)[: 256 * 32].view(256, 2, 16).to(torch.int64).cpu()
+base = c[:, 0:1, 0:1]
+d = ((c - base) & 0xFFFFFFFF).double()          # cycles since wave 0 entered the kernel
+for w, nm in ((0, "wave 0"), (1, "wave 4")):
+    x = d[:, w]
+    print(nm, "sections: staging %.0f  pass1 %.0f  softmax %.0f  pass2 %.0f  total %.0f" % tuple(
+        [(x[:, i + 1] - x[:, i]).mean().item() for i in range(4)] + [(x[:, 4] - x[:, 0]).mean().item()]))
+raw = has.view(torch.int32)[: 256 * 32].view(256, 32).double().cpu()
+print("loader wave 8, cycles per sweep: pass 1 issue %.0f land %.0f barrier %.0f | pass 2 issue %.0f land %.0f barrier %.0f" % tuple(raw[:, 8:14].mean(0).tolist()))
