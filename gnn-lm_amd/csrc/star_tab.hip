@@ -34,6 +34,7 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 typedef __attribute__((address_space(3))) const float lds_cfloat_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const f32x2 lds_cfloat2_t;
+typedef __attribute__((address_space(3))) const f32x4 lds_cfloat4_t;
 
 namespace {
 
@@ -42,6 +43,9 @@ namespace {
 #endif                       //   1 pass-1 MFMAs, 2 pass-2 MFMAs, 4 bank conflicts (every look-up reads row 0), 8 the table DMA,
                              //   16 code staging, 32 U loads in the sweep, 64 Z stores, 128 the table look-ups themselves
 #define STAB_OFF(bit_) ((GNNLM_STAB_OFF & (bit_)) != 0)
+#ifndef GNNLM_STAB_X
+#define GNNLM_STAB_X 0
+#endif
 #ifndef GNNLM_STAB_CLK
 #define GNNLM_STAB_CLK 0     // 1: cycle stamps of waves 0 and 4 of the first 256 workgroups written over has_nb (tools/star_clk.py)
 #endif
@@ -68,11 +72,12 @@ __host__ __device__ inline Carve carve(int M) {
     return c;
 }
 
-template <int DSUB>
+// MT: the number of sub-quantizers when known at compile time (the code-row stride then folds into the DS offsets), else 0
+template <int DSUB, int MT>
 __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams p, int h0) {
     constexpr int MPC = CD / DSUB;              // sub-quantizers per chunk: 4 (dsub 8) or 8 (dsub 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int M = p.M, D = p.D, H = p.H, kg = p.kg, NCH = D / CD;
+    const int M = MT ? MT : p.M, D = p.D, H = p.H, kg = p.kg, NCH = D / CD;
     const int MS = M + 4;                       // code row stride (bytes): rows of a tile sit on different banks
     const Carve cv = carve(M);
     float* tab = reinterpret_cast<float*>(smem + cv.tab);              // [2][TABF]
@@ -86,7 +91,6 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = wave >> 1, half = wave & 1;                          // token of this wave, neighbour half
-    const int n16 = lane & 15, g = lane >> 4;
     const int tok0 = blockIdx.x * TPW;
     const int i_tok = min(tok0 + t, p.T - 1);                          // tail workgroups recompute the last token
     const bool live = tok0 + t < p.T;
@@ -182,7 +186,16 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     if (!STAB_OFF(8)) {                                                                              \
         const float* s_ = tsrc + (int64_t)(c_) * TABF;                                               \
         const unsigned d_ = tab_lds + ((c_) & 1) * (TABF * 4);                                       \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) STAB_DMA_ONE(s_ + q * 256, d_ + q * 1024)     \
+        /* the instruction offset counts for the global AND the LDS address: two M0 values and two address registers */ \
+        unsigned keep_;                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                            \
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"              \
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"  \
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"                                                      \
+                     "global_load_lds_dwordx4 %2, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"              \
+                     "global_load_lds_dwordx4 %2, off offset:2048\n\tglobal_load_lds_dwordx4 %2, off offset:3072\n\t"  \
+                     "s_mov_b32 m0, %0"                                                              \
+                     : "=&s"(keep_) : "v"(s_), "v"(s_ + 1024), "s"(d_) : "memory", "scc");           \
     }
         // U: wave lw moves token lw's rows of the chunk; lane = slot (hh, ab, dq, li): 16 B of head 4 hh + li, sub-quantizer
         // dq, first (ab = 0) or second half in the order the lane group of dq reads its centroid rows (see pass 1)
@@ -273,14 +286,16 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     {
         const int li = lane & 3, dq = (lane >> 2) & 3, ng = lane >> 4;
         const float* ul = ubuf + t * 256 + (dq * 4 + li) * 4;
-        const int lo = DSUB == 8 ? 4 * (dq & 1) : 0, hi = 4 - lo;
+        const int lo = DSUB == 8 ? 4 * (dq & 1) : 0;
+        // LDS byte address of (row 0 of this lane's sub-quantizer, the half it reads first) in buffer 0; the other half is ^ 16
+        const unsigned lb1 = (unsigned)(uintptr_t)(lds_void_t*)tab + ((DSUB == 8 ? dq * 256 * 8 : 2 * dq * 256 * 4) + lo) * 4;
         f32x4 acc[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q][0] = acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         // code bytes of this lane: neighbour 64 half + 16 q + 4 ng + li, sub-quantizer(s) dq of the chunk (padding rows are zeros)
         const unsigned char* crow = lcodes + (t * KGM + 64 * half + 4 * ng + li) * MS + (DSUB == 8 ? dq : 2 * dq);
         unsigned code[4];
-        float4 xa[2][4], xb[2][4], ua[2][2], ub[2][2];
+        f32x4 xa[2][4], xb[2][4], ua[2][2], ub[2][2];
         __syncthreads();                                               // codes staged, chunks 0 and 1 landed
         clk1 = STAB_CLK();
 #define STAB_CODES(c_)                                                                               \
@@ -290,18 +305,18 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         // look-up of tile q_ of the chunk in table buffer tb_ into register set s_
 #define STAB_LOOK(s_, q_, tb_)                                                                       \
     if (STAB_OFF(128)) {                                                                             \
-        xa[s_][q_] = make_float4(1.f, 2.f, 3.f, (float)code[q_]); xb[s_][q_] = xa[s_][q_];           \
+        xa[s_][q_] = f32x4{1.f, 2.f, 3.f, (float)code[q_]}; xb[s_][q_] = xa[s_][q_];           \
     } else if constexpr (DSUB == 8) {                                                                \
-        const float* r_ = (tb_) + (dq * 256 + (STAB_OFF(4) ? 0u : code[q_])) * 8;                   \
-        xa[s_][q_] = *reinterpret_cast<const float4*>(r_ + lo);                                      \
-        xb[s_][q_] = *reinterpret_cast<const float4*>(r_ + hi);                                      \
+        const unsigned a_ = ((STAB_OFF(4) ? 0u : code[q_]) << 5) + (tb_);                            \
+        xa[s_][q_] = *(lds_cfloat4_t*)(uintptr_t)a_;                                                 \
+        xb[s_][q_] = *(lds_cfloat4_t*)(uintptr_t)(a_ ^ 16u);                                         \
     } else {                                                                                         \
-        xa[s_][q_] = *reinterpret_cast<const float4*>((tb_) + ((2 * dq) * 256 + (STAB_OFF(4) ? 0u : (code[q_] & 255u))) * 4);     \
-        xb[s_][q_] = *reinterpret_cast<const float4*>((tb_) + ((2 * dq + 1) * 256 + (STAB_OFF(4) ? 0u : (code[q_] >> 8))) * 4);   \
+        xa[s_][q_] = *(lds_cfloat4_t*)(uintptr_t)(((STAB_OFF(4) ? 0u : (code[q_] & 255u)) << 4) + (tb_));                \
+        xb[s_][q_] = *(lds_cfloat4_t*)(uintptr_t)(((STAB_OFF(4) ? 0u : (code[q_] >> 8)) << 4) + (tb_) + 256 * 4 * 4);    \
     }
 #define STAB_ULOOK(s_, u_)                                                                           \
-    ua[s_][0] = *reinterpret_cast<const float4*>(u_);       ub[s_][0] = *reinterpret_cast<const float4*>((u_) + 64);  \
-    ua[s_][1] = *reinterpret_cast<const float4*>((u_) + 128); ub[s_][1] = *reinterpret_cast<const float4*>((u_) + 192);
+    ua[s_][0] = *reinterpret_cast<const f32x4*>(u_);       ub[s_][0] = *reinterpret_cast<const f32x4*>((u_) + 64);  \
+    ua[s_][1] = *reinterpret_cast<const f32x4*>((u_) + 128); ub[s_][1] = *reinterpret_cast<const f32x4*>((u_) + 192);
         // 8 MFMAs: k step e_ of the halves xv_ / uv_ of register set s_, all four tiles, both head groups
 #define STAB_P1_STEP(s_, xv_, uv_, e_)                                                               \
     if (!STAB_OFF(1)) {                                                                              \
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         // buffer nobody refills: harmless), code bytes of chunk c_ + 2
 #define STAB_P1_ITER(c_, cur_, nxt_)                                                                 \
     {                                                                                                \
-        const float* tb_ = tab + (((c_) + 1) & 1) * TABF;                                            \
+        const unsigned tb_ = lb1 + (((c_) + 1) & 1) * (TABF * 4);                                    \
         const float* u_ = ul + (((c_) + 1) & 1) * 1024;                                              \
         const int c2_ = min((c_) + 2, NCH - 1);                                                      \
         STAB_P1_STEP(cur_, xa, ua, x) STAB_PIN(); STAB_LOOK(nxt_, 0, tb_) STAB_LOOK(nxt_, 1, tb_) STAB_PIN(); \
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     }
         STAB_CODES(0)
         {
-            const float* tb_ = tab;
+            const unsigned tb_ = lb1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { STAB_LOOK(0, q, tb_) }
             STAB_ULOOK(0, ul)
@@ -369,7 +384,6 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     }
     __syncthreads();
     // ---------------------------------------------------------------- softmax over the neighbours: wave (t, half) -> heads 4 half ..
-    float a_reg[16];
     {
         float al[4][2];
 #pragma unroll
@@ -394,67 +408,90 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     __syncthreads();                    // alphas written, chunks 0 and 1 landed
     clk3 = STAB_CLK();
 
-    // ================================================================ pass 2: Z[16 (8 real) heads x 32 dims] = alpha^T X per chunk
+    // ================================================================ pass 2: Z[8 heads x 32 dims] = alpha^T X per chunk, on v_mfma_f32_4x4x1 too
+    // Block (dg, ns) = lane / 4 is (sub-quantizer dg of the chunk, neighbour slot ns of a group of four); lane j of the block
+    // supplies A = alpha[head j (+ 4)][neighbour 4 grp + ns] and B = X[that neighbour][dim 8 dg + 2 j + e], e = 0, 1: ONE
+    // ds_read_b64 out of the centroid row feeds four MFMAs (two dims x two head groups), the B operands ARE the look-ups.
+    // A block accumulates Z[4 heads][4 dims] over ITS neighbour slot; the four slots of a (dg, j) meet once per chunk by
+    // two DPP row rotations per accumulator register.  All 16 operand columns are real work (on 16x16x4 the 8 heads
+    // filled half of the rows: twice the MFMA time, and on this part nothing issues in the shadow of an f32 MFMA --
+    // tools/probes/mfma_mix.hip -- so MFMA cycles and instruction count simply add).
     {
         const int kh = half;
-        // k step ks, lane group g  <->  neighbour j = 64 kh + 4 ks + g (alpha = 0 and code row = zeros for padding)
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) a_reg[ks] = n16 < HB ? sc[(t * HB + n16) * SCS + 64 * kh + 4 * ks + g] : 0.f;
-        // The two 16-column MFMA tiles of a chunk take the EVEN and the ODD dims: column n of tile ct is dim
-        // DSUB * mloc + 2 * dp + ct = 2 n + ct with mloc = n / (DSUB / 2), dp = n % (DSUB / 2).  A lane's two B operands are
-        // then neighbours in one centroid row: ONE ds_read_b64 and one code byte per k step feed both MFMAs.
+        const int j4 = lane & 3, ns = (lane >> 2) & 3, dg = lane >> 4;
+        // this lane's sub-quantizer slot in the chunk and byte offset in its centroid row
+        const int msub = DSUB == 8 ? dg : 2 * dg + (j4 >> 1);
+        const int boff = DSUB == 8 ? 8 * j4 : 8 * (j4 & 1);
         constexpr unsigned ROWSH = DSUB == 8 ? 5 : 4;      // log2 of a centroid row in bytes
-        const int mloc = n16 / (DSUB / 2), dp = n16 % (DSUB / 2);
-        const unsigned lbase = (unsigned)(uintptr_t)(lds_void_t*)tab + (mloc * 256 * DSUB + 2 * dp) * 4;   // (row 0, dim pair) in buffer 0
-        const unsigned shift = 8 * (mloc & 3);
-        const int widx = mloc >> 2;
-        const unsigned char* cbase = lcodes + (t * KGM + 64 * kh + g) * MS;
-        float* zb = zbuf + ((kh * TPW + t) * HB + 4 * g) * CD + 2 * n16;     // this lane's dim pair of heads 4 g .. 4 g + 3
+        const unsigned lbase = (unsigned)(uintptr_t)(lds_void_t*)tab + msub * 256 * DSUB * 4 + boff;   // row 0 in buffer 0
+        const unsigned shift = 8 * (msub & 3);
+        const int widx = msub >> 2;
+        // group grp, slot ns  <->  neighbour j = 64 kh + 4 grp + ns (alpha = 0 and code row = zeros for padding)
+        float a_reg[16][2];
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) {
+            a_reg[gq][0] = sc[(t * HB + j4) * SCS + 64 * kh + 4 * gq + ns];
+            a_reg[gq][1] = sc[(t * HB + 4 + j4) * SCS + 64 * kh + 4 * gq + ns];
+        }
+        const unsigned char* cbase = lcodes + (t * KGM + 64 * kh + ns) * MS;
+        float* zb = zbuf + ((kh * TPW + t) * HB + j4) * CD + 8 * dg;   // (head j4, this lane group's 8 dims): see the write below
         uint32_t w[16];                 // code words of this lane's 16 neighbours for the chunk whose look-ups come next
         f32x2 b[2][16];
-#define STAB_W(ks_, c_) w[ks_] = reinterpret_cast<const uint32_t*>(cbase + 4 * (ks_) * MS + MPC * (c_))[widx];
-#define STAB_BLOOK(s_, ks_, sb_)                                                                     \
+#define STAB_W(gq_, c_) w[gq_] = reinterpret_cast<const uint32_t*>(cbase + 4 * (gq_) * MS + MPC * (c_))[widx];
+#define STAB_BLOOK(s_, gq_, sb_)                                                                     \
     {                                                                                                \
-        const unsigned cc_ = STAB_OFF(4) ? 0u : __builtin_amdgcn_ubfe(w[ks_], shift, 8u);            \
-        if (STAB_OFF(128)) b[s_][ks_] = f32x2{(float)cc_, 1.f};                                      \
-        else b[s_][ks_] = *(lds_cfloat2_t*)(uintptr_t)((cc_ << ROWSH) + (sb_));                      \
+        const unsigned cc_ = STAB_OFF(4) ? 0u : __builtin_amdgcn_ubfe(w[gq_], shift, 8u);            \
+        if (STAB_OFF(128)) b[s_][gq_] = f32x2{(float)cc_, 1.f};                                      \
+        else b[s_][gq_] = *(lds_cfloat2_t*)(uintptr_t)((cc_ << ROWSH) + (sb_));                      \
     }
-        // iteration c_: per k step the look-up of chunk c_ + 1 (the B operands ARE the look-ups), the code word of chunk
-        // c_ + 2 into the register just consumed, two MFMAs of chunk c_; four accumulator chains
+        // x += x of the lane 4 / 8 further round the row of 16: the four neighbour slots of a (dg, j) meet
+#if GNNLM_STAB_X & 2
+#define STAB_ROR_ADD(x_, n_) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:" #n_ " row_mask:0xf bank_mask:0xf" : "+v"(x_));
+#else
+#define STAB_ROR_ADD(x_, n_) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:" #n_ " row_mask:0xf bank_mask:0xf" : "+v"(x_));
+#endif
+        // iteration c_: per group the look-up of chunk c_ + 1, the code word of chunk c_ + 2 into the register just consumed,
+        // four MFMAs of chunk c_
 #define STAB_P2_ITER(c_, cur_, nxt_)                                                                 \
     {                                                                                                \
         const unsigned sb_ = lbase + (((c_) + 1) & 1) * (TABF * 4);                                  \
         const int c2_ = min((c_) + 2, NCH - 1);                                                      \
-        f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0, y0 = z0, y1 = z0;                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 16; ks += 2) {                                      \
-            STAB_BLOOK(nxt_, ks, sb_) STAB_W(ks, c2_)                                                \
+        f32x4 z[2][2];                                                                               \
+        z[0][0] = z[0][1] = z[1][0] = z[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};                           \
+        _Pragma("unroll") for (int gq = 0; gq < 16; ++gq) {                                         \
+            STAB_BLOOK(nxt_, gq, sb_) STAB_W(gq, c2_)                                                \
             if (!STAB_OFF(2)) {                                                                      \
-                z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[cur_][ks].x, z0, 0, 0, 0);    \
-                z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks], b[cur_][ks].y, z1, 0, 0, 0);    \
-            } else asm volatile("" :: "v"(b[cur_][ks].x), "v"(b[cur_][ks].y));                        \
-            STAB_PIN();                                                                              \
-            STAB_BLOOK(nxt_, ks + 1, sb_) STAB_W(ks + 1, c2_)                                        \
-            if (!STAB_OFF(2)) {                                                                      \
-                y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks + 1], b[cur_][ks + 1].x, y0, 0, 0, 0); \
-                y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[ks + 1], b[cur_][ks + 1].y, y1, 0, 0, 0); \
-            } else asm volatile("" :: "v"(b[cur_][ks + 1].x), "v"(b[cur_][ks + 1].y));                \
+                z[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_reg[gq][0], b[cur_][gq].x, z[0][0], 0, 0, 0); \
+                z[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_reg[gq][1], b[cur_][gq].x, z[0][1], 0, 0, 0); \
+                z[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_reg[gq][0], b[cur_][gq].y, z[1][0], 0, 0, 0); \
+                z[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_reg[gq][1], b[cur_][gq].y, z[1][1], 0, 0, 0); \
+            } else asm volatile("" :: "v"(b[cur_][gq].x), "v"(b[cur_][gq].y));                        \
             STAB_PIN();                                                                              \
         }                                                                                            \
-        z0 += y0; z1 += y1;                                                                          \
-        /* C layout: z<ct>[rr] = Z[head 4 g + rr][dim 2 n16 + ct]; heads 8..15 (g >= 2) are padding.  The loader waves add */ \
-        /* the two neighbour halves and store them during the next iteration. */                   \
-        if (g < 2) {                                                                                 \
-            float* zo_ = zb + ((c_) & 1) * (2 * TPW * HB * CD);                                      \
-            _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<f32x2*>(zo_ + CD * rr) = f32x2{z0[rr], z1[rr]}; \
+        asm volatile("s_nop 7\n\ts_nop 7");     /* the last MFMAs have written their registers before the DPP adds read them */ \
+        /* C layout: z[e][hh][i] of lane (dg, ns, j) = the part of Z[head 4 hh + i][dim 8 dg + 2 j + e] of neighbour slot ns */ \
+        /* (a DPP operand must have been written at least two instructions earlier: 16 registers per round) */ \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                \
+            _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                         \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) STAB_ROR_ADD(z[e][hh][i], 4)           \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                \
+            _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                         \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) STAB_ROR_ADD(z[e][hh][i], 8)           \
+        /* The loader waves add the two neighbour halves and store them during the next iteration. */ \
+        if (ns == 0) {                                                                               \
+            float* zo_ = zb + ((c_) & 1) * (2 * TPW * HB * CD) + 2 * j4 - j4 * CD;                   \
+            _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                         \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                    *reinterpret_cast<f32x2*>(zo_ + (4 * hh + i) * CD) = f32x2{z[0][hh][i], z[1][hh][i]}; \
         }                                                                                            \
         STAB_SYNC()                                                                                  \
     }
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) STAB_W(ks, 0)
+        for (int gq = 0; gq < 16; ++gq) STAB_W(gq, 0)
         {
             const unsigned sb_ = lbase;
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) { STAB_BLOOK(0, ks, sb_) STAB_W(ks, min(1, NCH - 1)) }
+            for (int gq = 0; gq < 16; ++gq) { STAB_BLOOK(0, gq, sb_) STAB_W(gq, min(1, NCH - 1)) }
         }
         STAB_SYNC()                                                    // E(-1): everybody has its alphas, the score rows may go
         for (int c = 0; c < NCH; c += 2) {
@@ -462,6 +499,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
             if (c + 1 < NCH) STAB_P2_ITER(c + 1, 1, 0)
         }
 #undef STAB_P2_ITER
+#undef STAB_ROR_ADD
 #undef STAB_BLOOK
 #undef STAB_W
     }
@@ -490,17 +528,17 @@ int star_attn_tab(const StarAttnParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(star_attn_tab_eligible(p), "star_attn_tab: shape not supported by the table-resident kernel");
     const int lds_bytes = carve(p.M).total;
     static bool attr_set = false;
+    const auto k8m = &star_attn_tab_kernel<8, 128>, k8 = &star_attn_tab_kernel<8, 0>, k4 = &star_attn_tab_kernel<4, 0>;
     if (!attr_set) {
-        GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&star_attn_tab_kernel<8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&star_attn_tab_kernel<4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (const void* f : {reinterpret_cast<const void*>(k8m), reinterpret_cast<const void*>(k8), reinterpret_cast<const void*>(k4)})
+            GNNLM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const dim3 grid((unsigned)cdiv(p.T, TPW)), block(NTHREADS);
     for (int h0 = 0; h0 < p.H; h0 += HB) {
-        if (p.dsub == 8) hipLaunchKernelGGL((star_attn_tab_kernel<8>), grid, block, lds_bytes, stream, p, h0);
-        else hipLaunchKernelGGL((star_attn_tab_kernel<4>), grid, block, lds_bytes, stream, p, h0);
+        if (p.dsub == 8 && p.M == 128) hipLaunchKernelGGL(k8m, grid, block, lds_bytes, stream, p, h0);
+        else if (p.dsub == 8) hipLaunchKernelGGL(k8, grid, block, lds_bytes, stream, p, h0);
+        else hipLaunchKernelGGL(k4, grid, block, lds_bytes, stream, p, h0);
     }
     GNNLM_LAUNCH_CHECK();
     return OK;
