@@ -121,6 +121,13 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         __builtin_amdgcn_sched_barrier(0);                            \
     }
 #define STAB_PIN() __builtin_amdgcn_sched_barrier(0)
+    // x += x of the lane 4 / 8 further round its row of 16 lanes (DPP); the operand must not have been written by one of the
+    // two preceding instructions
+#if GNNLM_STAB_X & 2
+#define STAB_ROR_ADD(x_, n_) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:" #n_ " row_mask:0xf bank_mask:0xf" : "+v"(x_));
+#else
+#define STAB_ROR_ADD(x_, n_) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:" #n_ " row_mask:0xf bank_mask:0xf" : "+v"(x_));
+#endif
     [[maybe_unused]] const long long clk0 = STAB_CLK();
 
     // ---------------------------------------------------------------- staging: validity, code rows (zeros when invalid)
@@ -293,26 +300,26 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q][0] = acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         // code bytes of this lane: neighbour 64 half + 16 q + 4 ng + li, sub-quantizer(s) dq of the chunk (padding rows are zeros)
-        const unsigned char* crow = lcodes + (t * KGM + 64 * half + 4 * ng + li) * MS + (DSUB == 8 ? dq : 2 * dq);
+        const unsigned char* crow = lcodes + (t * KGM + 64 * half + 4 * ng + li) * MS + (DSUB == 8 ? 0 : 4 * (dq >> 1));
+        const unsigned cshift = DSUB == 8 ? 8 * dq : 16 * (dq & 1);     // this lane's byte (dsub 8) or byte pair (dsub 4) of the code word
         unsigned code[4];
         f32x4 xa[2][4], xb[2][4], ua[2][2], ub[2][2];
         __syncthreads();                                               // codes staged, chunks 0 and 1 landed
         clk1 = STAB_CLK();
 #define STAB_CODES(c_)                                                                               \
     _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                    \
-        code[q] = DSUB == 8 ? (unsigned)crow[q * 16 * MS + MPC * (c_)]                               \
-                            : (unsigned)*reinterpret_cast<const unsigned short*>(crow + q * 16 * MS + MPC * (c_));
+        code[q] = *reinterpret_cast<const uint32_t*>(crow + q * 16 * MS + MPC * (c_));
         // look-up of tile q_ of the chunk in table buffer tb_ into register set s_
 #define STAB_LOOK(s_, q_, tb_)                                                                       \
     if (STAB_OFF(128)) {                                                                             \
         xa[s_][q_] = f32x4{1.f, 2.f, 3.f, (float)code[q_]}; xb[s_][q_] = xa[s_][q_];           \
     } else if constexpr (DSUB == 8) {                                                                \
-        const unsigned a_ = ((STAB_OFF(4) ? 0u : code[q_]) << 5) + (tb_);                            \
+        const unsigned a_ = ((STAB_OFF(4) ? 0u : __builtin_amdgcn_ubfe(code[q_], cshift, 8u)) << 5) + (tb_); \
         xa[s_][q_] = *(lds_cfloat4_t*)(uintptr_t)a_;                                                 \
         xb[s_][q_] = *(lds_cfloat4_t*)(uintptr_t)(a_ ^ 16u);                                         \
     } else {                                                                                         \
-        xa[s_][q_] = *(lds_cfloat4_t*)(uintptr_t)(((STAB_OFF(4) ? 0u : (code[q_] & 255u)) << 4) + (tb_));                \
-        xb[s_][q_] = *(lds_cfloat4_t*)(uintptr_t)(((STAB_OFF(4) ? 0u : (code[q_] >> 8)) << 4) + (tb_) + 256 * 4 * 4);    \
+        xa[s_][q_] = *(lds_cfloat4_t*)(uintptr_t)(((STAB_OFF(4) ? 0u : __builtin_amdgcn_ubfe(code[q_], cshift, 8u)) << 4) + (tb_));                    \
+        xb[s_][q_] = *(lds_cfloat4_t*)(uintptr_t)(((STAB_OFF(4) ? 0u : __builtin_amdgcn_ubfe(code[q_], cshift + 8u, 8u)) << 4) + (tb_) + 256 * 4 * 4);  \
     }
 #define STAB_ULOOK(s_, u_)                                                                           \
     ua[s_][0] = *reinterpret_cast<const f32x4*>(u_);       ub[s_][0] = *reinterpret_cast<const f32x4*>((u_) + 64);  \
@@ -366,6 +373,19 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         clk2 = STAB_CLK();
         // C layout of the 16 blocks: acc[q][hh][rr] of lane (ng, dq, li) = the part of S[neighbour 64 half + 16 q + 4 ng + rr]
         // [head 4 hh + li] that comes from the dims of sub-quantizer dq: the four dq lanes meet, dq = 0 writes
+        asm volatile("s_nop 7\n\ts_nop 7");
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) STAB_ROR_ADD(acc[q][hh][rr], 4)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) STAB_ROR_ADD(acc[q][hh][rr], 8)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t okw = *reinterpret_cast<const uint32_t*>(okf + t * KGM + 64 * half + 16 * q + 4 * ng);
@@ -373,9 +393,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
             for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    float v = acc[q][hh][rr];
-                    v += __shfl_xor(v, 4);
-                    v += __shfl_xor(v, 8);
+                    const float v = acc[q][hh][rr];
                     const int j = 64 * half + 16 * q + 4 * ng + rr;
                     if (dq == 0) sc[(t * HB + 4 * hh + li) * SCS + j] = ((okw >> (8 * rr)) & 1u) ? v : -INFINITY;
                 }
@@ -424,8 +442,6 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         const int boff = DSUB == 8 ? 8 * j4 : 8 * (j4 & 1);
         constexpr unsigned ROWSH = DSUB == 8 ? 5 : 4;      // log2 of a centroid row in bytes
         const unsigned lbase = (unsigned)(uintptr_t)(lds_void_t*)tab + msub * 256 * DSUB * 4 + boff;   // row 0 in buffer 0
-        const unsigned shift = 8 * (msub & 3);
-        const int widx = msub >> 2;
         // group grp, slot ns  <->  neighbour j = 64 kh + 4 grp + ns (alpha = 0 and code row = zeros for padding)
         float a_reg[16][2];
 #pragma unroll
@@ -433,23 +449,20 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
             a_reg[gq][0] = sc[(t * HB + j4) * SCS + 64 * kh + 4 * gq + ns];
             a_reg[gq][1] = sc[(t * HB + 4 + j4) * SCS + 64 * kh + 4 * gq + ns];
         }
-        const unsigned char* cbase = lcodes + (t * KGM + 64 * kh + ns) * MS;
+        const unsigned char* cbase = lcodes + (t * KGM + 64 * kh + ns) * MS + (msub & ~3);
+        const unsigned shift = 8 * (msub & 3);
         float* zb = zbuf + ((kh * TPW + t) * HB + j4) * CD + 8 * dg;   // (head j4, this lane group's 8 dims): see the write below
         uint32_t w[16];                 // code words of this lane's 16 neighbours for the chunk whose look-ups come next
         f32x2 b[2][16];
-#define STAB_W(gq_, c_) w[gq_] = reinterpret_cast<const uint32_t*>(cbase + 4 * (gq_) * MS + MPC * (c_))[widx];
+// (a ds_read_u8 of the lane's own byte would save the v_bfe, but measured 11 % slower on the whole sweep: four lanes reading
+// different bytes of one dword do not broadcast)
+#define STAB_W(gq_, c_) w[gq_] = *reinterpret_cast<const uint32_t*>(cbase + 4 * (gq_) * MS + MPC * (c_));
 #define STAB_BLOOK(s_, gq_, sb_)                                                                     \
     {                                                                                                \
         const unsigned cc_ = STAB_OFF(4) ? 0u : __builtin_amdgcn_ubfe(w[gq_], shift, 8u);            \
         if (STAB_OFF(128)) b[s_][gq_] = f32x2{(float)cc_, 1.f};                                      \
         else b[s_][gq_] = *(lds_cfloat2_t*)(uintptr_t)((cc_ << ROWSH) + (sb_));                      \
     }
-        // x += x of the lane 4 / 8 further round the row of 16: the four neighbour slots of a (dg, j) meet
-#if GNNLM_STAB_X & 2
-#define STAB_ROR_ADD(x_, n_) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:" #n_ " row_mask:0xf bank_mask:0xf" : "+v"(x_));
-#else
-#define STAB_ROR_ADD(x_, n_) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:" #n_ " row_mask:0xf bank_mask:0xf" : "+v"(x_));
-#endif
         // iteration c_: per group the look-up of chunk c_ + 1, the code word of chunk c_ + 2 into the register just consumed,
         // four MFMAs of chunk c_
 #define STAB_P2_ITER(c_, cur_, nxt_)                                                                 \
