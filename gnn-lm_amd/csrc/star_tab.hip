@@ -9,21 +9,24 @@
 // the decoded features:
 //   * the 1024 feature dims are swept in 32-dim chunks; a chunk's sub-tables ((32 / dsub) x 256 rows = 32 KiB,
 //     contiguous in the [M][256][dsub] table) arrive by LDS-DMA (global_load_lds_dwordx4, coalesced, L2-resident
-//     source, no VGPRs), double-buffered, one barrier per chunk;
-//   * FOUR tokens share a workgroup (8 waves: two per token), i.e. one table sweep per pass serves 4 x 128
-//     neighbours -- 2 x 1 MiB of L2 -> LDS traffic per 4 tokens instead of the 2 x 16,384 L1 gathers per token;
-//   * pass 1, S = X U^T on v_mfma_f32_16x16x4_f32: a lane's A operand IS its look-up.  Lane (r, g) of a 16-neighbour
-//     tile reads the 32-B centroid row of (neighbour r, sub-quantizer 4c + g) with two ds_read_b128 and feeds the 8
-//     floats to 8 MFMAs (k index g <-> that sub-quantizer's dims).  No decoded slab is ever written or re-read.
-//     Odd lane groups read the two halves of the row in the other order so that a ds_read_b128 group spreads over
-//     all 16 slots of the bank window; the k <-> dim map is permuted accordingly on the U side (free);
-//   * softmax over the neighbours per (token, head);
-//   * pass 2, Z = alpha^T X: the B operand of each MFMA is ONE ds_read_b32 straight out of the table,
-//     X[j][d] = tab[(m(d), code[j][m(d)], d % dsub)]; the code bytes of a k-step's 4 neighbours come with one
-//     ds_read_b32 per (k-step, chunk).  The two waves of a token split the neighbours and meet through 1 KiB of LDS.
-// Per token and pass: 2048 MFMAs (the heads fill 8 of the 16 MFMA columns -- 4.2 MFLOP issued for 2.1 useful, the
-// floor of this shape on the f32 matrix cores: ~0.44 ms per 8192 tokens for both passes), 16 KiB of random LDS
-// reads, 0 L1 gathers.  HBM traffic is unchanged: the code rows (read once per token, staged in LDS), U and Z.
+//     source, no VGPRs), double-buffered;
+//   * FOUR tokens share a workgroup (8 compute waves: two per token, 64 neighbours each), i.e. one table sweep per
+//     pass serves 4 x 128 neighbours -- 2 x 1 MiB of L2 -> LDS traffic per 4 tokens instead of 2 x 16,384 L1 gathers
+//     per token; four more waves only move data (table and U in, Z out);
+//   * both contractions run on v_mfma_f32_4x4x1_16B_f32, whose 16 independent 4 x 4 blocks take the 8 heads without
+//     padding (on the 16x16x4 shape the heads fill half of a 16-wide operand: twice the matrix time).  A lane's MFMA
+//     operands ARE its look-ups -- pass 1 (S = X U^T): the 32-B centroid row of (neighbour, sub-quantizer), two
+//     ds_read_b128, eight k steps; pass 2 (Z = alpha^T X): 8 B of the row, one ds_read_b64, two dims x two head
+//     groups.  No decoded slab is ever written or re-read.  Blocks that split a sum (sub-quantizers in pass 1,
+//     neighbour slots in pass 2) meet by two DPP row rotations per accumulator register;
+//   * softmax over the neighbours per (token, head) between the sweeps.
+// What sets the time (tools/probes/mfma_mix.hip, tools/star_clk.py): on this part nothing issues in the shadow of an
+// f32 MFMA -- a VALU or DS instruction next to a 4x4x1 / 16x16x4 stream costs its own 4-6 cycles of the SIMD, from
+// the same wave or from the other one -- so a sweep costs (MFMA cycles) + ~4.4 x (every other instruction of the
+// three waves of the SIMD), and the work went into both terms: 128 MFMAs of ~9 cycles per SIMD and chunk, 3 (pass 2)
+// or 5 (pass 1) instructions per look-up, no vector-memory instruction in the compute waves.  Per 8192 tokens:
+// 962 us (round 2 start, 16x16x4 ping-pong) -> 685 us; MFMA time alone is ~300 us at the ~1.9 GHz the part holds here.
+// HBM traffic is unchanged: the code rows (read once per token, staged in LDS), U and Z.
 #include "kernels.h"
 
 namespace gnnlm {
@@ -43,9 +46,6 @@ namespace {
 #endif                       //   1 pass-1 MFMAs, 2 pass-2 MFMAs, 4 bank conflicts (every look-up reads row 0), 8 the table DMA,
                              //   16 code staging, 32 U loads in the sweep, 64 Z stores, 128 the table look-ups themselves
 #define STAB_OFF(bit_) ((GNNLM_STAB_OFF & (bit_)) != 0)
-#ifndef GNNLM_STAB_X
-#define GNNLM_STAB_X 0
-#endif
 #ifndef GNNLM_STAB_CLK
 #define GNNLM_STAB_CLK 0     // 1: cycle stamps of waves 0 and 4 of the first 256 workgroups written over has_nb (tools/star_clk.py)
 #endif
@@ -56,7 +56,7 @@ constexpr int HB = 8;                   // heads per launch
 constexpr int CD = 32;                  // feature dims per chunk
 constexpr int TABF = CD * 256;          // floats per table chunk (32 KiB)
 constexpr int SCS = KGM + 4;            // score row stride: the heads of a token land on different banks
-constexpr int NTHREADS = 768;           // 8 compute waves (two per token) + 4 loader waves (table DMA only)
+constexpr int NTHREADS = 768;           // 8 compute waves (two per token) + 4 loader waves (table and U in, Z out)
 
 struct Carve {
     int tab, sc, ubuf, okf, lcodes, total;      // byte offsets
@@ -123,41 +123,41 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
 #define STAB_PIN() __builtin_amdgcn_sched_barrier(0)
     // x += x of the lane 4 / 8 further round its row of 16 lanes (DPP); the operand must not have been written by one of the
     // two preceding instructions
-#if GNNLM_STAB_X & 2
-#define STAB_ROR_ADD(x_, n_) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:" #n_ " row_mask:0xf bank_mask:0xf" : "+v"(x_));
-#else
 #define STAB_ROR_ADD(x_, n_) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:" #n_ " row_mask:0xf bank_mask:0xf" : "+v"(x_));
-#endif
     [[maybe_unused]] const long long clk0 = STAB_CLK();
 
     // ---------------------------------------------------------------- staging: validity, code rows (zeros when invalid)
-    for (int e = tid; e < TPW * KGM; e += NTHREADS) {
-        const int tt = e >> 7, j = e & (KGM - 1);
-        const int i = min(tok0 + tt, p.T - 1);
-        okf[e] = (j < kg && star_nb_ok(p, i, j, p.ids[(int64_t)i * kg + j])) ? 1 : 0;
-    }
-    __syncthreads();
-    {
-        // six 16-B pieces per thread and round, the loads of a round in flight together (one piece after the other paid two
-        // memory round trips per piece: 20k cycles of staging per workgroup)
+    // (all twelve waves; the loader waves put the first two table chunks on their way before they join)
+    [[maybe_unused]] long long st[4] = {0, 0, 0, 0};
+    auto stage_codes = [&]() {
+        // One pass: every 16-B piece of a code row re-derives the neighbour's validity from its id (the eight pieces of a row sit
+        // in neighbouring lanes: one request), piece 0 records it.  Six pieces per thread and round, the loads of a round in
+        // flight together.  (Validity first, a barrier, then the rows one piece after the other: 20k cycles per workgroup.)
         constexpr int RB = 6;
         const int per_row = M >> 4, n_items = TPW * KGM * per_row;
         for (int e0 = 0; e0 < n_items; e0 += RB * NTHREADS) {
+            int64_t id[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int e = e0 + r * NTHREADS + tid;
+                const int row = e / per_row, tt = row >> 7, j = row & (KGM - 1);
+                id[r] = (e < n_items && j < kg) ? p.ids[(int64_t)min(tok0 + tt, p.T - 1) * kg + j] : -1;
+            }
+            if (GNNLM_STAB_CLK) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[0] = STAB_CLK(); }
             int64_t src[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const int e = e0 + r * NTHREADS + tid;
-                src[r] = -1;
-                if (e < n_items) {
-                    const int row = e / per_row, part = e - row * per_row;
-                    const int tt = row >> 7, j = row & (KGM - 1);
-                    const int i = min(tok0 + tt, p.T - 1);
-                    if (okf[row] && !STAB_OFF(16)) src[r] = star_code_row(p, i, j, p.ids[(int64_t)i * kg + j]) * M + 16 * part;
-                }
+                const int row = e / per_row, part = e - row * per_row, tt = row >> 7, j = row & (KGM - 1);
+                const int i = min(tok0 + tt, p.T - 1);
+                const bool ok = e < n_items && j < kg && star_nb_ok(p, i, j, id[r]);
+                if (e < n_items && part == 0) okf[row] = ok ? 1 : 0;
+                src[r] = ok && !STAB_OFF(16) ? star_code_row(p, i, j, id[r]) * M + 16 * part : -1;
             }
             uint4 v[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) v[r] = src[r] >= 0 ? *reinterpret_cast<const uint4*>(p.codes + src[r]) : make_uint4(0, 0, 0, 0);
+            if (GNNLM_STAB_CLK) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[1] = STAB_CLK(); }
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const int e = e0 + r * NTHREADS + tid;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
                 }
             }
         }
-    }
+    };
 
     // Both sweeps have the same skeleton.  Chunk k of the table lives in buffer k & 1.  Iteration c of a compute wave issues
     // the MFMAs of chunk c from registers, INTERLEAVED with the look-ups of chunk c + 1 into a second register set, then the
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
 #define STAB_LAND() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
         STAB_DMA_TAB(0) STAB_DMA_U(0)
         if (NCH > 1) { STAB_DMA_TAB(1) STAB_DMA_U(1) }
+        stage_codes();
         STAB_LAND();
         __syncthreads();                // codes staged, chunks 0 and 1 landed
         STAB_SYNC()                     // E(-1)
@@ -281,6 +282,8 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         return;
     }
 
+    stage_codes();
+    if (GNNLM_STAB_CLK) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st[2] = STAB_CLK(); }
     [[maybe_unused]] long long clk1 = 0, clk2 = 0, clk3 = 0;
     // ================================================================ pass 1: S[128 nb x 8 heads] = X U^T on v_mfma_f32_4x4x1 (16 blocks)
     // Block b = lane / 4 of an MFMA is (neighbour group ng = b / 4, sub-quantizer dq = b % 4 of the chunk); lane li = lane % 4
@@ -521,6 +524,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         const long long clk4 = STAB_CLK();
         unsigned* o = reinterpret_cast<unsigned*>(p.has_nb) + blockIdx.x * 32 + (tid ? 16 : 0);
         o[0] = (unsigned)clk0; o[1] = (unsigned)clk1; o[2] = (unsigned)clk2; o[3] = (unsigned)clk3; o[4] = (unsigned)clk4;
+        o[5] = (unsigned)(st[0] - clk0); o[6] = (unsigned)(st[1] - clk0); o[7] = (unsigned)(st[2] - clk0);
     }
 #endif
 #undef STAB_DMA_ONE

@@ -24,3 +24,4 @@ for w, nm in ((0, "wave 0"), (1, "wave 4")):
         [(x[:, i + 1] - x[:, i]).mean().item() for i in range(4)] + [(x[:, 4] - x[:, 0]).mean().item()]))
 raw = has.view(torch.int32)[: 256 * 32].view(256, 32).double().cpu()
 print("loader wave 8, cycles per sweep: pass 1 issue %.0f land %.0f barrier %.0f | pass 2 issue %.0f land %.0f barrier %.0f" % tuple(raw[:, 8:14].mean(0).tolist()))
+print("staging of wave 0 (one round): ids back %.0f, code pieces back %.0f, LDS written %.0f" % tuple(raw[:, 5:8].mean(0).tolist()))
