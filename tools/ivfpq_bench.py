@@ -13,7 +13,7 @@ if __name__ == "__main__":
     idx = synthetic_ivfpq_index(N, 1024, 4096, 64, dev, dense_probes=int(os.environ.get("DENSE", 4)))
     q = torch.randn(n, 1024, device=dev); q = q / q.norm(dim=1, keepdim=True)
     from gnnlm_amd import _lib
-    idx.search_device(q[:1024], k); torch.cuda.synchronize()
+    idx.search_device(q, k); torch.cuda.synchronize()      # same shapes as the timed call
     _lib.profile_begin()
     t0 = time.perf_counter(); v, i = idx.search_device(q, k); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     prof = _lib.profile_end()
