@@ -87,18 +87,26 @@ def build(args, dev, rank, world):
     rs = np.random.RandomState(1234)
     cen, A, b = make_codec(rs, M, dsub, d, opq=True)
     sharded = (world > 1 or args.force_exchange) and args.store == "sharded"
-    shard = Shard(args.n_store, world if sharded else 1, rank if sharded else 0)
+    # halo layout: every shard also holds the 2 rows before / after its range, so that a context group (l = r = 2) is ONE
+    # request answered by its centre's owner (dist.exchange_fetch_groups; used when the HGT needs every slot, L > 1)
+    shard = Shard(args.n_store, world if sharded else 1, rank if sharded else 0, halo_left=2, halo_right=2)
     n_local = shard.n_local
-    codes = device_codes(n_local, M, dev, 1234 + shard.row0)              # uint8 i.i.d. uniform
+    codes = device_codes(shard.store_rows, M, dev, 1234 + shard.row0)     # uint8 i.i.d. uniform
+    if sharded and world > 1:
+        # the rows near a shard boundary exist on two ranks: give them content that depends on the global row only
+        near = torch.cat([torch.arange(max(0, b_ - 4), min(args.n_store, b_ + 4)) for b_ in range(shard.per, args.n_store, shard.per)])
+        near = near[(near >= shard.store_row0) & (near < shard.store_row0 + shard.store_rows)].to(dev)
+        if near.numel():
+            codes[near - shard.store_row0] = (((near.reshape(-1, 1) * 2654435761 + torch.arange(M, device=dev) * 40503) >> 7) & 255).to(torch.uint8)
     # the label table (413 MB for WikiText-103) is replicated on every rank unless --shard-vals: only the
     # 13.2-GB code table needs the range sharding, and replicated labels save the k=1024-per-token exchange
     shard_vals = sharded and args.shard_vals
     vgen = torch.Generator(device=dev)
     vgen.manual_seed(4321 + (shard.row0 if shard_vals else 0))
-    vals = zipf_dev(n_local if shard_vals else args.n_store, vocab, vgen, dev).to(torch.int32)
+    vals = zipf_dev(shard.store_rows if shard_vals else args.n_store, vocab, vgen, dev).to(torch.int32)
     t = lambda a: torch.from_numpy(a).to(dev)
-    store = CodeStore(codes=codes, centroids=t(cen), n_store=args.n_store, row0=shard.row0, vals=vals, A=t(A), b=t(b))
-    store.vals_row0 = shard.row0 if shard_vals else 0
+    store = CodeStore(codes=codes, centroids=t(cen), n_store=args.n_store, row0=shard.store_row0, vals=vals, A=t(A), b=t(b))
+    store.vals_row0 = shard.store_row0 if shard_vals else 0
     torch.manual_seed(1234)
     hgt = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=args.layers, n_heads=H)
     w = make_asm_weights(rs, vocab, d, cutoff)
@@ -644,6 +652,7 @@ def main():
                        "store": ("range-sharded + RCCL all-to-all" if sharded else "replicated" if world > 1 else "single GPU"),
                        "rccl_ranks": world if dist.is_initialized() else 0,
                        "exchange": (args.exchange if sharded else None),
+                       "exchange_requests": ((("one per context group (halo layout)" if args.layers > 1 else "centre rows only")) if sharded else None),
                        "xgmi_bytes_per_step_per_rank": (round(link_bytes_per_step) if link_bytes_per_step is not None else None),
                        "replicated_store": replicated,
                        "gemm_precision": args.precision, "max_abs_dlogp_vs_f32": dlogp,

@@ -17,6 +17,12 @@ k = 1024-per-token exchange for 3 % of the store's bytes (``bench.py --shard-val
 exchange per table per step is the right shape.  Row validity needs no communication: a row is valid
 iff 0 <= row < n_store, which the requester knows.
 
+Halo layout: with L > 1 the consumers need every slot of a context group (centre, l rows
+before, r rows after; token_block_dataset.py:358,380-385).  A shard built with ``Shard(..., halo_left=l,
+halo_right=r)`` also keeps the l rows before and the r rows after its range, so the OWNER OF THE CENTRE can answer
+the whole group: one 8-B request per group instead of 1 + l + r, answered with (1 + l + r) * M bytes
+(`exchange_fetch_groups`; ids on the links / (1 + l + r), bucketing work too, payload unchanged).
+
 The function is backend-agnostic (RCCL on the GPUs; the CPU tests run it over gloo with a numpy
 gather injected for the owner-side lookup).
 """
@@ -32,6 +38,8 @@ class Shard:
     n_store: int
     world: int
     rank: int
+    halo_left: int = 0          # rows kept in front of / behind the owned range (copies of the neighbours' edge rows)
+    halo_right: int = 0
 
     @property
     def per(self):
@@ -44,6 +52,17 @@ class Shard:
     @property
     def n_local(self):
         return max(0, min((self.rank + 1) * self.per, self.n_store) - self.row0)
+
+    @property
+    def store_row0(self):
+        """First row this rank HOLDS (owned range plus halo)."""
+        return max(0, self.row0 - self.halo_left) if self.n_local else self.row0
+
+    @property
+    def store_rows(self):
+        if not self.n_local:
+            return 0
+        return min(self.n_store, self.row0 + self.n_local + self.halo_right) - self.store_row0
 
     def owner(self, rows: torch.Tensor) -> torch.Tensor:
         """Owning rank of each global row; out-of-range rows (incl. -1) are kept local."""
@@ -160,6 +179,31 @@ def exchange_fetch_padded(rows: torch.Tensor, shard: Shard, local_gather: Callab
     return back, index, overflow
 
 
+def exchange_fetch_groups(ids: torch.Tensor, left: int, right: int, shard: Shard,
+                          group_gather: Callable[[torch.Tensor], torch.Tensor], group=None, cap: int = 0,
+                          bucket=None):
+    """Halo-layout fetch of whole context groups: ONE request (the centre id, 8 B) per group, answered by the centre's
+    owner with the group's 1 + left + right rows.  ``group_gather(centres [n]) -> [n, 1 + left + right, C]`` runs on the
+    owner (slot order: centre, o - left .. o - 1, o + 1 .. o + right; zero rows for slots outside the store and for
+    centres < 0); the owner's shard must hold `left` / `right` halo rows.
+    cap = 0: exact variable-split exchange; cap > 0: fixed-capacity sync-free exchange.
+    -> (payload [P * n_g, C], index int32 [G * n_g], overflow [1] or None): slot s lives in payload row index[s]."""
+    assert shard.halo_left >= left and shard.halo_right >= right, "the shard was built without the halo rows this needs"
+    n_g = 1 + left + right
+    centres = ids.reshape(-1)
+    centres = torch.where((centres >= 0) & (centres < shard.n_store), centres, torch.full_like(centres, -1)).contiguous()
+    k = torch.arange(n_g, device=centres.device, dtype=torch.int64)
+    if cap:
+        back, index, ovf = exchange_fetch_padded(centres, shard, group_gather, cap, group,
+                                                 bucket=bucket or bucket_padded_torch)
+    else:
+        back, index = exchange_fetch(centres, shard, group_gather, group, bucket=bucket or bucket_torch, unpermute=False)
+        ovf = None
+    assert back.shape[1] == n_g
+    slot_index = (index.long().reshape(-1, 1) * n_g + k).reshape(-1).to(torch.int32)
+    return back.reshape((back.shape[0] * n_g,) + tuple(back.shape[2:])), slot_index, ovf
+
+
 def slot_rows(ids: torch.Tensor, left: int, right: int, n_store: int) -> torch.Tensor:
     """Global row of every slot of every group (centre, o-left..o-1, o+1..o+right); -1 if invalid
     (token_block_dataset.py:358,380-385)."""
@@ -181,7 +225,7 @@ class ShardedFetcher:
         self.mode, self.slack = mode, slack
         self.overflow = None                                # device counter of rows that did not fit (padded mode)
         self.link_bytes = 0                                 # bytes this rank put on / took off its xGMI links so far
-        assert store.row0 == shard.row0 and store.codes.shape[0] == shard.n_local
+        assert store.row0 == shard.store_row0 and store.codes.shape[0] == shard.store_rows
 
     def check(self):
         """Raise if the fixed-capacity exchange dropped requests (skewed ids): rerun with mode='exact' or more slack."""
@@ -201,6 +245,27 @@ class ShardedFetcher:
         W = self.shard.world
         self.link_bytes += int(n_rows * (W - 1) / W) * 2 * (8 + row_bytes)     # uniform-id expectation
 
+    def _fetch_groups(self, ids, left, right):
+        """Halo layout: one request per context group (see exchange_fetch_groups)."""
+        st, W, n_g = self.store, self.shard.world, 1 + left + right
+        M = st.codes.shape[1]
+
+        def gather(centres):
+            return self.ops.pq_gather_decode(st.codes, st.centroids, centres, left, right, n_store=st.n_store, row0=st.row0,
+                                             want_x=False, want_codes=True, want_valid=False)["codes"].view(-1, n_g, M)
+        G = ids.numel()
+        valid = slot_rows(ids, left, right, st.n_store) >= 0
+        if self.mode == "padded":
+            cap = bucket_capacity(G, W, self.slack)
+            codes, index, ovf = exchange_fetch_groups(ids, left, right, self.shard, gather, self.group, cap, bucket_padded_hip)
+            self.overflow = ovf if self.overflow is None else self.overflow + ovf
+            self.link_bytes += cap * (W - 1) * 2 * (8 + n_g * M)
+            valid = valid & (index.long() < W * cap * n_g)
+        else:
+            codes, index, _ = exchange_fetch_groups(ids, left, right, self.shard, gather, self.group, 0, bucket_hip)
+            self._account_exact(G, n_g * M)
+        return codes, valid.to(torch.uint8), index
+
     def _gather_codes(self, rows):
         st = self.store
         return self.ops.pq_gather_decode(st.codes, st.centroids, rows, 0, 0, n_store=st.n_store, row0=st.row0,
@@ -214,6 +279,8 @@ class ShardedFetcher:
     def fetch_codes(self, ids, left, right, centres_only):
         """-> (fetched_codes uint8 [S, M] in bucketed order, fetched_valid uint8 [S], fetched_index int32 [S])
         for the slots of ``ids`` [n, kg]: slot s lives in row ``fetched_index[s]``."""
+        if not centres_only and (left or right) and self.shard.halo_left >= left and self.shard.halo_right >= right:
+            return self._fetch_groups(ids, left, right)
         rows = ids.reshape(-1) if centres_only else slot_rows(ids, left, right, self.store.n_store)
         rows = torch.where((rows >= 0) & (rows < self.store.n_store), rows, torch.full_like(rows, -1))
         if self.mode == "padded":

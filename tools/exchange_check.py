@@ -21,24 +21,28 @@ for L in (1, 2):
     ref = eng.score(b, 0.25, 0.01)
     shard = Shard(prob["n_store"], world, rank)
     full = eng.store
-    sl = slice(shard.row0, shard.row0 + shard.n_local)
     # the table itself is the same on every rank (seeded by L only); the requests differ per rank
     tab = make_problem(n_store=5000, d=64, n_heads=4, M=16, dsub=4, vocab=600, cutoff=[100, 300], T=16, kg=8, left=2, right=2,
                        n_layers=L, k=32, seed=10 * L, n_blocks=2)
     codes = torch.from_numpy(tab["codes"]).to(dev); vals = torch.from_numpy(tab["vals"]).to(dev)
     full.codes, full.vals = codes, vals                 # direct path on the common table
     ref = eng.score(b, 0.25, 0.01)
-    part = CodeStore(codes=codes[sl].contiguous(), centroids=full.centroids, n_store=full.n_store, row0=shard.row0,
-                     vals=vals[sl].contiguous(), A=full.A, b=full.b)
-    for mode in ("exact", "padded"):
-        f = ShardedFetcher(part, shard, mode=mode)
-        b.fetched_codes, b.fetched_valid, b.fetched_index = f.fetch_codes(b.ids, 2, 2, centres_only=(L == 1))
-        b.fetched_centres_only = (L == 1)
-        b.knn_vals = f.fetch_knn_vals(b.knn_ids)
-        out = eng.score(b, 0.25, 0.01)
-        torch.cuda.synchronize()
-        f.check()
-        assert torch.equal(out["logp"], ref["logp"]) and torch.equal(out["recall"], ref["recall"]), (L, mode)
-        if rank == 0:
-            print("exchange path == direct path, L =", L, mode, "ranks", world)
+    # L = 2 needs every slot of a context group: once slot by slot, once through the halo layout (the shard also holds the
+    # two rows before / after its range; one request per group, answered by the centre's owner)
+    for halo in ((0, 0),) if L == 1 else ((0, 0), (2, 2)):
+        hs = Shard(prob["n_store"], world, rank, halo_left=halo[0], halo_right=halo[1])
+        sl = slice(hs.store_row0, hs.store_row0 + hs.store_rows)
+        part = CodeStore(codes=codes[sl].contiguous(), centroids=full.centroids, n_store=full.n_store, row0=hs.store_row0,
+                         vals=vals[sl].contiguous(), A=full.A, b=full.b)
+        for mode in ("exact", "padded"):
+            f = ShardedFetcher(part, hs, mode=mode)
+            b.fetched_codes, b.fetched_valid, b.fetched_index = f.fetch_codes(b.ids, 2, 2, centres_only=(L == 1))
+            b.fetched_centres_only = (L == 1)
+            b.knn_vals = f.fetch_knn_vals(b.knn_ids)
+            out = eng.score(b, 0.25, 0.01)
+            torch.cuda.synchronize()
+            f.check()
+            assert torch.equal(out["logp"], ref["logp"]) and torch.equal(out["recall"], ref["recall"]), (L, mode, halo)
+            if rank == 0:
+                print("exchange path == direct path, L =", L, mode, "halo" if halo[0] else "slots", "ranks", world)
 dist.destroy_process_group()
