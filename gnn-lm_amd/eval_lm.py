@@ -182,7 +182,10 @@ def main(args, tables=None, model=None):
             group.append(blocks[i + len(group)])
         i += len(group)
         L = group[0][2] - group[0][0]
-        idx = torch.cat([torch.arange(c, e, device=device) for c, _, e in group])
+        if all(group[j + 1][0] == group[j][2] for j in range(len(group) - 1)):
+            idx = slice(group[0][0], group[-1][2])           # back-to-back blocks (no --gcn-context-window): plain views, no gather
+        else:
+            idx = torch.cat([torch.arange(c, e, device=device) for c, _, e in group])
         target = tabs["targets"][idx].view(len(group), L)
         graph = NeighborGraph(ids=tabs["nbrs"][idx].contiguous(), n_blocks=len(group), T=L, left=left, right=right,
                               store=store, tgt_h=tabs["feats"][idx].contiguous(), max_intra_context=args.intra_context)

@@ -67,8 +67,11 @@ class SequenceScorer(object):
         if no_pad is None:
             no_pad = not bool(sample["target"].eq(self.pad).any())
         hypos = []
+        starts = [int(v) for v in start_idxs]
+        # one reduction for the whole batch instead of a sum and a division per hypothesis (64 launches per 32-block batch)
+        score_all = probs[:, starts[0]:].sum(dim=1) / (tsz - starts[0]) if no_pad and len(set(starts)) == 1 and tsz > starts[0] else None
         for i in range(bsz):
-            s = int(start_idxs[i])
+            s = starts[i]
             if no_pad:
                 ref = sample["target"][i, s:]
                 tgt_len = ref.numel()
@@ -84,7 +87,7 @@ class SequenceScorer(object):
                 rec_i = recall[i, s:][mask] if recall is not None else None
             hypos.append([{
                 "tokens": ref,
-                "score": p_i.sum() / tgt_len,
+                "score": score_all[i] if score_all is not None else p_i.sum() / tgt_len,
                 "attention": None,
                 "alignment": None,
                 "positional_scores": p_i,
