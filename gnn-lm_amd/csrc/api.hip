@@ -233,9 +233,23 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         GNNLM_REQUIRE(din == (l == 0 ? dpq : d), "hgt: layer.din must be M*dsub for layer 0 and d afterwards");
 
         // ---- tgt projections (hgt.py:315-322 with the 'intra' relation folded into K and V)
-        TRY(linear(ht_in, d, w.wq_t, w.bq_t, b.q, Tt, d, d, nullptr, 1.f, s));
-        TRY(linear(ht_in, d, w.wk_t, w.bk_t, b.k, Tt, d, d, nullptr, 1.f, s));
-        if (causal_attn_fused_ok(T, dk)) {
+        // q, k', v' of the batch: [Tt, ldq] with the three at column offsets 0 / d / 2d when they come out of one GEMM
+        const float *qp = b.q, *kp = b.k, *vp = b.vt;
+        int64_t ldq = d;
+        const bool qkv_one = causal_attn_fused_ok(T, dk) && w.bq_t && w.wk_t == w.wq_t + (int64_t)d * d &&
+                             w.wv_t == w.wk_t + (int64_t)d * d && w.bk_t == w.bq_t + d && w.bv_t == w.bk_t + d &&
+                             b.k == b.q + Tt * d && b.vt == b.k + Tt * d;
+        if (qkv_one) {
+            // weights stored back to back (hgt.py does): ONE 3d-wide GEMM instead of three d-wide ones (same input; 1536
+            // tiles on the 512 workgroup slots instead of 3 x 512 with a prologue and an epilogue each)
+            TRY(linear(ht_in, d, w.wq_t, w.bq_t, b.q, Tt, 3 * d, d, nullptr, 1.f, s));
+            kp = b.q + d; vp = b.q + 2 * d; ldq = 3 * (int64_t)d;
+        } else {
+            TRY(linear(ht_in, d, w.wq_t, w.bq_t, b.q, Tt, d, d, nullptr, 1.f, s));
+            TRY(linear(ht_in, d, w.wk_t, w.bk_t, b.k, Tt, d, d, nullptr, 1.f, s));
+        }
+        if (qkv_one) {
+        } else if (causal_attn_fused_ok(T, dk)) {
             // recipe shape: V' row-major, then scores + masked softmax + P.V in one kernel (attn.hip)
             // (the kernel itself runs after the star branch and adds its result into the message sum, see below)
             TRY(linear(ht_in, d, w.wv_t, w.bv_t, b.vt, Tt, d, d, nullptr, 1.f, s));
@@ -269,7 +283,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         }
         {   // absorbed star queries U[i,h,:] = Wku_h q[i,h,:]
             GemmParams g{};
-            g.A = b.q; g.lda = d; g.W = w.wku; g.ldw = dk; g.C = b.U; g.ldc = (int64_t)H * din;
+            g.A = qp; g.lda = ldq; g.W = w.wku; g.ldw = dk; g.C = b.U; g.ldc = (int64_t)H * din;
             g.M = (int)Tt; g.N = din; g.K = dk; g.batch1 = H;
             g.sA1 = dk; g.sW1 = (int64_t)din * dk; g.sC1 = din;
             TRY(gemm_nt(g, s));
@@ -302,7 +316,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             TRY(gemm_nt(g, s));
             // recipe shape: the causal branch adds itself into the sum with coalesced row accesses -- cheaper than
             // the residual loads of the GEMM epilogue (same value: star + causal, fp32 addition commutes)
-            if (fused) TRY(causal_attn_fused(b.q, b.k, b.vt, d, b.ms, d, nb, T, H, dk, m.max_intra_context, s, true));
+            if (fused) TRY(causal_attn_fused(qp, kp, vp, ldq, b.ms, d, nb, T, H, dk, m.max_intra_context, s, true));
         }
         // a_linear on the cross-type mean (0.5 folded into alpha) + residual, then LayerNorm (hgt.py:397-405)
         TRY(linear(b.ms, d, w.wa_t, w.ba_t, b.aout, Tt, d, d, nullptr, 0.5f, s));

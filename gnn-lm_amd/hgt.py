@@ -139,7 +139,14 @@ def prepare_hgt_weights(sd: Dict[str, torch.Tensor], n_layers: int, n_heads: int
                 Ks, Vs = pre @ Ks, pre @ Vs
             wku[h], wvz_t[h], bvz[h * dk:(h + 1) * dk] = Ks, Vs.t(), bvh
         out["wku"], out["wvz_t"], out["bvz"] = wku, wvz_t, bvz
-        layers.append(({k: dev32(v) for k, v in out.items()}, din))
+        lay = {k: dev32(v) for k, v in out.items()}
+        # the three tgt projections read the same input: stored back to back ([3d, d] / [3d]) so that the C side can run
+        # them as ONE GEMM with N = 3d (it checks the pointers; separate tensors still work)
+        qkv_w = torch.cat([lay["wq_t"], lay["wk_t"], lay["wv_t"]]).contiguous()
+        qkv_b = torch.cat([lay["bq_t"], lay["bk_t"], lay["bv_t"]]).contiguous()
+        for j, nm in enumerate("qkv"):
+            lay[f"w{nm}_t"], lay[f"b{nm}_t"] = qkv_w[j * d:(j + 1) * d], qkv_b[j * d:(j + 1) * d]
+        layers.append((lay, din))
     codec = {"centroids": store.centroids.to(device, torch.float32).contiguous()}
     if A is not None:
         codec["opq_at"] = dev32(A.t())
