@@ -68,7 +68,7 @@ __host__ __device__ inline Carve carve(int M) {
     c.ubuf = c.sc + TPW * HB * SCS * 4;
     c.okf = c.ubuf + 2 * TPW * 1024;
     c.lcodes = c.okf + TPW * KGM;
-    c.total = c.lcodes + ((TPW * KGM * (M + 4) + 15) & ~15);
+    c.total = c.lcodes + TPW * KGM * M;
     return c;
 }
 
@@ -78,14 +78,18 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     constexpr int MPC = CD / DSUB;              // sub-quantizers per chunk: 4 (dsub 8) or 8 (dsub 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = MT ? MT : p.M, D = p.D, H = p.H, kg = p.kg, NCH = D / CD;
-    const int MS = M + 4;                       // code row stride (bytes): rows of a tile sit on different banks
     const Carve cv = carve(M);
     float* tab = reinterpret_cast<float*>(smem + cv.tab);              // [2][TABF]
     float* sc = reinterpret_cast<float*>(smem + cv.sc);                // pass 1 -> softmax: [TPW][HB][SCS] scores -> alphas
     float* zbuf = sc;                                                  // pass 2: [2 buffers][2 neighbour halves][TPW][HB][CD] sums on their way out
     float* ubuf = reinterpret_cast<float*>(smem + cv.ubuf);            // pass 1: [2 buffers][TPW][64 slots of 16 B] U rows in MFMA operand order
     unsigned char* okf = smem + cv.okf;                                // [TPW][KGM]
-    unsigned char* lcodes = smem + cv.lcodes;                          // [TPW][KGM][MS]
+    // code rows, PIECE-MAJOR: [M / 16 pieces][TPW * KGM rows][16 B] -- a 16-B piece of 64 consecutive rows is 1 KiB of LDS in
+    // row order, i.e. what one LDS-DMA instruction writes (lane = row); word reads of 8 consecutive rows hit 8 different banks
+    unsigned char* lcodes = smem + cv.lcodes;
+    constexpr int NR = TPW * KGM;
+    // byte offset of the 4-B word that holds code column MPC * c_ (+ a lane's column base < 16 - (MPC * c_ & 15)) of row 0
+#define STAB_COL(c_) (((MPC * (c_)) >> 4) * (NR * 16) + ((MPC * (c_)) & 15))
     static_assert(2 * 2 * TPW * HB * CD <= TPW * HB * SCS, "the outgoing sums reuse the score rows");
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -163,8 +167,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
                 const int e = e0 + r * NTHREADS + tid;
                 if (e < n_items) {
                     const int row = e / per_row, part = e - row * per_row;
-                    uint32_t* dst = reinterpret_cast<uint32_t*>(lcodes + row * MS + 16 * part);
-                    dst[0] = v[r].x; dst[1] = v[r].y; dst[2] = v[r].z; dst[3] = v[r].w;
+                    *reinterpret_cast<uint4*>(lcodes + part * (NR * 16) + row * 16) = v[r];
                 }
             }
         }
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q][0] = acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         // code bytes of this lane: neighbour 64 half + 16 q + 4 ng + li, sub-quantizer(s) dq of the chunk (padding rows are zeros)
-        const unsigned char* crow = lcodes + (t * KGM + 64 * half + 4 * ng + li) * MS + (DSUB == 8 ? 0 : 4 * (dq >> 1));
+        const unsigned char* crow = lcodes + (t * KGM + 64 * half + 4 * ng + li) * 16 + (DSUB == 8 ? 0 : 4 * (dq >> 1));
         const unsigned cshift = DSUB == 8 ? 8 * dq : 16 * (dq & 1);     // this lane's byte (dsub 8) or byte pair (dsub 4) of the code word
         unsigned code[4];
         f32x4 xa[2][4], xb[2][4], ua[2][2], ub[2][2];
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
         clk1 = STAB_CLK();
 #define STAB_CODES(c_)                                                                               \
     _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                    \
-        code[q] = *reinterpret_cast<const uint32_t*>(crow + q * 16 * MS + MPC * (c_));
+        code[q] = *reinterpret_cast<const uint32_t*>(crow + q * 256 + STAB_COL(c_));
         // look-up of tile q_ of the chunk in table buffer tb_ into register set s_
 #define STAB_LOOK(s_, q_, tb_)                                                                       \
     if (STAB_OFF(128)) {                                                                             \
@@ -452,14 +455,14 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
             a_reg[gq][0] = sc[(t * HB + j4) * SCS + 64 * kh + 4 * gq + ns];
             a_reg[gq][1] = sc[(t * HB + 4 + j4) * SCS + 64 * kh + 4 * gq + ns];
         }
-        const unsigned char* cbase = lcodes + (t * KGM + 64 * kh + ns) * MS + (msub & ~3);
+        const unsigned char* cbase = lcodes + (t * KGM + 64 * kh + ns) * 16 + (msub & ~3);
         const unsigned shift = 8 * (msub & 3);
         float* zb = zbuf + ((kh * TPW + t) * HB + j4) * CD + 8 * dg;   // (head j4, this lane group's 8 dims): see the write below
         uint32_t w[16];                 // code words of this lane's 16 neighbours for the chunk whose look-ups come next
         f32x2 b[2][16];
 // (a ds_read_u8 of the lane's own byte would save the v_bfe, but measured 11 % slower on the whole sweep: four lanes reading
 // different bytes of one dword do not broadcast)
-#define STAB_W(gq_, c_) w[gq_] = *reinterpret_cast<const uint32_t*>(cbase + 4 * (gq_) * MS + MPC * (c_));
+#define STAB_W(gq_, c_) w[gq_] = *reinterpret_cast<const uint32_t*>(cbase + 64 * (gq_) + STAB_COL(c_));
 #define STAB_BLOOK(s_, gq_, sb_)                                                                     \
     {                                                                                                \
         const unsigned cc_ = STAB_OFF(4) ? 0u : __builtin_amdgcn_ubfe(w[gq_], shift, 8u);            \
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
     }
 #endif
 #undef STAB_DMA_ONE
+#undef STAB_COL
 #undef STAB_SYNC
 #undef STAB_PIN
 #undef STAB_CLK
