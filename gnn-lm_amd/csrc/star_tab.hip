@@ -72,7 +72,7 @@ __host__ __device__ inline Carve carve(int M) {
     return c;
 }
 
-// MT: the number of sub-quantizers when known at compile time (the code-row stride then folds into the DS offsets), else 0
+// MT: the number of sub-quantizers when known at compile time (piece counts and loop bounds of the staging fold), else 0
 template <int DSUB, int MT>
 __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams p, int h0) {
     constexpr int MPC = CD / DSUB;              // sub-quantizers per chunk: 4 (dsub 8) or 8 (dsub 4)
