@@ -290,7 +290,10 @@ bool gemm_dma_eligible(const GemmParams& p) {
     // (GNNLM_DMA_STORE=1 at build time sends them here too, for A/B runs).
 #ifndef GNNLM_DMA_STORE
     // ... except the head-sized ones, which get the 256x256 tiles: 655360x1024x1024 (3-layer path) 123 -> 128 TFLOP/s
-    if (!p.lse_part && (p.m_dev || cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch1 * p.batch2 < GNNLM_DMA_BIG_TILES)) return false;
+    // ... and, round 2 (tools/gemm_bench.py step8k, us: register-staged -> this kernel, 128x128 tiles): the step's K = 1024
+    // problems 8192x1024x1024 169 -> 157, 8192x3072x1024 (Q, K, V in one) 464 -> 436, Z Wvz (batch 8, N = 128) 150 -> 142;
+    // K = 128 (absorbed queries) stays where it is (200 -> 218)
+    if (!p.lse_part && (p.m_dev || (p.K < 512 && cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch1 * p.batch2 < GNNLM_DMA_BIG_TILES))) return false;
 #endif
     if (p.precision == 0 && p.K == 64 && p.lse_part && p.batch1 * p.batch2 == 1 && p.M <= 128 * 768) return true;   // A-stationary kernel
     return p.precision == 0 && p.K % GNNLM_DMA_BK == 0 && p.K >= GNNLM_DMA_MIN_K;

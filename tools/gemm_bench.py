@@ -19,6 +19,10 @@ SHAPES = [  # name, M, N, K, batch1, batch2
     ("ntgt 163840x1024x1024", 163840, 1024, 1024, 1, 1),
     ("sq 4096^3", 4096, 4096, 4096, 1, 1),
     ("head8k 8192x20002x1024", 8192, 20002, 1024, 1, 1),
+    ("step8k proj 8192x1024x1024", 8192, 1024, 1024, 1, 1),
+    ("step8k qkv 8192x3072x1024", 8192, 3072, 1024, 1, 1),
+    ("step8k U 8192x1024x128 b8", 8192, 1024, 128, 8, 1),
+    ("step8k Zvz 8192x128x1024 b8", 8192, 128, 1024, 8, 1),
 ]
 ORDER = int(os.environ.get("TILE_ORDER", "0"))
 PREC = int(os.environ.get("PRECISION", "0"))
