@@ -15,3 +15,29 @@ def test_kernels_are_bit_stable():
                        timeout=900, env=dict(os.environ, REPS="12"), cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "MISMATCH" not in p.stdout and p.stdout.count("OK") >= 10
+
+
+def test_star_attn_tab_repeatable_under_load():
+    """The table-resident star kernel synchronises its waves with raw s_barrier / s_waitcnt pairs and hand-issued LDS-DMA:
+    300 launches on the same inputs (8192 tokens: eight workgroup rounds per CU, every launch a different interleaving
+    of the loader and compute waves) must reproduce the first result bit for bit, with other kernels queued in between."""
+    import torch
+    from gnnlm_amd import ops
+    dev = torch.device("cuda:0")
+    T, H, M, dsub, kg, N = 8192, 8, 128, 8, 128, 2_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    codes = torch.randint(0, 256, (N, M), generator=g, device=dev, dtype=torch.uint8)
+    cen = torch.randn(M, 256, dsub, generator=g, device=dev)
+    U = torch.randn(T, H, M * dsub, generator=g, device=dev) / 32
+    ids = torch.randint(-1, N, (T, kg), generator=g, device=dev)
+    Z0, has0 = ops.star_attn(U, ids, codes=codes, centroids=cen)
+    Z0, has0 = Z0.clone(), has0.clone()
+    noise = torch.randn(4096, 4096, device=dev)
+    for it in range(300):
+        if it % 7 == 0:
+            noise = noise @ noise.t() * 1e-4                      # something else on the device between launches
+        Z, has = ops.star_attn(U, ids, codes=codes, centroids=cen)
+        if it % 25 == 0 or it == 299:
+            assert torch.equal(Z, Z0) and torch.equal(has, has0), it
+    torch.cuda.synchronize()
