@@ -421,7 +421,10 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GNNLM_BENCH_BACKEND=gloo GNNLM_BENCH_DEVICE=0 (tests only): several ranks on ONE GPU, collectives staged through the host --
+    # the whole sharded code path (halo shards, fetch streams, reductions) with a real second rank on a one-GPU box
+    backend = os.environ.get("GNNLM_BENCH_BACKEND", "nccl")
+    local_rank = int(os.environ.get("GNNLM_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
@@ -431,7 +434,19 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def all_reduce(t, op=None):
+        op = op or dist.ReduceOp.SUM
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     from gnnlm_amd import _lib, ops
     from gnnlm_amd.dist import ShardedFetcher
@@ -596,7 +611,7 @@ def main():
             dtr = time.perf_counter() - t0r
             if world > 1:
                 ttr = torch.tensor([dtr], device=dev, dtype=torch.float64)
-                dist.all_reduce(ttr, op=dist.ReduceOp.MAX)
+                all_reduce(ttr, dist.ReduceOp.MAX)
                 dtr = ttr.item()
             replicated = {"tokens_per_s": round(args.steps * args.blocks * args.tokens_per_sample * world / dtr, 1),
                           "ms_per_step": round(dtr / args.steps * 1e3, 4)}
@@ -609,9 +624,9 @@ def main():
             search = knn_search(args, eng, batches, dev, dt / args.steps * 1e3)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        all_reduce(tt, dist.ReduceOp.MAX)
         dt = tt.item()
-        dist.all_reduce(acc)
+        all_reduce(acc)
     tokens = args.steps * args.blocks * args.tokens_per_sample * world
     score_sum = acc.item()
 

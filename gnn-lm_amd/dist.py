@@ -71,6 +71,17 @@ class Shard:
         return torch.where(ok, own, torch.full_like(own, self.rank))
 
 
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None):
+    """all_to_all_single; a process group that cannot move device memory (gloo: used to run TWO ranks on ONE GPU in the
+    tests -- RCCL refuses two ranks per device) is served through pinned host copies of the same buffers."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
 def bucket_torch(rows: torch.Tensor, shard: Shard):
     """Backend-agnostic bucketing (stable sort by owner).  -> (counts [world] i64, send_rows, inv)."""
     owner = shard.owner(rows)
@@ -107,14 +118,14 @@ def exchange_fetch(rows: torch.Tensor, shard: Shard, local_gather: Callable[[tor
     rows = rows.reshape(-1).contiguous()
     counts, send_rows, inv = bucket(rows, shard)
     recv_counts = torch.empty_like(counts)
-    dist.all_to_all_single(recv_counts, counts, group=group)
+    _all_to_all(recv_counts, counts, group=group)
     in_splits, out_splits = counts.tolist(), recv_counts.tolist()
     recv_rows = torch.empty(sum(out_splits), dtype=rows.dtype, device=rows.device)
-    dist.all_to_all_single(recv_rows, send_rows, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    _all_to_all(recv_rows, send_rows, out_splits, in_splits, group)
     payload = local_gather(recv_rows).contiguous()
     assert payload.shape[0] == recv_rows.numel()
     back = torch.empty((S,) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
-    dist.all_to_all_single(back, payload, output_split_sizes=in_splits, input_split_sizes=out_splits, group=group)
+    _all_to_all(back, payload, in_splits, out_splits, group)
     if not unpermute:
         return back, inv
     return back[inv.long()]
@@ -172,10 +183,10 @@ def exchange_fetch_padded(rows: torch.Tensor, shard: Shard, local_gather: Callab
     rows = rows.reshape(-1).contiguous()
     send, index, overflow = bucket(rows, shard, cap)
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
+    _all_to_all(recv, send, group=group)
     payload = local_gather(recv).contiguous()                       # [world*cap, ...]; -1 ids give zero rows
     back = torch.zeros((shard.world * cap + 1,) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
-    dist.all_to_all_single(back[:shard.world * cap], payload, group=group)
+    _all_to_all(back[:shard.world * cap], payload, group=group)
     return back, index, overflow
 
 

@@ -49,3 +49,26 @@ def test_bench_modes_agree():
     b = run_bench("--no-cpu-baseline", "--force-exchange")
     c = run_bench("--no-cpu-baseline", "--graph")
     assert a["config"]["synthetic_ppl"] == b["config"]["synthetic_ppl"] == c["config"]["synthetic_ppl"]
+
+
+@pytest.mark.parametrize("extra", [(), ("--layers", "2"), ("--shard-vals", "--exchange", "exact")])
+def test_bench_two_ranks_on_one_gpu(extra):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with both ranks on
+    device 0 and the collectives staged through the host (gloo): the sharded code path of the bench -- halo shards with
+    matching boundary rows, fetch stream, padded / exact exchange, the replicated-store comparison, the max-over-ranks
+    timing and the score reduction -- runs with a real second rank.  L = 2 goes through the halo layout."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--small", "--blocks", "2", "--steps", "3",
+           "--warmup", "2", "--n-store", "30000", "--gcn-k", "16", "--k", "32", "--tokens-per-sample", "32", "--no-cpu-baseline",
+           *extra]
+    env = dict(os.environ, GNNLM_BENCH_BACKEND="gloo", GNNLM_BENCH_DEVICE="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                                   # rank 0 prints, once
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "weak"
+    c = r["config"]
+    assert c["rccl_ranks"] == 2 and c["store"].startswith("range-sharded") and c["xgmi_bytes_per_step_per_rank"] > 0
+    if "--shard-vals" not in extra:                                    # (the comparison run needs the full label table)
+        assert c["replicated_store"]["tokens_per_s"] > 0

@@ -79,3 +79,16 @@ def test_exchange_over_rccl_single_rank():
                        text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("exchange path == direct path") == 6          # L = 1; L = 2 slot by slot and halo layout; x exact, padded
+
+
+def test_exchange_two_ranks_on_one_gpu():
+    """World = 2 on ONE GPU: two processes share device 0 and exchange through gloo (host-staged copies of the same
+    buffers -- RCCL refuses two ranks per device), so the bucketing kernels, the owner-side HIP gather (also of halo
+    rows across the shard boundary), the bucketed payload + index path of the consumers and the fixed-capacity mode all
+    run with a real second rank on the one-GPU box.  The RCCL transport itself is what test_exchange_rccl_two_ranks adds."""
+    env = dict(os.environ, GNNLM_CHECK_BACKEND="gloo", GNNLM_CHECK_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tools", "exchange_check.py")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("exchange path == direct path") == 6 and "ranks 2" in r.stdout

@@ -2,14 +2,20 @@
 """Exercise of the sharded-store exchange over RCCL: the routing, the HIP owner-side gather and the fetched-codes path
 of the HGT must give the same result as the direct path on a replicated store -- with any number of ranks
 (`python tools/exchange_check.py` = one rank; `python -m torch.distributed.run --nproc-per-node N ...` = N ranks),
-in the exact (variable-split) and the padded (fixed-capacity, sync-free) mode."""
+in the exact (variable-split) and the padded (fixed-capacity, sync-free) mode, slot by slot and through the halo layout."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 import numpy as np, torch, torch.distributed as dist
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))); torch.cuda.set_device(dev)
-dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+# GNNLM_CHECK_BACKEND=gloo GNNLM_CHECK_DEVICE=0: several ranks on ONE GPU (the collectives staged through the host): the routing,
+# the bucketing kernels, the owner-side gather and the consumers with world > 1 on a one-GPU box
+backend = os.environ.get("GNNLM_CHECK_BACKEND", "nccl")
+dev = torch.device("cuda", int(os.environ.get("GNNLM_CHECK_DEVICE", os.environ.get("LOCAL_RANK", "0")))); torch.cuda.set_device(dev)
+if backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+else:
+    dist.init_process_group(backend, rank=rank, world_size=world)
 from gnnlm_amd.dist import Shard, ShardedFetcher
 from gnnlm_amd.hgt import CodeStore
 from gnnlm_amd.synthetic import make_problem, build_engine, to_batch
