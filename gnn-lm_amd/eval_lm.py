@@ -75,6 +75,8 @@ def get_parser():
     p.add_argument("--fp16", action="store_true")
     p.add_argument("--cpu", action="store_true")
     p.add_argument("--save-knnlm-dstore", action="store_true")
+    p.add_argument("--dstore-mmap", default=None, help="where --save-knnlm-dstore writes <subset>_dstore[-keytype]/")
+    p.add_argument("--dstore-fp16", action="store_true")
     p.add_argument("--output-word-probs", action="store_true")
     p.add_argument("--output-word-stats", action="store_true")
     p.add_argument("--output-knn-recall", action="store_true")
@@ -132,8 +134,8 @@ def main(args, tables=None, model=None):
         raise RuntimeError("gnnlm_amd.eval_lm needs an MI355X: the product path has no CPU fallback")
     if not (args.graph and args.use_precompute_feat):
         raise NotImplementedError("only the --graph --use-precompute-feat eval path is built (the base LM is out of scope)")
-    if args.save_knnlm_dstore:
-        raise NotImplementedError("--save-knnlm-dstore needs the base LM forward (SURVEY.md 8f.4)")
+    if args.save_knnlm_dstore and not args.dstore_mmap:
+        raise ValueError("--save-knnlm-dstore needs --dstore-mmap")
     if args.knnlm and args.save_knnlm_dstore:
         raise ValueError("Cannot use knnlm while trying to build the datastore!")
     if args.context_window > 0:
@@ -169,6 +171,25 @@ def main(args, tables=None, model=None):
                               no_load_keys=("do_not_recomp" in args.knn_sim_func), use_memory=True,
                               metric_type=args.knn_sim_func, device=device) if not getattr(args, "knn_model", None) \
             else args.knn_model
+    # --save-knnlm-dstore (fairseq_cli/eval_lm.py:103-104,178-205,222-242): the keys the scorer hands back per hypothesis
+    # (`--knn-keytype`, here the HGT output "gcn_feat") and the target tokens, written as the split's datastore
+    save = None
+    if args.save_knnlm_dstore:
+        dstore_size, dim = int(tabs["n_tok"]), int(tabs["d"])              # dataset.sizes.sum() (:104)
+        fp16 = bool(args.dstore_fp16)
+        suffix = "" if not args.knn_keytype else f"-{args.knn_keytype}"
+        save_dir = os.path.join(args.dstore_mmap, f"{args.gen_subset}_dstore{suffix}")
+        os.makedirs(save_dir, exist_ok=True)
+        vocab = tabs.get("vocab") or int(tabs["targets"].max().item()) + 1
+        info = {"dstore_size": dstore_size, "hidden_size": dim, "vocab_size": int(vocab), "dstore_fp16": fp16, "val_size": 1}
+        logger.info(f"keytype being saved: {args.knn_keytype}")
+        logger.info(f"dstore info: {info}")
+        json.dump(info, open(os.path.join(save_dir, "info.json"), "w"), indent=4, sort_keys=True)
+        save = {"dir": save_dir, "idx": 0, "size": dstore_size, "dim": dim,
+                "keys": np.memmap(os.path.join(save_dir, "keys.npy"), dtype=np.float16 if fp16 else np.float32, mode="w+",
+                                  shape=(dstore_size, dim)),
+                "vals": np.memmap(os.path.join(save_dir, "vals.npy"), dtype=np.int16 if fp16 and vocab < 2 ** 15 else np.int32,
+                                  mode="w+", shape=(dstore_size, 1))}
     acc = torch.zeros(1, device=device, dtype=torch.float64)
     count, ntok = 0, 0
     timers = []             # gen_timer (eval_lm.py:214-219) as HIP event pairs on the stream: no per-batch host sync
@@ -201,10 +222,24 @@ def main(args, tables=None, model=None):
         ev1.record()
         timers.append((ev0, ev1))
         ntok += sample["ntokens"]
+        if save is not None:                                     # one device -> host copy per batch (this run is a writer anyway)
+            keys = torch.cat([h[0]["dstore_keys"].reshape(-1, save["dim"]) for h in hypos])
+            toks = torch.cat([h[0]["tokens"].reshape(-1) for h in hypos])
+            n_new = min(keys.shape[0], save["size"] - save["idx"])
+            if n_new < keys.shape[0]:
+                logger.warning("exceed offset at sample " + str(i))          # :227-230
+            sl = slice(save["idx"], save["idx"] + n_new)
+            save["keys"][sl] = keys[:n_new].to(torch.float16 if save["keys"].dtype == np.float16 else torch.float32).cpu().numpy()
+            save["vals"][sl, 0] = toks[:n_new].cpu().numpy().astype(save["vals"].dtype)
+            save["idx"] += n_new
         pos = torch.cat([h[0]["positional_scores"].float().reshape(-1) for h in hypos])     # one launch per batch
         ops.masked_sum_f64(pos, None, acc)                                                  # score_sum (:273), in f64
         count += pos.numel()                                                                # :274
     score_sum = acc.item()                                                                  # the only host sync
+    if save is not None:
+        save["keys"].flush()
+        save["vals"].flush()
+        logger.info(f"Saved {save['idx']} data to {save['dir']}")                           # :322-323
     wall = time.perf_counter() - wall0                                                      # the loop as a whole ("wps", :316)
     gen_time = sum(a.elapsed_time(b) for a, b in timers) / 1e3
     if torch.distributed.is_available() and torch.distributed.is_initialized():

@@ -286,3 +286,40 @@ def test_find_knn_producer(dev, tmp_path):
     for k2 in (8, 4):
         t = np.memmap(str(data / "test_dstore" / f"neighbors.mmap.{k2}"), dtype=np.int64, mode="r", shape=(n_test, k2))
         assert np.array_equal(np.array(t), ref[:, :k2])
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+def test_eval_lm_save_knnlm_dstore(dev, tmp_path, fp16):
+    """--save-knnlm-dstore (fairseq_cli/eval_lm.py:103-104,178-205,222-242,322-323) on the precomputed-feature path: the
+    split's kNN datastore of the GNN features -- info.json, keys.npy ([n, d], the `--knn-keytype gcn_feat` rows the
+    scorer hands back, incl. the ragged last block), vals.npy ([n, 1], the target tokens, int16 for an fp16 store with a
+    small vocabulary) -- equals what the oracle computes, and the DataStore mirror reads it back."""
+    import json
+    from gnnlm_amd import eval_lm
+    from gnnlm_amd.data_store import DataStore
+    from oracle import pipeline
+    c = make_data_dir(tmp_path)
+    blk, T, n_test = c["blk"], c["T"], c["n_test"]
+    out = tmp_path / "dstores"
+    res = eval_lm.cli_main(c["base"] + ["--save-knnlm-dstore", "--dstore-mmap", str(out)] + (["--dstore-fp16"] if fp16 else []))
+    assert res["count"] == n_test
+    sdir = out / "test_dstore-gcn_feat"
+    info = json.load(open(sdir / "info.json"))
+    d = c["prob"]["d"]
+    assert info == {"dstore_size": n_test, "hidden_size": d, "vocab_size": 600, "dstore_fp16": fp16, "val_size": 1}
+    keys = np.memmap(sdir / "keys.npy", dtype=np.float16 if fp16 else np.float32, mode="r", shape=(n_test, d))
+    vals = np.memmap(sdir / "vals.npy", dtype=np.int16 if fp16 else np.int32, mode="r", shape=(n_test, 1))
+    ref = []
+    for s in range(0, n_test, T):
+        e = min(n_test, s + T)
+        one = {"neighbor_idxs": blk["ids"][s:e], "tgt_feats": blk["tgt_feats"][s:e], "targets": blk["targets"][s:e],
+               "knn_sims": None, "knn_ids": None}
+        ref.append(pipeline.eval_block(one, c["model"], 0.0, 1.0)["gcn_feat"].float().numpy())
+    ref = np.concatenate(ref)
+    assert np.array_equal(vals[:, 0], blk["targets"])
+    assert np.abs(np.asarray(keys, np.float32) - ref).max() < (2e-2 if fp16 else 1e-4)       # fp16 rounding of O(1) features
+    ds = DataStore.from_pretrained(str(sdir), use_memory=True)
+    assert ds.dstore_size == n_test and ds.hidden_size == d and np.array_equal(np.asarray(ds.vals).reshape(-1), blk["targets"])
+    with pytest.raises(ValueError):
+        eval_lm.cli_main(c["base"] + ["--save-knnlm-dstore", "--dstore-mmap", str(out), "--knnlm", "--lmbda", "0.25",
+                                      "--dstore-dir", str(c["data"] / "train_dstore")])
