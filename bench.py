@@ -66,7 +66,7 @@ def parse():
                     help="GEMM arithmetic: f32 = native f32 MFMA (headline, the reference's precision); bf16x3 / bf16x6 = "
                          "opt-in split-bf16 emulation of the f32 product on the bf16 MFMA (max |dlogp| vs f32 is reported)")
     ap.add_argument("--shard-vals", action="store_true", help="also range-shard the label table (default: replicated)")
-    ap.add_argument("--exchange", choices=["padded", "exact"], default="padded",
+    ap.add_argument("--exchange", choices=["padded", "exact", "peer"], default="padded",
                     help="sharded store: fixed-capacity sync-free exchange (2 all-to-alls, no host round trip; dropped rows are "
                          "checked for after the run) or the exact variable-split one (3 all-to-alls, 2 host syncs per table)")
     ap.add_argument("--force-exchange", action="store_true",
@@ -449,10 +449,14 @@ def main():
             t.copy_(h)
 
     from gnnlm_amd import _lib, ops
-    from gnnlm_amd.dist import ShardedFetcher
+    from gnnlm_amd.dist import PeerMappedFetcher, ShardedFetcher
     eng, shard, sharded, cpu_model, (d, vocab) = build(args, dev, rank, world)
     batches = make_batches(args, dev, rank, d, vocab)
-    fetcher = ShardedFetcher(eng.store, shard, mode=args.exchange) if sharded else None
+    # --exchange peer: no collective -- the peers' shards are mapped into this process (HIP IPC) and gathered by one kernel
+    fetcher = None
+    if sharded:
+        fetcher = PeerMappedFetcher(eng.store, shard, share_vals=args.shard_vals) if args.exchange == "peer" \
+            else ShardedFetcher(eng.store, shard, mode=args.exchange)
     centres_only = args.layers == 1
     acc = torch.zeros(1, device=dev, dtype=torch.float64)
 

@@ -445,7 +445,7 @@ size_t gnnlm_sizeof(const char* name) {
 #define GNNLM_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
     GNNLM_SZ(gnnlm_gemm_t) GNNLM_SZ(gnnlm_gather_t) GNNLM_SZ(gnnlm_star_attn_t) GNNLM_SZ(gnnlm_chain_attn_t)
     GNNLM_SZ(gnnlm_adaptive_softmax_t) GNNLM_SZ(gnnlm_knn_interp_t) GNNLM_SZ(gnnlm_hgt_layer_t)
-    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t)
+    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t) GNNLM_SZ(gnnlm_peer_gather_t)
 #undef GNNLM_SZ
     return 0;
 }
@@ -457,6 +457,13 @@ size_t gnnlm_sizeof(const char* name) {
     }
 
 int gnnlm_gemm_nt(const gnnlm_gemm_t* d, void* stream) { GNNLM_DESC(d); return gemm_nt(*d, (hipStream_t)stream); }
+int gnnlm_gather_rows_peer(const gnnlm_peer_gather_t* d, void* stream) { GNNLM_DESC(d); return gather_rows_peer(*d, (hipStream_t)stream); }
+int gnnlm_enable_peer_access(int32_t peer_device) {
+    const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return OK; }
+    GNNLM_HIP(e);
+    return OK;
+}
 int gnnlm_lse_reduce(const float* part, int32_t n_parts, int64_t rows, const int32_t* m_dev, float* lse, void* stream) {
     return lse_reduce(part, n_parts, rows, m_dev, lse, (hipStream_t)stream);
 }

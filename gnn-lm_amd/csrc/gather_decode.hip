@@ -275,6 +275,50 @@ int bucket_rows_padded(const int64_t* rows, int64_t n, int64_t n_store, int64_t 
     return OK;
 }
 
+namespace {
+// one request per group of LPR lanes (16 B each; LPR = row_bytes / 16), or one lane per request for short rows
+__global__ __launch_bounds__(256) void gather_rows_peer_kernel(gnnlm_peer_gather_t d, int lpr) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t s = gid / lpr;
+    const int part = (int)(gid - s * lpr);
+    if (s >= d.n) return;
+    const int64_t row = d.rows[s];
+    bool ok = row >= 0 && row < d.n_store;
+    int g = 0;
+    int64_t local = 0;
+    if (ok) {
+        g = (int)min((int64_t)d.world - 1, row / d.rows_per_rank);
+        local = row - d.shard_row0[g];
+        ok = local >= 0 && local < d.shard_rows[g];
+    }
+    if (part == 0 && d.out_valid) d.out_valid[s] = ok ? 1 : 0;
+    if (d.row_bytes >= 16) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) v = reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(d.shard[g]) + local * d.row_bytes)[part];
+        reinterpret_cast<uint4*>(static_cast<uint8_t*>(d.out) + s * d.row_bytes)[part] = v;
+    } else {
+        const uint8_t* src = static_cast<const uint8_t*>(d.shard[g]) + local * d.row_bytes;
+        uint8_t* dst = static_cast<uint8_t*>(d.out) + s * d.row_bytes;
+        for (int b = 0; b < d.row_bytes; ++b) dst[b] = ok ? src[b] : 0;
+    }
+}
+}  // namespace
+
+int gather_rows_peer(const gnnlm_peer_gather_t& d, hipStream_t stream) {
+    GNNLM_REQUIRE(d.world >= 1 && d.world <= 16 && d.rows_per_rank > 0 && d.n_store > 0 && d.n >= 0 && d.n < (1ll << 31),
+                  "gather_rows_peer: bad arguments");
+    GNNLM_REQUIRE(d.row_bytes > 0 && (d.row_bytes <= 16 || d.row_bytes % 16 == 0) && d.row_bytes <= 4096, "gather_rows_peer: row_bytes must be 1..16 or a multiple of 16");
+    if (d.n == 0) return OK;
+    GNNLM_REQUIRE(d.rows && d.out, "gather_rows_peer: null operand");
+    for (int g = 0; g < d.world; ++g)
+        GNNLM_REQUIRE(d.shard_rows[g] == 0 || (d.shard[g] && (d.row_bytes < 16 || (uintptr_t)d.shard[g] % 16 == 0)), "gather_rows_peer: null / misaligned shard");
+    GNNLM_REQUIRE(d.row_bytes < 16 || (uintptr_t)d.out % 16 == 0, "gather_rows_peer: misaligned output");
+    const int lpr = d.row_bytes >= 16 ? d.row_bytes / 16 : 1;
+    hipLaunchKernelGGL(gather_rows_peer_kernel, dim3((unsigned)cdiv(d.n * lpr, 256)), dim3(256), 0, stream, d, lpr);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
 int pq_encode(const float* x, int64_t ldx, const float* cen, const float* norm2, int M, int dsub, int64_t n, uint8_t* codes,
               hipStream_t stream) {
     GNNLM_REQUIRE(M > 0 && dsub > 0 && n >= 0, "pq_encode: bad shape");

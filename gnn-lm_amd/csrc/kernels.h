@@ -34,6 +34,7 @@ int pq_encode(const float* x, int64_t ldx, const float* cen, const float* norm2,
               hipStream_t stream);
 int bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t per, int world, int self, int64_t* counts,
                 int64_t* cursor, int64_t* send_rows, int32_t* inv, hipStream_t stream);
+int gather_rows_peer(const gnnlm_peer_gather_t& d, hipStream_t stream);
 int bucket_rows_padded(const int64_t* rows, int64_t n, int64_t n_store, int64_t per, int world, int64_t cap, int64_t* cursor,
                        int64_t* send_rows, int32_t* inv, int64_t* overflow, hipStream_t stream);
 int star_attn(const StarAttnParams& p, hipStream_t stream);

@@ -310,3 +310,68 @@ class ShardedFetcher:
             return back[index.long()].reshape(knn_ids.shape)
         self._account_exact(rows.numel(), 4)
         return exchange_fetch(rows, self.shard, self._gather_vals, self.group, bucket=bucket_hip).reshape(knn_ids.shape)
+
+
+class PeerMappedFetcher:
+    """The alternative to the exchange: every rank maps its peers' shards into its own address space (HIP
+    IPC handles, passed round once with all_gather_object) and gathers the rows it needs itself -- ONE kernel
+    (`gnnlm_gather_rows_peer`), no collective, no bucketing, no padding; over xGMI its loads go straight to the owner's
+    HBM.  Same contract as :class:`ShardedFetcher` (codes in request order: the index is the identity)."""
+
+    def __init__(self, store, shard: Shard, group=None, share_vals: bool = False):
+        from torch.multiprocessing.reductions import reduce_tensor
+        from . import _lib
+        self._lib, self.store, self.shard, self.group = _lib, store, shard, group
+        assert store.row0 == shard.store_row0 and store.codes.shape[0] == shard.store_rows
+        W = shard.world
+        mine = {"codes": reduce_tensor(store.codes) if store.codes.numel() else None,
+                "vals": reduce_tensor(store.vals) if share_vals and store.vals is not None and store.vals.numel() else None,
+                "device": store.codes.device.index}
+        everyone = [None] * W
+        if W > 1:
+            dist.all_gather_object(everyone, mine, group=group)
+        else:
+            everyone[0] = mine
+        open_ = lambda h: None if h is None else h[0](*h[1])
+        self.peers = {k: [getattr(store, k) if g == shard.rank else open_(everyone[g][k]) for g in range(W)] for k in ("codes", "vals")}
+        here = store.codes.device.index
+        for g in range(W):
+            if g != shard.rank and everyone[g]["device"] != here:
+                _lib.call("gnnlm_enable_peer_access", everyone[g]["device"])
+        self._shards = [Shard(shard.n_store, W, g, shard.halo_left, shard.halo_right) for g in range(W)]
+        self.share_vals = share_vals
+        self.link_bytes = 0
+
+    def check(self):
+        pass                                                    # nothing can overflow
+
+    def _gather(self, rows, what, row_bytes, out):
+        L = self._lib
+        d = L.gnnlm_peer_gather_t()
+        for g, (sh, t) in enumerate(zip(self._shards, self.peers[what])):
+            d.shard[g] = t.data_ptr() if t is not None and t.numel() else None
+            d.shard_row0[g], d.shard_rows[g] = sh.store_row0, (t.shape[0] if t is not None else 0)
+        d.world, d.row_bytes = self.shard.world, row_bytes
+        d.rows_per_rank, d.n_store = self.shard.per, self.shard.n_store
+        rows = rows.reshape(-1).contiguous()
+        valid = torch.empty(rows.numel(), dtype=torch.uint8, device=rows.device)
+        d.rows, d.n, d.out, d.out_valid = rows.data_ptr(), rows.numel(), out.data_ptr(), valid.data_ptr()
+        L.call_desc("gnnlm_gather_rows_peer", d)
+        W = self.shard.world
+        self.link_bytes += int(rows.numel() * (W - 1) / W) * row_bytes          # uniform-id expectation, payload only
+        return valid
+
+    def fetch_codes(self, ids, left, right, centres_only):
+        rows = ids.reshape(-1) if centres_only else slot_rows(ids, left, right, self.store.n_store)
+        M = self.store.codes.shape[1]
+        codes = torch.empty(rows.numel(), M, dtype=torch.uint8, device=ids.device)
+        valid = self._gather(rows, "codes", M, codes)
+        return codes, valid, torch.arange(rows.numel(), dtype=torch.int32, device=ids.device)
+
+    def fetch_knn_vals(self, knn_ids):
+        assert self.share_vals, "built without the label shards"
+        rows = torch.where(knn_ids < 0, knn_ids + self.store.n_store, knn_ids).reshape(-1)
+        v = self.store.vals
+        out = torch.empty(rows.numel(), dtype=v.dtype, device=knn_ids.device)
+        self._gather(rows, "vals", v.element_size(), out)
+        return out.to(torch.int32).reshape(knn_ids.shape)

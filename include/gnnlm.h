@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNLM_ABI_VERSION 3
+#define GNNLM_ABI_VERSION 4
 #define GNNLM_OK 0
 #define GNNLM_E_INVALID (-22)
 #define GNNLM_E_NOMEM (-12)
@@ -342,6 +342,26 @@ int gnnlm_bucket_rows(const int64_t* rows, int64_t n, int64_t n_store, int64_t r
  * which the call ADDS to).  `cursor` is an int64[world] scratch.  Equal-split all-to-alls can then be used. */
 int gnnlm_bucket_rows_padded(const int64_t* rows, int64_t n, int64_t n_store, int64_t rows_per_rank, int32_t world,
                              int64_t cap, int64_t* cursor, int64_t* send_rows, int32_t* inv, int64_t* overflow, void* stream);
+
+/* Peer-mapped alternative to the exchange: every rank maps the shards of its peers into its own address
+ * space (hipIpcOpenMemHandle; over xGMI the loads of this kernel then go to the owner's HBM directly) and gathers the
+ * requested rows itself -- one kernel, no collective, no bucketing, payload in request order.  shard[g] is the base of the
+ * rows [shard_row0[g], shard_row0[g] + shard_rows[g]) rank g HOLDS (its range plus halo, if any); the owner of a row is
+ * row / rows_per_rank as in gnnlm_bucket_rows.  Rows outside [0, n_store) (the -1 of invalid slots) give zero rows and
+ * out_valid 0.  row_bytes: 1..16 or a multiple of 16 (128-B code rows, 4-B / 2-B labels). */
+typedef struct gnnlm_peer_gather {
+    const void* shard[16];
+    int64_t shard_row0[16], shard_rows[16];
+    int32_t world, row_bytes;
+    int64_t rows_per_rank, n_store;
+    const int64_t* rows;  int64_t n;
+    void* out;                 /* [n, row_bytes] */
+    uint8_t* out_valid;        /* optional [n] */
+} gnnlm_peer_gather_t;
+int gnnlm_gather_rows_peer(const gnnlm_peer_gather_t* desc, void* stream);
+/* hipDeviceEnablePeerAccess(peer) for the current device (no error if already enabled); the Python side calls it once per
+ * peer before the first gather when the shards live on other devices */
+int gnnlm_enable_peer_access(int32_t peer_device);
 
 /* ------------------------------------------------------------------------------------------------
  * Opt-in live timing (bench.py's roofline): while a profile is open every launch of the selected

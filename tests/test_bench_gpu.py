@@ -51,7 +51,8 @@ def test_bench_modes_agree():
     assert a["config"]["synthetic_ppl"] == b["config"]["synthetic_ppl"] == c["config"]["synthetic_ppl"]
 
 
-@pytest.mark.parametrize("extra", [(), ("--layers", "2"), ("--shard-vals", "--exchange", "exact")])
+@pytest.mark.parametrize("extra", [(), ("--layers", "2"), ("--shard-vals", "--exchange", "exact"),
+                                   ("--exchange", "peer", "--layers", "2"), ("--exchange", "peer", "--shard-vals")])
 def test_bench_two_ranks_on_one_gpu(extra):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with both ranks on
     device 0 and the collectives staged through the host (gloo): the sharded code path of the bench -- halo shards with

@@ -70,7 +70,7 @@ def test_exchange_rccl_two_ranks():
                         "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "tools", "exchange_check.py")],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("exchange path == direct path") >= 6
+    assert r.stdout.count("exchange path == direct path") >= 9
 
 
 def test_exchange_over_rccl_single_rank():
@@ -78,7 +78,7 @@ def test_exchange_over_rccl_single_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_check.py")], capture_output=True,
                        text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("exchange path == direct path") == 6          # L = 1; L = 2 slot by slot and halo layout; x exact, padded
+    assert r.stdout.count("exchange path == direct path") == 9          # L = 1; L = 2 slot by slot and halo layout; x exact, padded, peer-mapped
 
 
 def test_exchange_two_ranks_on_one_gpu():
@@ -91,4 +91,4 @@ def test_exchange_two_ranks_on_one_gpu():
                         "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tools", "exchange_check.py")],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.count("exchange path == direct path") == 6 and "ranks 2" in r.stdout
+    assert r.stdout.count("exchange path == direct path") == 9 and "ranks 2" in r.stdout

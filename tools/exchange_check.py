@@ -16,7 +16,7 @@ if backend == "nccl":
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 else:
     dist.init_process_group(backend, rank=rank, world_size=world)
-from gnnlm_amd.dist import Shard, ShardedFetcher
+from gnnlm_amd.dist import PeerMappedFetcher, Shard, ShardedFetcher
 from gnnlm_amd.hgt import CodeStore
 from gnnlm_amd.synthetic import make_problem, build_engine, to_batch
 for L in (1, 2):
@@ -40,8 +40,9 @@ for L in (1, 2):
         sl = slice(hs.store_row0, hs.store_row0 + hs.store_rows)
         part = CodeStore(codes=codes[sl].contiguous(), centroids=full.centroids, n_store=full.n_store, row0=hs.store_row0,
                          vals=vals[sl].contiguous(), A=full.A, b=full.b)
-        for mode in ("exact", "padded"):
-            f = ShardedFetcher(part, hs, mode=mode)
+        for mode in ("exact", "padded", "peer"):
+            # "peer": no collective at all -- the shards are mapped into every rank (HIP IPC) and gathered directly
+            f = PeerMappedFetcher(part, hs, share_vals=True) if mode == "peer" else ShardedFetcher(part, hs, mode=mode)
             b.fetched_codes, b.fetched_valid, b.fetched_index = f.fetch_codes(b.ids, 2, 2, centres_only=(L == 1))
             b.fetched_centres_only = (L == 1)
             b.knn_vals = f.fetch_knn_vals(b.knn_ids)
