@@ -452,11 +452,34 @@ def main():
     from gnnlm_amd.dist import PeerMappedFetcher, ShardedFetcher
     eng, shard, sharded, cpu_model, (d, vocab) = build(args, dev, rank, world)
     batches = make_batches(args, dev, rank, d, vocab)
-    # --exchange peer: no collective -- the peers' shards are mapped into this process (HIP IPC) and gathered by one kernel
+    # --exchange peer: no collective and no fetch step for the codes -- the peers' shards are mapped into this process (HIP
+    # IPC) and the star-attention / gather kernels read every row from its owner's memory themselves; only sharded LABELS
+    # (--shard-vals) are still gathered into a local buffer (one kernel)
     fetcher = None
-    if sharded:
-        fetcher = PeerMappedFetcher(eng.store, shard, share_vals=args.shard_vals) if args.exchange == "peer" \
-            else ShardedFetcher(eng.store, shard, mode=args.exchange)
+    if sharded and args.exchange == "peer":
+        pf = PeerMappedFetcher(eng.store, shard, share_vals=args.shard_vals)
+        eng.store = pf.mapped_store()
+        eng.store.vals_row0 = shard.store_row0 if args.shard_vals else 0
+
+        class _MappedCodes:                                       # the bench's fetcher interface over the mapped store
+            link_bytes = 0
+
+            def fetch_codes(self, ids, left, right, centres_only):
+                n = ids.numel() if centres_only else ids.numel() * (1 + left + right)
+                self.link_bytes += int(n * (world - 1) / world) * eng.store.codes.shape[1]     # rows the kernels pull over the links
+                return None, None, None
+
+            def fetch_knn_vals(self, knn_ids):
+                r = pf.fetch_knn_vals(knn_ids)
+                self.link_bytes += pf.link_bytes
+                pf.link_bytes = 0
+                return r
+
+            def check(self):
+                pass
+        fetcher = _MappedCodes()
+    elif sharded:
+        fetcher = ShardedFetcher(eng.store, shard, mode=args.exchange)
     centres_only = args.layers == 1
     acc = torch.zeros(1, device=dev, dtype=torch.float64)
 

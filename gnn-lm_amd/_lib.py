@@ -40,6 +40,8 @@ def _parse_structs(text):
                     ctype = ctypes.c_void_p
                 elif base in _SCALARS:
                     ctype = _SCALARS[base]
+                elif base in structs:                     # a struct of the header embedded by value
+                    ctype = structs[base]
                 else:
                     raise ValueError(f"gnnlm.h: unsupported field type {base!r} in {m.group(3)}")
                 if arr:

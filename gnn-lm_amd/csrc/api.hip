@@ -167,7 +167,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
     GNNLM_REQUIRE(io.tgt_feats && io.ids && io.out_tgt, "hgt: null io");
     const bool dense0 = io.ntgt_feats != nullptr;        // layer-0 ntgt states given (input adapters): no code store
     GNNLM_REQUIRE(dense0 || (m.centroids && m.M > 0 && m.dsub > 0), "hgt: codec missing");
-    GNNLM_REQUIRE(dense0 || io.fetched_codes || m.codes, "hgt: no code store");
+    GNNLM_REQUIRE(dense0 || io.fetched_codes || m.codes || m.shards, "hgt: no code store");
     GNNLM_REQUIRE(!dense0 || (io.ntgt_valid && io.ld_ntgt >= m.d && io.ld_ntgt % 4 == 0 && !io.fetched_codes),
                   "hgt: ntgt_feats needs ntgt_valid, ld_ntgt >= d (a multiple of 4) and no fetched_codes");
     const bool ntgt = needs_ntgt(m, io);
@@ -200,6 +200,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         // layer-0 ntgt states: PQ lookup of every slot, then the OPQ rotation (pq_wrapper.py:189-202)
         GatherParams g{};
         g.codes = io.fetched_codes ? io.fetched_codes : m.codes;
+        if (!io.fetched_codes) g.shards = m.shards;
         g.direct = io.fetched_codes ? 1 : 0;
         g.in_valid = io.fetched_valid;
         g.in_index = io.fetched_index;
@@ -297,6 +298,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             else if (io.fetched_valid) { a.nb_valid = io.fetched_valid; a.nb_valid_stride = io.fetched_centres_only ? 1 : n_g; }
             if (l == 0 && !dense0) {
                 a.codes = io.fetched_codes ? io.fetched_codes : m.codes;
+                if (!io.fetched_codes) a.shards = m.shards;
                 a.codes_direct = io.fetched_codes ? (io.fetched_centres_only ? 1 : n_g) : 0;
                 a.codes_index = io.fetched_codes ? io.fetched_index : nullptr;
                 a.row0 = m.row0; a.n_local = m.n_local; a.M = m.M; a.dsub = m.dsub; a.centroids = m.centroids;
@@ -445,7 +447,7 @@ size_t gnnlm_sizeof(const char* name) {
 #define GNNLM_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
     GNNLM_SZ(gnnlm_gemm_t) GNNLM_SZ(gnnlm_gather_t) GNNLM_SZ(gnnlm_star_attn_t) GNNLM_SZ(gnnlm_chain_attn_t)
     GNNLM_SZ(gnnlm_adaptive_softmax_t) GNNLM_SZ(gnnlm_knn_interp_t) GNNLM_SZ(gnnlm_hgt_layer_t)
-    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t) GNNLM_SZ(gnnlm_peer_gather_t)
+    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t) GNNLM_SZ(gnnlm_peer_gather_t) GNNLM_SZ(gnnlm_shards_t)
 #undef GNNLM_SZ
     return 0;
 }

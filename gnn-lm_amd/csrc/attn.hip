@@ -746,8 +746,10 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(p.U && p.ids && p.Z, "star_attn: null operand");
     GNNLM_REQUIRE(p.T >= 0 && p.H > 0 && p.kg > 0 && p.D > 0 && p.D % 4 == 0 && p.D <= 1024,
                   "star_attn: need D % 4 == 0 and D <= 1024");
-    GNNLM_REQUIRE((p.codes != nullptr) != (p.X != nullptr), "star_attn: exactly one of codes / X");
-    if (p.codes) {
+    const bool pq = p.codes != nullptr || p.shards != nullptr;
+    GNNLM_REQUIRE(pq != (p.X != nullptr), "star_attn: exactly one of codes (or mapped shards) / X");
+    GNNLM_REQUIRE(!p.shards || (!p.codes_direct && p.n_store > 0), "star_attn: a shard table needs n_store and no fetched codes");
+    if (pq) {
         GNNLM_REQUIRE(p.centroids && p.M > 0 && p.dsub % 4 == 0 && p.M * p.dsub == p.D,
                       "star_attn: PQ source needs centroids and M*dsub == D, dsub % 4 == 0");
     } else {
@@ -761,7 +763,8 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(shmem <= 160 * 1024, "star_attn: kg too large for LDS");
     const int nq = p.D / 4;
     const double rows = (double)p.T * p.kg;
-    if (star_attn_tab_eligible(p) && !getenv("GNNLM_STAR_SWEEP") && !getenv("GNNLM_STAR_GENERIC")) {
+    GNNLM_REQUIRE(!p.shards || star_attn_tab_eligible(p), "star_attn: mapped shards need the table-resident kernel (k_g <= 128, dsub 4 / 8, M % 16 == 0)");
+    if (star_attn_tab_eligible(p) && (p.shards || (!getenv("GNNLM_STAR_SWEEP") && !getenv("GNNLM_STAR_GENERIC")))) {
         // table-resident formulation (star_tab.hip): the default for the PQ source with k_g <= 128
         ProfScope prof(K_STAR, stream, 4.0 * rows * p.H * p.D, rows * (8.0 + p.M) + 8.0 * p.T * p.H * p.D);
         return star_attn_tab(p, stream);

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(GatherParams p) {
         const int c = (int)(s - g * n_g);
         bool local;
         int64_t lrow;
+        const uint8_t* srow = nullptr;           // with mapped shards: the row in its owner's memory
         if (p.direct) {
             lrow = p.in_index ? (int64_t)p.in_index[s] : s;
             local = p.in_valid[s] != 0;
@@ -39,7 +40,12 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(GatherParams p) {
             const int64_t row = centre + delta;
             const bool valid = centre >= 0 && row >= 0 && row < p.n_store;
             lrow = row - p.row0;
-            local = valid && lrow >= 0 && lrow < p.n_local;   // sharded store: caller routes ids
+            if (p.shards) {
+                srow = valid ? shard_row_ptr(p.shards, row, p.M) : nullptr;
+                local = srow != nullptr;
+            } else {
+                local = valid && lrow >= 0 && lrow < p.n_local;   // sharded store: caller routes ids
+            }
         }
         if (lane == 0) {
             if (p.out_valid) p.out_valid[s] = local ? 1 : 0;
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(GatherParams p) {
                 p.out_labels[s] = lab;
             }
         }
-        const uint8_t* crow = p.codes + (local ? lrow : 0) * p.M;
+        const uint8_t* crow = srow ? srow : p.codes + (local ? lrow : 0) * p.M;        // (not dereferenced unless local)
         if (p.out_codes) {
             for (int m = lane; m < p.M; m += 64) p.out_codes[s * p.M + m] = local ? crow[m] : 0;
         }
@@ -334,14 +340,16 @@ int gather_decode(const GatherParams& p, hipStream_t stream) {
     // an empty request (a rank of the sharded exchange that receives no rows) or an empty shard is legal and must
     // not fail on the null pointers torch hands out for empty tensors: its peers are already inside the next collective
     if (p.n_groups == 0) return OK;
-    GNNLM_REQUIRE((p.codes || p.n_local == 0) && (p.direct ? p.in_valid != nullptr : p.ids != nullptr), "gather_decode: null codes/ids");
+    const bool mapped = p.shards != nullptr;    // the code rows come from a set of mapped shards (ABI 4)
+    GNNLM_REQUIRE(!mapped || (!p.direct && !(p.out_labels && p.vals)), "gather_decode: a shard table excludes direct codes and a label table");
+    GNNLM_REQUIRE((mapped || p.codes || p.n_local == 0) && (p.direct ? p.in_valid != nullptr : p.ids != nullptr), "gather_decode: null codes/ids");
     GNNLM_REQUIRE(p.M > 0 && p.dsub > 0 && p.dsub % 4 == 0, "gather_decode: dsub must be a multiple of 4");
     GNNLM_REQUIRE(!p.out_x || (p.centroids && p.ld_x % 4 == 0 && (uintptr_t)p.out_x % 16 == 0),
                   "gather_decode: out_x needs centroids, 16-byte alignment and ld % 4 == 0");
     GNNLM_REQUIRE(p.vals_itemsize == 2 || p.vals_itemsize == 4, "gather_decode: vals must be int16 or int32");
     const int64_t n_slots = p.n_groups * (1 + p.left + p.right);
     if (n_slots == 0) return OK;
-    if (!p.direct && !p.out_x && p.out_codes && p.left == 0 && p.right == 0 && p.M % 16 == 0 &&
+    if (!mapped && !p.direct && !p.out_x && p.out_codes && p.left == 0 && p.right == 0 && p.M % 16 == 0 &&
         (uintptr_t)p.codes % 16 == 0 && (uintptr_t)p.out_codes % 16 == 0) {
         ProfScope prof(K_GATHER, stream, 0.0, (2.0 * p.M + 8.0) * n_slots);
         const int64_t blocks = std::min<int64_t>(cdiv(n_slots * (p.M >> 4), 256), 256 * 16);

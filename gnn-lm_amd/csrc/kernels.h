@@ -45,9 +45,16 @@ int star_attn_tab(const StarAttnParams& p, hipStream_t stream);
 // Neighbour (i, j) takes part in the star softmax iff its id is a row of the store, the row is present on this
 // shard (PQ source read from the store) and the caller's validity byte (exchange / gather_decode) says so: the
 // rule of gather_decode_kernel, so layer-0 star attention and the ntgt states can never disagree.
+// row `row` (>= 0) of a set of mapped shards: pointer to its M bytes, or nullptr if no shard holds it
+__device__ __forceinline__ const uint8_t* shard_row_ptr(const gnnlm_shards_t* sh, int64_t row, int M) {
+    const int g = (int)min((int64_t)sh->n - 1, row / sh->rows_per_rank);
+    const int64_t local = row - sh->row0[g];
+    return local >= 0 && local < sh->rows[g] ? sh->base[g] + local * M : nullptr;
+}
 __device__ __forceinline__ bool star_nb_ok(const StarAttnParams& p, int i, int j, int64_t id) {
     bool ok = id >= 0 && (p.n_store <= 0 || id < p.n_store);
-    if (p.codes && !p.codes_direct) ok = ok && id - p.row0 >= 0 && id - p.row0 < p.n_local;
+    if (p.shards) ok = ok && shard_row_ptr(p.shards, id, p.M) != nullptr;
+    else if (p.codes && !p.codes_direct) ok = ok && id - p.row0 >= 0 && id - p.row0 < p.n_local;
     if (ok && p.nb_valid) ok = p.nb_valid[((int64_t)i * p.kg + j) * p.nb_valid_stride] != 0;
     return ok;
 }
@@ -56,6 +63,11 @@ __device__ __forceinline__ int64_t star_code_row(const StarAttnParams& p, int i,
     if (!p.codes_direct) return id - p.row0;
     const int64_t s = ((int64_t)i * p.kg + j) * p.codes_direct;
     return p.codes_index ? (int64_t)p.codes_index[s] : s;
+}
+// pointer to the M code bytes of a VALID neighbour (i, j) (star_nb_ok): one table, the slots of an exchange, or mapped shards
+__device__ __forceinline__ const uint8_t* star_code_ptr(const StarAttnParams& p, int i, int j, int64_t id) {
+    if (p.shards) return shard_row_ptr(p.shards, id, p.M);
+    return p.codes + star_code_row(p, i, j, id) * p.M;
 }
 int chain_attn(const ChainAttnParams& p, hipStream_t stream);
 

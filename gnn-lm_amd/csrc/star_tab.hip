@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
                 id[r] = (e < n_items && j < kg) ? p.ids[(int64_t)min(tok0 + tt, p.T - 1) * kg + j] : -1;
             }
             if (GNNLM_STAB_CLK) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[0] = STAB_CLK(); }
-            int64_t src[RB];
+            const uint8_t* src[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const int e = e0 + r * NTHREADS + tid;
@@ -156,11 +156,11 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
                 const int i = min(tok0 + tt, p.T - 1);
                 const bool ok = e < n_items && j < kg && star_nb_ok(p, i, j, id[r]);
                 if (e < n_items && part == 0) okf[row] = ok ? 1 : 0;
-                src[r] = ok && !STAB_OFF(16) ? star_code_row(p, i, j, id[r]) * M + 16 * part : -1;
+                src[r] = ok && !STAB_OFF(16) ? star_code_ptr(p, i, j, id[r]) + 16 * part : nullptr;     // (a mapped shard of a peer: the load crosses xGMI)
             }
             uint4 v[RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) v[r] = src[r] >= 0 ? *reinterpret_cast<const uint4*>(p.codes + src[r]) : make_uint4(0, 0, 0, 0);
+            for (int r = 0; r < RB; ++r) v[r] = src[r] ? *reinterpret_cast<const uint4*>(src[r]) : make_uint4(0, 0, 0, 0);
             if (GNNLM_STAB_CLK) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[1] = STAB_CLK(); }
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
 #define STAB_DMA_TAB(c_)                                                                             \
     if (!STAB_OFF(8)) {                                                                              \
         const float* s_ = tsrc + (int64_t)(c_) * TABF;                                               \
-        const unsigned d_ = tab_lds + ((c_) & 1) * (TABF * 4);                                       \
+        const unsigned d_ = __builtin_amdgcn_readfirstlane(tab_lds + ((c_) & 1) * (TABF * 4));       \
         /* the instruction offset counts for the global AND the LDS address: two M0 values and two address registers */ \
         unsigned keep_;                                                                              \
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                            \
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
             usrc = p.U + ((int64_t)min(tok0 + lw, p.T - 1) * H + h0 + min(4 * hh + li_, H - 1 - h0)) * D + 8 * dq_ + (ab ? 4 - lo_ : lo_);
         }
         const unsigned u_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)ubuf) + lw * 1024;
-#define STAB_DMA_U(c_) if (!STAB_OFF(32)) STAB_DMA_ONE(usrc + (c_) * CD, u_lds + ((c_) & 1) * 4096)
+#define STAB_DMA_U(c_) if (!STAB_OFF(32)) STAB_DMA_ONE(usrc + (c_) * CD, __builtin_amdgcn_readfirstlane(u_lds + ((c_) & 1) * 4096))
 #define STAB_LAND() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
         STAB_DMA_TAB(0) STAB_DMA_U(0)
         if (NCH > 1) { STAB_DMA_TAB(1) STAB_DMA_U(1) }
@@ -540,8 +540,8 @@ __global__ __launch_bounds__(NTHREADS) void star_attn_tab_kernel(StarAttnParams 
 }  // namespace
 
 bool star_attn_tab_eligible(const StarAttnParams& p) {
-    return p.codes && p.centroids && p.kg <= KGM && (p.dsub == 4 || p.dsub == 8) && p.M % 16 == 0 && p.D % CD == 0 &&
-           p.M * p.dsub == p.D && (uintptr_t)p.codes % 16 == 0 && (uintptr_t)p.centroids % 16 == 0 &&
+    return (p.codes || p.shards) && p.centroids && p.kg <= KGM && (p.dsub == 4 || p.dsub == 8) && p.M % 16 == 0 && p.D % CD == 0 &&
+           p.M * p.dsub == p.D && (uintptr_t)p.codes % 16 == 0 && (uintptr_t)p.centroids % 16 == 0 && !(p.shards && p.codes_direct) &&
            (uintptr_t)p.U % 16 == 0 && carve(p.M).total <= 160 * 1024;
 }
 

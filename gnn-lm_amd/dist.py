@@ -345,6 +345,14 @@ class PeerMappedFetcher:
     def check(self):
         pass                                                    # nothing can overflow
 
+    def mapped_store(self):
+        """The store with its shard table: handed to the engine, the star-attention / gather kernels read every code row from
+        its owner's memory themselves -- no fetch step at all for the codes (``fetch_codes`` stays for consumers that want a
+        local copy)."""
+        import dataclasses
+        return dataclasses.replace(self.store, shards=[(t, sh.store_row0) for t, sh in zip(self.peers["codes"], self._shards)],
+                                   rows_per_rank=self.shard.per)
+
     def _gather(self, rows, what, row_bytes, out):
         L = self._lib
         d = L.gnnlm_peer_gather_t()

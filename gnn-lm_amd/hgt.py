@@ -38,6 +38,30 @@ class CodeStore:
     vals: Optional[torch.Tensor] = None  # int16/int32 [n_local]
     A: Optional[torch.Tensor] = None     # f32 [M*dsub, d]  OPQ matrix (decode: (x - b) @ A)
     b: Optional[torch.Tensor] = None     # f32 [M*dsub]
+    # Range-sharded store with EVERY shard mapped into this process (dist.PeerMappedFetcher.mapped_store): shard g =
+    # (codes tensor [rows_g, M], first global row it holds); rows_per_rank = ceil(n_store / world).  The kernels then read
+    # a row from its owner's memory directly and `codes` / `row0` only describe the local shard.
+    shards: Optional[list] = None
+    rows_per_rank: int = 0
+
+
+def shards_device_ptr(store):
+    """Device address of the store's gnnlm_shards_t (built once, kept alive on the store); None for a one-table store."""
+    if store is None or not getattr(store, "shards", None):
+        return None
+    t = getattr(store, "_shards_dev", None)
+    if t is None:
+        import ctypes
+        assert len(store.shards) <= 16 and store.rows_per_rank > 0
+        sh = _lib.gnnlm_shards_t()
+        sh.n, sh.rows_per_rank = len(store.shards), store.rows_per_rank
+        for g, (c, r0) in enumerate(store.shards):
+            sh.base[g] = c.data_ptr() if c is not None and c.numel() else None
+            sh.row0[g], sh.rows[g] = r0, (c.shape[0] if c is not None else 0)
+        dev = next(c.device for c, _ in store.shards if c is not None)
+        t = torch.frombuffer(bytearray(ctypes.string_at(ctypes.byref(sh), ctypes.sizeof(sh))), dtype=torch.uint8).to(dev)
+        store._shards_dev = t
+    return t.data_ptr()
 
 
 @dataclass
@@ -228,6 +252,7 @@ class HGT(nn.Module):
         m.codes = store.codes.data_ptr()
         m.vals, m.vals_itemsize = (store.vals.data_ptr(), store.vals.element_size()) if store.vals is not None else (None, 4)
         m.n_store, m.row0, m.n_local = store.n_store, store.row0, store.codes.shape[0]
+        m.shards = shards_device_ptr(store)
 
     def invalidate(self):
         """Drop the prepared (folded) weights, e.g. after swapping parameter tensors by hand."""

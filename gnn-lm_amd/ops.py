@@ -156,9 +156,11 @@ def pq_lookup_direct(codes, centroids):
 
 
 def star_attn(U, ids, codes=None, centroids=None, row0=0, X=None, x_group_stride=1, codes_direct=0, n_store=None,
-              nb_valid=None, nb_valid_stride=1):
+              nb_valid=None, nb_valid_stride=1, shards=None, rows_per_rank=0):
     """n_store: rows of the whole store (ids >= n_store are not neighbours; default: the rows of ``codes``);
-    nb_valid (uint8): validity byte of neighbour (i, j) at [(i*kg + j) * nb_valid_stride]."""
+    nb_valid (uint8): validity byte of neighbour (i, j) at [(i*kg + j) * nb_valid_stride];
+    shards = [(codes_g [rows_g, M], first global row), ...] + rows_per_rank: a range-sharded table whose shards are all
+    mapped into this process (instead of ``codes``; needs ``n_store``)."""
     _dev(U, ids, codes, centroids, X, nb_valid)
     _f32(U, centroids, X)
     _dtype(ids, torch.int64, "ids"), _dtype(codes, torch.uint8, "codes"), _dtype(nb_valid, torch.uint8, "nb_valid")
@@ -169,7 +171,13 @@ def star_attn(U, ids, codes=None, centroids=None, row0=0, X=None, x_group_stride
     a = _lib.gnnlm_star_attn_t()
     a.U, a.ids = U.data_ptr(), ids.data_ptr()
     a.T, a.H, a.D, a.kg = T, H, D, kg
-    if codes is not None:
+    if shards:
+        from .hgt import CodeStore, shards_device_ptr
+        keep = CodeStore(codes=None, centroids=centroids, n_store=n_store, shards=shards, rows_per_rank=rows_per_rank)
+        a.shards = shards_device_ptr(keep)
+        a.M, a.dsub = centroids.shape[0], centroids.shape[2]
+        a.centroids = centroids.data_ptr()
+    elif codes is not None:
         a.codes, a.row0, a.n_local = codes.data_ptr(), row0, codes.shape[0]
         a.M, a.dsub = centroids.shape[0], centroids.shape[2]
         a.centroids = centroids.data_ptr()
@@ -183,6 +191,8 @@ def star_attn(U, ids, codes=None, centroids=None, row0=0, X=None, x_group_stride
     if nb_valid is not None:
         a.nb_valid, a.nb_valid_stride = nb_valid.data_ptr(), nb_valid_stride
     call_desc("gnnlm_star_attn", a)
+    if shards:
+        Z._gnnlm_keep = keep                                    # the device copy of the shard table outlives the queued launch
     return Z, has_nb
 
 

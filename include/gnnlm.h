@@ -89,6 +89,18 @@ int gnnlm_lse_reduce(const float* part, int32_t n_parts, int64_t rows, const int
  * A slot is valid iff ids[g] != -1 and 0 <= row < n_store (the bound of :384) and the
  * row lies in the shard [row0, row0+n_local).
  * ---------------------------------------------------------------------------------------------- */
+/* A range-sharded code table whose shards are ALL mapped into this process (the local one, the peers' through HIP IPC:
+ * gnnlm_amd.dist.PeerMappedFetcher): the kernels that read code rows then take row r from shard min(n - 1, r /
+ * rows_per_rank) -- over xGMI straight from the owner's HBM, no exchange and no copy.  The table lives in DEVICE memory;
+ * the descriptors carry a pointer to it (NULL: not used, codes / row0 / n_local describe one table) -- by value it would
+ * add 400 B of kernel arguments to every launch.  base[g] holds the rows [row0[g], row0[g] + rows[g]) (rank g's range plus its halo). */
+typedef struct gnnlm_shards {
+    int32_t n, reserved;
+    int64_t rows_per_rank;
+    const uint8_t* base[16];
+    int64_t row0[16], rows[16];
+} gnnlm_shards_t;
+
 typedef struct gnnlm_gather {
     const uint8_t* codes;      /* [n_local, M] */
     const void* vals;          /* [n_local] int16 / int32 (optional) */
@@ -106,6 +118,7 @@ typedef struct gnnlm_gather {
     int32_t direct;            /* 1: `codes` is an already-fetched [n_slots, M] buffer (slot s = row s), */
     const uint8_t* in_valid;   /*    validity comes from in_valid[n_slots]; ids is ignored */
     const int32_t* in_index;   /*    optional with direct: slot s reads row in_index[s] of `codes` */
+    const gnnlm_shards_t* shards;  /* ABI 4 (DEVICE pointer): replaces codes / row0 / n_local for the code rows (not with direct, not for vals) */
 } gnnlm_gather_t;
 int gnnlm_pq_gather_decode(const gnnlm_gather_t* desc, void* stream);
 
@@ -141,6 +154,7 @@ typedef struct gnnlm_star_attn {
      * always agree.  The reference raises IndexError for rows >= n_store (token_block_dataset.py:370). */
     int64_t n_store;
     const uint8_t* nb_valid;  int64_t nb_valid_stride;
+    const gnnlm_shards_t* shards;  /* ABI 4 (DEVICE pointer): replaces codes / row0 / n_local (PQ source, not with codes_direct) */
 } gnnlm_star_attn_t;
 int gnnlm_star_attn(const gnnlm_star_attn_t* desc, void* stream);
 
@@ -294,6 +308,7 @@ typedef struct gnnlm_hgt {
     int64_t n_store, row0, n_local;
     const gnnlm_hgt_layer_t* layers;   /* HOST array [n_layers] */
     int32_t gemm_precision;    /* precision of the GEMMs (see gnnlm_gemm_t.precision); 0 = exact f32 */
+    const gnnlm_shards_t* shards;  /* ABI 4 (DEVICE pointer): the code table is this set of mapped shards instead of `codes` */
 } gnnlm_hgt_t;
 
 typedef struct gnnlm_hgt_io {

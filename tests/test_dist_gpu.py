@@ -70,7 +70,7 @@ def test_exchange_rccl_two_ranks():
                         "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "tools", "exchange_check.py")],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("exchange path == direct path") >= 9
+    assert r.stdout.count("exchange path == direct path") >= 9 and r.stdout.count("mapped shards == direct path") >= 3
 
 
 def test_exchange_over_rccl_single_rank():
@@ -79,6 +79,7 @@ def test_exchange_over_rccl_single_rank():
                        text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("exchange path == direct path") == 9          # L = 1; L = 2 slot by slot and halo layout; x exact, padded, peer-mapped
+    assert r.stdout.count("mapped shards == direct path") == 3           # ... and the kernels reading the shards themselves
 
 
 def test_exchange_two_ranks_on_one_gpu():
@@ -92,3 +93,4 @@ def test_exchange_two_ranks_on_one_gpu():
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("exchange path == direct path") == 9 and "ranks 2" in r.stdout
+    assert r.stdout.count("mapped shards == direct path") == 3

@@ -525,3 +525,34 @@ def test_causal_attn_other_shapes_refused(ops, dev):
     x = torch.randn(64, 64, device=dev)
     with pytest.raises(GnnlmError):
         ops.causal_attn(x, x, x, 1, 64, 2)
+
+
+def test_star_attn_mapped_shards(ops, dev):
+    """gnnlm_star_attn_t.shards (ABI 4): the code table as a set of mapped shards (here three tensors of one device, with
+    halo rows, as dist.PeerMappedFetcher maps its peers' memory) == the same table as one tensor, bit for bit; a row no
+    shard holds is no neighbour."""
+    rs = np.random.RandomState(21)
+    T, H, M, dsub, kg, N = 37, 8, 128, 8, 128, 3001
+    codes = torch.from_numpy(rs.randint(0, 256, size=(N, M)).astype(np.uint8)).to(dev)
+    cen = torch.from_numpy(rs.randn(M, 256, dsub).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(T, H, M * dsub) / 32).astype(np.float32)).to(dev)
+    ids = rs.randint(0, N, size=(T, kg)).astype(np.int64)
+    ids[0, :5] = [-1, 0, N - 1, 1000, 1001]
+    ids[1] = -1
+    ids = torch.from_numpy(ids).to(dev)
+    per = -(-N // 3)
+    shards = []
+    for g in range(3):
+        lo, hi = max(0, g * per - 2), min(N, (g + 1) * per + 2)
+        shards.append((codes[lo:hi].clone(), lo))
+    Z0, h0 = ops.star_attn(U, ids, codes=codes, centroids=cen)
+    Z1, h1 = ops.star_attn(U, ids, centroids=cen, n_store=N, shards=shards, rows_per_rank=per)
+    assert torch.equal(Z0, Z1) and torch.equal(h0, h1)
+    holes = [(shards[0][0], 0), (shards[1][0][:10], shards[1][1]), (shards[2][0], shards[2][1])]      # shard 1 lost most of its rows
+    Z2, _ = ops.star_attn(U, ids, centroids=cen, n_store=N, shards=holes, rows_per_rank=per)
+    own = torch.clamp(torch.div(ids.clamp(min=0), per, rounding_mode="floor"), max=2)      # a row is looked up in ITS OWNER's shard only
+    lo = torch.tensor([h[1] for h in holes], device=dev)[own]
+    hi = lo + torch.tensor([h[0].shape[0] for h in holes], device=dev)[own]
+    keep = (ids >= lo) & (ids < hi)
+    Z3, _ = ops.star_attn(U, torch.where(keep, ids, torch.full_like(ids, -1)), codes=codes, centroids=cen)
+    assert torch.equal(Z2, Z3)

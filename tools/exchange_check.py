@@ -52,4 +52,16 @@ for L in (1, 2):
             assert torch.equal(out["logp"], ref["logp"]) and torch.equal(out["recall"], ref["recall"]), (L, mode, halo)
             if rank == 0:
                 print("exchange path == direct path, L =", L, mode, "halo" if halo[0] else "slots", "ranks", world)
+        # no fetch step at all: the engine's kernels read every code row from its owner's (mapped) shard themselves
+        from gnnlm_amd.engine import GnnLmEngine
+        f = PeerMappedFetcher(part, hs, share_vals=True)
+        eng_m = GnnLmEngine(eng.hgt, eng.asm, f.mapped_store(), eng.left, eng.right)
+        b.fetched_codes = b.fetched_valid = b.fetched_index = None
+        b.fetched_centres_only = False
+        b.knn_vals = f.fetch_knn_vals(b.knn_ids)
+        out = eng_m.score(b, 0.25, 0.01)
+        torch.cuda.synchronize()
+        assert torch.equal(out["logp"], ref["logp"]) and torch.equal(out["recall"], ref["recall"]), (L, "mapped", halo)
+        if rank == 0:
+            print("mapped shards == direct path, L =", L, "halo" if halo[0] else "slots", "ranks", world)
 dist.destroy_process_group()
