@@ -47,7 +47,10 @@ int star_attn_tab(const StarAttnParams& p, hipStream_t stream);
 // rule of gather_decode_kernel, so layer-0 star attention and the ntgt states can never disagree.
 // row `row` (>= 0) of a set of mapped shards: pointer to its M bytes, or nullptr if no shard holds it
 __device__ __forceinline__ const uint8_t* shard_row_ptr(const gnnlm_shards_t* sh, int64_t row, int M) {
-    const int g = (int)min((int64_t)sh->n - 1, row / sh->rows_per_rank);
+    const int64_t per = sh->rows_per_rank;
+    // (a 64-bit division costs ~10x a 32-bit one; the stores of this path have fewer than 2^32 rows)
+    const int64_t q = ((uint64_t)(row | per) >> 32) == 0 ? (int64_t)((uint32_t)row / (uint32_t)per) : row / per;
+    const int g = (int)min((int64_t)sh->n - 1, q);
     const int64_t local = row - sh->row0[g];
     return local >= 0 && local < sh->rows[g] ? sh->base[g] + local * M : nullptr;
 }
