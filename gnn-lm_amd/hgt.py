@@ -49,8 +49,10 @@ def shards_device_ptr(store):
     """Device address of the store's gnnlm_shards_t (built once, kept alive on the store); None for a one-table store."""
     if store is None or not getattr(store, "shards", None):
         return None
+    key = (store.rows_per_rank,) + tuple((c.data_ptr() if c is not None else 0, c.shape[0] if c is not None else 0, r0)
+                                         for c, r0 in store.shards)
     t = getattr(store, "_shards_dev", None)
-    if t is None:
+    if t is None or getattr(store, "_shards_key", None) != key:          # (re)built when a shard tensor was swapped
         import ctypes
         assert len(store.shards) <= 16 and store.rows_per_rank > 0
         sh = _lib.gnnlm_shards_t()
@@ -60,7 +62,7 @@ def shards_device_ptr(store):
             sh.row0[g], sh.rows[g] = r0, (c.shape[0] if c is not None else 0)
         dev = next(c.device for c, _ in store.shards if c is not None)
         t = torch.frombuffer(bytearray(ctypes.string_at(ctypes.byref(sh), ctypes.sizeof(sh))), dtype=torch.uint8).to(dev)
-        store._shards_dev = t
+        store._shards_dev, store._shards_key = t, key
     return t.data_ptr()
 
 
