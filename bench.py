@@ -424,6 +424,8 @@ def main():
     # GNNLM_BENCH_BACKEND=gloo GNNLM_BENCH_DEVICE=0 (tests only): several ranks on ONE GPU, collectives staged through the host --
     # the whole sharded code path (halo shards, fetch streams, reductions) with a real second rank on a one-GPU box
     backend = os.environ.get("GNNLM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        os.environ["GNNLM_TEST_HOST_STAGED"] = "1"
     local_rank = int(os.environ.get("GNNLM_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"

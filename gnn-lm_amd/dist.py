@@ -75,6 +75,10 @@ def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits
     """all_to_all_single; a process group that cannot move device memory (gloo: used to run TWO ranks on ONE GPU in the
     tests -- RCCL refuses two ranks per device) is served through pinned host copies of the same buffers."""
     if inp.is_cuda and dist.get_backend(group) == "gloo":
+        import os
+        if os.environ.get("GNNLM_TEST_HOST_STAGED") != "1":          # never silently: the product's transport is RCCL
+            raise RuntimeError("sharded exchange: device tensors over a gloo process group (host-staged copies) are a test "
+                               "transport only -- use backend 'nccl' (RCCL), or set GNNLM_TEST_HOST_STAGED=1 in a test")
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
         out.copy_(o)

@@ -11,6 +11,8 @@ rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE",
 # GNNLM_CHECK_BACKEND=gloo GNNLM_CHECK_DEVICE=0: several ranks on ONE GPU (the collectives staged through the host): the routing,
 # the bucketing kernels, the owner-side gather and the consumers with world > 1 on a one-GPU box
 backend = os.environ.get("GNNLM_CHECK_BACKEND", "nccl")
+if backend != "nccl":
+    os.environ["GNNLM_TEST_HOST_STAGED"] = "1"
 dev = torch.device("cuda", int(os.environ.get("GNNLM_CHECK_DEVICE", os.environ.get("LOCAL_RANK", "0")))); torch.cuda.set_device(dev)
 if backend == "nccl":
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
