@@ -113,6 +113,43 @@ def test_full_store_star_attn(dev, full_store):
     assert np.array_equal(has.cpu().numpy(), ok.any(1).astype(np.float32))
 
 
+def test_full_store_mapped_shards(dev, full_store):
+    """The 103 M-row table as EIGHT mapped shards (views of the one tensor with two halo rows each side, i.e. the pointer
+    table dist.PeerMappedFetcher builds from its peers' memory): star attention and the slot decode through the shard
+    table reproduce the one-table results bit for bit -- shard bases beyond 4 GiB, rows at both ends of every shard."""
+    from gnnlm_amd import _lib, ops
+    from gnnlm_amd.dist import Shard
+    from gnnlm_amd.hgt import CodeStore, shards_device_ptr
+    rs = np.random.RandomState(14)
+    W = 8
+    shs = [Shard(N_FULL, W, g, halo_left=2, halo_right=2) for g in range(W)]
+    views = [(full_store["codes"][s_.store_row0:s_.store_row0 + s_.store_rows], s_.store_row0) for s_ in shs]
+    edges = np.array([r for s_ in shs for r in (s_.row0 - 1, s_.row0, s_.row0 + 1, s_.row0 + s_.n_local - 1) if 0 <= r < N_FULL])
+    T, kg = 64, 128
+    ids = np.concatenate([edges, spread_rows(rs, T * kg - len(edges))]).astype(np.int64).reshape(T, kg)
+    ids[0, 5], ids[1, :], ids[2, 7] = -1, -1, N_FULL + 3
+    cen = torch.from_numpy(full_store["cen"]).to(dev)
+    U = torch.from_numpy((rs.randn(T, H, D) / np.sqrt(D)).astype(np.float32)).to(dev)
+    idt = torch.from_numpy(ids).to(dev)
+    Z0, h0 = ops.star_attn(U, idt, codes=full_store["codes"], centroids=cen)
+    Z1, h1 = ops.star_attn(U, idt, centroids=cen, n_store=N_FULL, shards=views, rows_per_rank=shs[0].per)
+    assert torch.equal(Z0, Z1) and torch.equal(h0, h1)
+    # slot decode (the L > 1 path) through the shard table, straight on the C ABI
+    st = CodeStore(codes=None, centroids=cen, n_store=N_FULL, shards=views, rows_per_rank=shs[0].per)
+    cids = torch.from_numpy(ids.reshape(-1)[:4096].copy()).to(dev)
+    ref = ops.pq_gather_decode(full_store["codes"], cen, cids, 2, 2, want_codes=True)
+    g = _lib.gnnlm_gather_t()
+    n_slots = cids.numel() * 5
+    x = torch.empty(n_slots, D, device=dev)
+    oc = torch.empty(n_slots, M, device=dev, dtype=torch.uint8)
+    ov = torch.empty(n_slots, device=dev, dtype=torch.uint8)
+    g.shards, g.n_store, g.M, g.dsub, g.centroids = shards_device_ptr(st), N_FULL, M, DSUB, cen.data_ptr()
+    g.ids, g.n_groups, g.left, g.right, g.vals_itemsize = cids.data_ptr(), cids.numel(), 2, 2, 4
+    g.out_x, g.ld_x, g.out_codes, g.out_valid = x.data_ptr(), D, oc.data_ptr(), ov.data_ptr()
+    _lib.call_desc("gnnlm_pq_gather_decode", g)
+    assert torch.equal(x, ref["x"]) and torch.equal(oc, ref["codes"]) and torch.equal(ov, ref["valid"])
+
+
 def test_full_store_knn_interp(dev, full_store):
     from gnnlm_amd import ops
     rs = np.random.RandomState(13)
