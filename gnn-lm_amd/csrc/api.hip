@@ -106,6 +106,7 @@ struct HgtBufs {
     // ntgt side
     float *hn[2], *nq, *nk, *nv;
     uint8_t* valid;
+    int32_t *rows_out, *rows_kv;     // slot subsets of the elided ntgt updates
     int64_t Tp;
 };
 
@@ -135,9 +136,12 @@ void carve_hgt(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, Carver& c, HgtBuf
         b.nk = c.take<float>(S * dmax);
         b.nv = c.take<float>(S * dmax);
         b.valid = c.take<uint8_t>(S);
+        b.rows_out = c.take<int32_t>(S);
+        b.rows_kv = c.take<int32_t>(S);
     } else {
         b.hn[0] = b.hn[1] = b.nq = b.nk = b.nv = nullptr;
         b.valid = nullptr;
+        b.rows_out = b.rows_kv = nullptr;
     }
 }
 
@@ -148,6 +152,18 @@ int linear(const float* A, int64_t lda, const float* W, const float* bias, float
     g.bias = bias; g.bias_mode = bias ? 1 : 0;
     g.R = R; g.ldr = N; g.alpha = alpha;
     g.M = (int)M; g.N = N; g.K = K;
+    return gemm_nt(g, s);
+}
+
+// the same on a subset of rows: logical row r reads A row rows[r] and writes C row rows[r] (both in their full layouts)
+int linear_rows(const float* A, int64_t lda, const float* W, const float* bias, float* C, int64_t ldc, const int32_t* rows,
+                int64_t n_rows, int N, int K, float alpha, hipStream_t s) {
+    GemmParams g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.bias_mode = bias ? 1 : 0;
+    g.alpha = alpha;
+    g.a_rows = rows; g.c_rows = rows;
+    g.M = (int)n_rows; g.N = N; g.K = K;
     return gemm_nt(g, s);
 }
 
@@ -328,17 +344,47 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         // ---- ntgt update (only when a later layer -- or the caller -- consumes it)
         if (ntgt && (!last || io.out_ntgt)) {
             GNNLM_REQUIRE(w.wq_n && w.wk_n && w.wv_n && w.wa_n && w.ln_g_n && w.ln_b_n, "hgt: layer has null ntgt weights");
-            TRY(linear(hn_cur, ld_hn, w.wq_n, w.bq_n, b.nq, S, d, d, nullptr, 1.f, s));
-            TRY(linear(hn_cur, ld_hn, w.wk_n, w.bk_n, b.nk, S, d, d, nullptr, 1.f, s));
-            TRY(linear(hn_cur, ld_hn, w.wv_n, w.bv_n, b.nv, S, d, d, nullptr, 1.f, s));
-            ChainAttnParams ca{};
-            ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
-            ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
-            ca.out = b.nq; ca.ldo = d;      // in place over Q: a (group, head) task loads before it stores
-            TRY(chain_attn(ca, s));
-            TRY(linear(b.nq, d, w.wa_n, w.ba_n, b.nk, S, d, d, nullptr, 1.f, s));
+            // Only what a later layer reads is computed (outputs identical to the full update): the last layer's star edges
+            // read the CENTRE slot of each group, and a slot's update depends on its path neighbours at distance 1
+            // (build_ntgt_edges(context=1)) -- so layer l has to deliver the slots within r = n_layers - 2 - l positions of
+            // the centre, from K / V of the slots within r + 1.  L = 3, l = r = 2: layer 0 writes 3 of 5 slots (Q, a_linear,
+            // LayerNorm on 3/5 of the rows), layer 1 the centre only (Q, a_linear on 1/5, K and V on 3/5): 3.2 of the 8
+            // 655360 x 1024 x 1024 GEMMs of the two updates go away.  With out_ntgt (API parity, tests) everything is computed.
+            const int rad = io.out_ntgt ? n_g : m.n_layers - 2 - l;
+            const bool all_slots = rad >= std::max(m.left, m.right);
             float* hn_out = (last && io.out_ntgt) ? io.out_ntgt : (hn_cur == b.hn[0] ? b.hn[1] : b.hn[0]);
-            TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, S, d, m.ln_eps, valid, s, hn_cur, ld_hn));
+            if (all_slots) {
+                TRY(linear(hn_cur, ld_hn, w.wq_n, w.bq_n, b.nq, S, d, d, nullptr, 1.f, s));
+                TRY(linear(hn_cur, ld_hn, w.wk_n, w.bk_n, b.nk, S, d, d, nullptr, 1.f, s));
+                TRY(linear(hn_cur, ld_hn, w.wv_n, w.bv_n, b.nv, S, d, d, nullptr, 1.f, s));
+                ChainAttnParams ca{};
+                ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
+                ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
+                ca.out = b.nq; ca.ldo = d;      // in place over Q: a (group, head) task loads before it stores
+                TRY(chain_attn(ca, s));
+                TRY(linear(b.nq, d, w.wa_n, w.ba_n, b.nk, S, d, d, nullptr, 1.f, s));
+                TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, S, d, m.ln_eps, valid, s, hn_cur, ld_hn));
+            } else {
+                // slot of the position `o` relative to the centre: centre first, then o - left .. o - 1, then o + 1 .. o + right
+                auto slot = [&](int o) { return o == 0 ? 0 : (o < 0 ? m.left + 1 + o : m.left + o); };
+                int sel_out[8], sel_kv[8], n_out = 0, n_kv = 0;
+                for (int o = -std::min(rad, m.left); o <= std::min(rad, m.right); ++o) sel_out[n_out++] = slot(o);
+                for (int o = -std::min(rad + 1, m.left); o <= std::min(rad + 1, m.right); ++o) sel_kv[n_kv++] = slot(o);
+                TRY(group_rows(b.rows_out, G, n_g, sel_out, n_out, s));
+                TRY(group_rows(b.rows_kv, G, n_g, sel_kv, n_kv, s));
+                const int64_t R_out = G * n_out, R_kv = G * n_kv;
+                TRY(linear_rows(hn_cur, ld_hn, w.wq_n, w.bq_n, b.nq, d, b.rows_out, R_out, d, d, 1.f, s));
+                TRY(linear_rows(hn_cur, ld_hn, w.wk_n, w.bk_n, b.nk, d, b.rows_kv, R_kv, d, d, 1.f, s));
+                TRY(linear_rows(hn_cur, ld_hn, w.wv_n, w.bv_n, b.nv, d, b.rows_kv, R_kv, d, d, 1.f, s));
+                ChainAttnParams ca{};
+                ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
+                ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
+                ca.out = b.nq; ca.ldo = d;
+                ca.radius_p1 = rad + 1;
+                TRY(chain_attn(ca, s));
+                TRY(linear_rows(b.nq, d, w.wa_n, w.ba_n, b.nk, d, b.rows_out, R_out, d, d, 1.f, s));
+                TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, R_out, d, m.ln_eps, valid, s, hn_cur, ld_hn, b.rows_out));
+            }
             hn_cur = hn_out;
             ld_hn = d;
         }

@@ -491,24 +491,29 @@ __global__ __launch_bounds__(256) void chain_attn_kernel(ChainAttnParams p) {
     const int dk = p.dk;
     const float scale = p.scale ? p.scale[h] : 1.f;
 
+    // radius_p1 = r + 1 > 0: only the positions within r of the centre are destinations (a later layer reads nothing else);
+    // their sources lie within r + 1, and only those rows of Q / K / V exist
+    const int rad = p.radius_p1 > 0 ? p.radius_p1 - 1 : MAX_NG;
     float q[MAX_NG][MAX_EPT], k[MAX_NG][MAX_EPT], v[MAX_NG][MAX_EPT];
-    bool ok[MAX_NG];
+    bool ok[MAX_NG], dst[MAX_NG];
     int64_t slot_of[MAX_NG];
 #pragma unroll
     for (int pos = 0; pos < MAX_NG; ++pos) {
-        ok[pos] = false;
+        ok[pos] = dst[pos] = false;
         slot_of[pos] = 0;
         if (pos < n_g) {
             const int c = pos < p.left ? pos + 1 : (pos == p.left ? 0 : pos);
             const int64_t s = g * n_g + c;
+            const int dist = pos < p.left ? p.left - pos : pos - p.left;
             slot_of[pos] = s;
-            ok[pos] = p.valid[s] != 0;
+            dst[pos] = dist <= rad;
+            ok[pos] = dist <= rad + 1 && p.valid[s] != 0;
 #pragma unroll
             for (int t = 0; t < MAX_EPT; ++t) {
                 const int e = lane + 64 * t;
                 const bool in = ok[pos] && e < dk;
                 const int64_t off = s * p.ld + h * dk + (in ? e : 0);
-                q[pos][t] = in ? p.Q[off] : 0.f;
+                q[pos][t] = in && dst[pos] ? p.Q[off] : 0.f;
                 k[pos][t] = in ? p.K[off] : 0.f;
                 v[pos][t] = in ? p.V[off] : 0.f;
             }
@@ -517,6 +522,7 @@ __global__ __launch_bounds__(256) void chain_attn_kernel(ChainAttnParams p) {
 #pragma unroll
     for (int pos = 0; pos < MAX_NG; ++pos) {
         if (pos >= n_g) break;
+        if (!dst[pos]) continue;
         float sc[3];
         bool has[3];
 #pragma unroll

@@ -85,7 +85,10 @@ int causal_attn_fused(const float* Q, const float* K, const float* V, int64_t ld
 // out[r,:] = LayerNorm(x[r,:]) * gamma + beta ; optional row validity (invalid rows -> 0)
 int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo,
               int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream,
-              const float* residual = nullptr, int64_t ldr = 0);     // out = LN(x + residual)
+              const float* residual = nullptr, int64_t ldr = 0,      // out = LN(x + residual)
+              const int32_t* rows_idx = nullptr);                    // only the rows rows_idx[0..rows) (of x, residual, out, valid)
+// idx[g * n_sel + j] = g * n_g + sel[j]
+int group_rows(int32_t* idx, int64_t n_groups, int n_g, const int* sel, int n_sel, hipStream_t stream);
 
 // out = 0.5 * (a + b)
 int mean2(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);

@@ -15,10 +15,12 @@ namespace {
 template <bool REGS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t ldx, const float* residual, int64_t ldr,
                                                         const float* gamma, const float* beta, float* out, int64_t ldo,
-                                                        int64_t rows, int d, float eps, const uint8_t* valid) {
+                                                        int64_t rows, int d, float eps, const uint8_t* valid,
+                                                        const int32_t* rows_idx) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t r_ = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r_ >= rows) return;
+    const int64_t row = rows_idx ? (int64_t)rows_idx[r_] : r_;          // a subset of the rows of x / residual / out / valid
     const float* xr = x + row * ldx;
     const float* rr = residual ? residual + row * ldr : nullptr;
     float* orow = out + row * ldo;
@@ -329,16 +331,35 @@ __global__ __launch_bounds__(1024) void masked_sum_f64_kernel(const float* x, co
 
 }  // namespace
 
+// idx[g * n_sel + j] = g * n_g + sel[j]: the rows of the slots `sel` of every group
+struct SlotSel { int c[8]; };
+__global__ __launch_bounds__(256) void group_rows_kernel(int32_t* idx, int64_t n_groups, int n_g, SlotSel sel, int n_sel) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_groups * n_sel) return;
+    const int64_t g = e / n_sel;
+    idx[e] = (int32_t)(g * n_g + sel.c[(int)(e - g * n_sel)]);
+}
+int group_rows(int32_t* idx, int64_t n_groups, int n_g, const int* sel, int n_sel, hipStream_t stream) {
+    GNNLM_REQUIRE(idx && n_sel > 0 && n_sel <= 8 && n_groups * n_g < (1ll << 31), "group_rows: bad arguments");
+    if (n_groups == 0) return OK;
+    SlotSel s{};
+    for (int j = 0; j < n_sel; ++j) s.c[j] = sel[j];
+    hipLaunchKernelGGL(group_rows_kernel, dim3((unsigned)cdiv(n_groups * n_sel, 256)), dim3(256), 0, stream, idx, n_groups, n_g, s, n_sel);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
 int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo,
-              int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream, const float* residual, int64_t ldr) {
+              int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream, const float* residual, int64_t ldr,
+              const int32_t* rows_idx) {
     GNNLM_REQUIRE(x && gamma && beta && out && d > 0, "layernorm: bad arguments");
     if (rows == 0) return OK;
     ProfScope prof(K_LAYERNORM, stream, 0.0, (residual ? 12.0 : 8.0) * rows * d);
     const bool a16 = ((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)residual) % 16 == 0;
     const bool regs = d <= 1024 && d % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (!residual || ldr % 4 == 0) && a16;
     const dim3 grid((unsigned)cdiv(rows, 4)), block(256);
-    if (regs) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, stream, x, ldx, residual, ldr, gamma, beta, out, ldo, rows, d, eps, valid);
-    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, stream, x, ldx, residual, ldr, gamma, beta, out, ldo, rows, d, eps, valid);
+    if (regs) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, stream, x, ldx, residual, ldr, gamma, beta, out, ldo, rows, d, eps, valid, rows_idx);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, stream, x, ldx, residual, ldr, gamma, beta, out, ldo, rows, d, eps, valid, rows_idx);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

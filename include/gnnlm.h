@@ -167,6 +167,8 @@ typedef struct gnnlm_chain_attn {
     int64_t n_groups;  int32_t left, right, H, dk;
     const float* scale;        /* optional [H]; NULL = 1 (relation_pri/sqrt(dk) folded into K) */
     float* out;  int64_t ldo;
+    int32_t radius_p1;         /* ABI 4.  0: every slot is computed; r + 1 > 0: only the slots within r positions of the centre
+                                  are (Q is read for them, K / V up to r + 1 positions away; the other rows of `out` stay untouched) */
 } gnnlm_chain_attn_t;
 int gnnlm_chain_attn(const gnnlm_chain_attn_t* desc, void* stream);
 
