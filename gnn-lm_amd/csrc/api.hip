@@ -205,6 +205,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
     const int64_t Tp = b.Tp;
 
     const float* hn_cur = nullptr;
+    bool fold0 = false;                                  // layer 0 projects the decoded rows (b.hn[1]) with rotation-folded weights
     int64_t ld_hn = d;                                   // row stride of hn_cur (the caller's buffer in the dense0 case)
     const uint8_t* valid = nullptr;
     if (dense0) {
@@ -225,7 +226,14 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         g.M = m.M; g.dsub = m.dsub; g.centroids = m.centroids;
         g.ids = io.ids; g.n_groups = G; g.left = m.left; g.right = m.right;
         g.out_valid = b.valid;
-        if (m.opq_at) {
+        const gnnlm_hgt_layer_t& w0 = m.layers[0];
+        fold0 = m.opq_at && w0.wq_n0 && w0.bq_n0 && w0.wk_n0 && w0.bk_n0 && w0.wv_n0 && w0.bv_n0;
+        if (fold0) {
+            // layer 0's ntgt projections take the decoded rows (rotation folded into their weights); the rotation itself is
+            // computed inside the layer, for the rows whose residual is needed only
+            g.out_x = b.hn[1]; g.ld_x = dpq;
+            TRY(gather_decode(g, s));
+        } else if (m.opq_at) {
             g.out_x = b.nq; g.ld_x = dpq;
             TRY(gather_decode(g, s));
             TRY(linear(b.nq, dpq, m.opq_at, m.opq_nba, b.hn[0], S, d, dpq, nullptr, 1.f, s));
@@ -353,10 +361,18 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             const int rad = io.out_ntgt ? n_g : m.n_layers - 2 - l;
             const bool all_slots = rad >= std::max(m.left, m.right);
             float* hn_out = (last && io.out_ntgt) ? io.out_ntgt : (hn_cur == b.hn[0] ? b.hn[1] : b.hn[0]);
+            // projection inputs: the layer's ntgt states, or (layer 0 with folded weights) the decoded rows
+            const bool f0 = l == 0 && fold0;
+            const float* pin = f0 ? b.hn[1] : hn_cur;
+            const int64_t ld_pin = f0 ? dpq : ld_hn;
+            const int kin = f0 ? dpq : d;
+            const float *Wq = f0 ? w.wq_n0 : w.wq_n, *Bq = f0 ? w.bq_n0 : w.bq_n, *Wk = f0 ? w.wk_n0 : w.wk_n,
+                        *Bk = f0 ? w.bk_n0 : w.bk_n, *Wv = f0 ? w.wv_n0 : w.wv_n, *Bv = f0 ? w.bv_n0 : w.bv_n;
             if (all_slots) {
-                TRY(linear(hn_cur, ld_hn, w.wq_n, w.bq_n, b.nq, S, d, d, nullptr, 1.f, s));
-                TRY(linear(hn_cur, ld_hn, w.wk_n, w.bk_n, b.nk, S, d, d, nullptr, 1.f, s));
-                TRY(linear(hn_cur, ld_hn, w.wv_n, w.bv_n, b.nv, S, d, d, nullptr, 1.f, s));
+                if (f0) TRY(linear(b.hn[1], dpq, m.opq_at, m.opq_nba, b.hn[0], S, d, dpq, nullptr, 1.f, s));      // residual of every row
+                TRY(linear(pin, ld_pin, Wq, Bq, b.nq, S, d, kin, nullptr, 1.f, s));
+                TRY(linear(pin, ld_pin, Wk, Bk, b.nk, S, d, kin, nullptr, 1.f, s));
+                TRY(linear(pin, ld_pin, Wv, Bv, b.nv, S, d, kin, nullptr, 1.f, s));
                 ChainAttnParams ca{};
                 ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
                 ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
@@ -373,9 +389,10 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
                 TRY(group_rows(b.rows_out, G, n_g, sel_out, n_out, s));
                 TRY(group_rows(b.rows_kv, G, n_g, sel_kv, n_kv, s));
                 const int64_t R_out = G * n_out, R_kv = G * n_kv;
-                TRY(linear_rows(hn_cur, ld_hn, w.wq_n, w.bq_n, b.nq, d, b.rows_out, R_out, d, d, 1.f, s));
-                TRY(linear_rows(hn_cur, ld_hn, w.wk_n, w.bk_n, b.nk, d, b.rows_kv, R_kv, d, d, 1.f, s));
-                TRY(linear_rows(hn_cur, ld_hn, w.wv_n, w.bv_n, b.nv, d, b.rows_kv, R_kv, d, d, 1.f, s));
+                if (f0) TRY(linear_rows(b.hn[1], dpq, m.opq_at, m.opq_nba, b.hn[0], d, b.rows_out, R_out, d, dpq, 1.f, s));   // residual rows only
+                TRY(linear_rows(pin, ld_pin, Wq, Bq, b.nq, d, b.rows_out, R_out, d, kin, 1.f, s));
+                TRY(linear_rows(pin, ld_pin, Wk, Bk, b.nk, d, b.rows_kv, R_kv, d, kin, 1.f, s));
+                TRY(linear_rows(pin, ld_pin, Wv, Bv, b.nv, d, b.rows_kv, R_kv, d, kin, 1.f, s));
                 ChainAttnParams ca{};
                 ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
                 ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;

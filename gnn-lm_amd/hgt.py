@@ -165,6 +165,12 @@ def prepare_hgt_weights(sd: Dict[str, torch.Tensor], n_layers: int, n_heads: int
                 Ks, Vs = pre @ Ks, pre @ Vs
             wku[h], wvz_t[h], bvz[h * dk:(h + 1) * dk] = Ks, Vs.t(), bvh
         out["wku"], out["wvz_t"], out["bvz"] = wku, wvz_t, bvz
+        if pre is not None and n_layers > 1:
+            # layer 0's ntgt projections on the DECODED rows: h = (x - b) A, q = h Wq^T + bq = x (Wq A^T)^T + (bq - (b A) Wq^T)
+            for nm in "qkv":
+                W, bb = out[f"w{nm}_n"], out[f"b{nm}_n"]
+                out[f"w{nm}_n0"] = W @ pre.t()
+                out[f"b{nm}_n0"] = bb - (bq @ pre) @ W.t() if bq is not None else bb.clone()
         lay = {k: dev32(v) for k, v in out.items()}
         # the three tgt projections read the same input: stored back to back ([3d, d] / [3d]) so that the C side can run
         # them as ONE GEMM with N = 3d (it checks the pointers; separate tensors still work)

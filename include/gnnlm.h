@@ -297,6 +297,10 @@ typedef struct gnnlm_hgt_layer {
     int32_t din;
     /* node type ntgt (NULL in the last layer unless ntgt outputs are requested) */
     const float *wq_n, *bq_n, *wk_n, *bk_n, *wv_n, *bv_n, *wa_n, *ba_n, *ln_g_n, *ln_b_n;
+    /* ABI 4, layer 0 only, optional (all six or none): the ntgt projections with the OPQ rotation folded in -- [d, M*dsub]
+     * weights W' = W . A^T and biases b' = b + W . opq_nba that read the DECODED rows; the rotation (x - b) A itself is then
+     * only computed for the rows whose residual the layer needs */
+    const float *wq_n0, *bq_n0, *wk_n0, *bk_n0, *wv_n0, *bv_n0;
 } gnnlm_hgt_layer_t;
 
 typedef struct gnnlm_hgt {
