@@ -114,6 +114,8 @@ def lib():
         L.gnnlm_adaptive_workspace_bytes.argtypes = [vp, i64]
         L.gnnlm_adaptive_target_logp.argtypes = [vp, vp, i64, vp, i64, vp, vp, ctypes.c_size_t, vp]
         L.gnnlm_masked_sum_f64.argtypes = [vp, vp, i64, vp, vp]
+        L.gnnlm_ivfpq_pack_codes.argtypes = [vp, i64, i32, vp, vp]
+        L.gnnlm_ivfpq_pack_lut.argtypes = [vp, i64, i64, i32, vp, vp]
         L.gnnlm_hgt_workspace_bytes.argtypes = [vp, vp]
         L.gnnlm_hgt_forward.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
         for nm in ("gnnlm_gemm_nt", "gnnlm_pq_gather_decode", "gnnlm_star_attn", "gnnlm_chain_attn",

@@ -581,6 +581,12 @@ int gnnlm_adaptive_target_logp(const gnnlm_adaptive_softmax_t* w, const float* x
 int gnnlm_knn_interp(const gnnlm_knn_interp_t* d, void* stream) { GNNLM_DESC(d); return knn_interp(*d, (hipStream_t)stream); }
 int gnnlm_topk_merge(const gnnlm_topk_t* d, void* stream) { GNNLM_DESC(d); return topk_merge(*d, (hipStream_t)stream); }
 int gnnlm_ivfpq_scan(const gnnlm_ivfpq_scan_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_scan(*d, (hipStream_t)stream); }
+int gnnlm_ivfpq_pack_codes(const uint8_t* codes, int64_t N, int32_t M, uint8_t* out, void* stream) {
+    return ivfpq_pack_codes(codes, N, M, out, (hipStream_t)stream);
+}
+int gnnlm_ivfpq_pack_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M, float* out, void* stream) {
+    return ivfpq_pack_lut(lut, ld_lut, n, M, out, (hipStream_t)stream);
+}
 int gnnlm_masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, void* stream) {
     return masked_sum_f64(x, mask, n, out, (hipStream_t)stream);
 }

@@ -52,7 +52,7 @@ def _kmeans(x, k, iters, gen, spherical=False):
 class IVFPQIndex:
     """faiss ``search`` contract: ``search(queries [n, d] f32, k) -> (scores [n, k] descending, ids [n, k], -1 padded)``."""
 
-    def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=4, cand_cap=16384):
+    def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=2, cand_cap=32768):
         self.R, self.coarse, self.pq = R, coarse, pq                         # [d, d], [nlist, d], [M, 256, dsub]  f32
         self.list_off, self.list_ids, self.list_codes = list_off, list_ids, list_codes   # i64 [nlist+1], i64 [N], u8 [N, M]
         self.nprobe, self.cosine, self.dense_probes, self.cand_cap = nprobe, cosine, dense_probes, cand_cap
@@ -61,6 +61,12 @@ class IVFPQIndex:
         self.M, _, self.dsub = pq.shape
         self.ntotal = list_ids.shape[0]
         self.max_list = int((list_off[1:] - list_off[:-1]).max().item()) if self.nlist else 0
+        # M = 32 / 64: the scan runs on its own image of the code rows (blocks of 64 rows, bytes in rotated order) and on
+        # tables in [half][code][sub-quantizer] order -- look-ups without LDS bank conflicts (csrc/ivfpq.hip)
+        self.packed_codes = None
+        if self.M in (32, 64) and self.ntotal:
+            self.packed_codes = torch.empty(-(-self.ntotal // 64) * 64 * self.M, dtype=torch.uint8, device=self.device)
+            _lib.call("gnnlm_ivfpq_pack_codes", _lib.ptr(self.list_codes), self.ntotal, self.M, _lib.ptr(self.packed_codes), _lib.stream())
 
     # ------------------------------------------------------------------------------------------ offline producer
     @classmethod
@@ -125,11 +131,13 @@ class IVFPQIndex:
         task_p = (order % (p_hi - p_lo) + p_lo).to(torch.int32)
         s = _lib.gnnlm_ivfpq_scan_t()
         s.codes, s.ids, s.list_off, s.M = self.list_codes.data_ptr(), self.list_ids.data_ptr(), self.list_off.data_ptr(), self.M
+        if self.packed_codes is not None:
+            s.codes, s.packed = self.packed_codes.data_ptr(), 1                 # `lut` is then the packed table set
         s.lut, s.ld_lut = lut.data_ptr(), lut.stride(0)
         s.probe_list, s.probe_bias, s.ld_probe = probe_id.data_ptr(), probe_val.data_ptr(), probe_id.stride(0)
         s.task_q, s.task_p, s.n_tasks = task_q.data_ptr(), task_p.data_ptr(), order.numel()
         if tau is None:
-            s.out_val, s.out_id, s.ld_out, s.p0, s.seg = out[0].data_ptr(), out[1].data_ptr(), out[0].stride(0), p_lo, self.max_list
+            s.out_val, s.ld_out, s.p0, s.seg = out.data_ptr(), out.stride(0), p_lo, self.max_list       # scores only (out_id NULL)
         else:
             s.tau, s.cand_val, s.cand_id, s.cand_cnt, s.cap = tau.data_ptr(), cand[0].data_ptr(), cand[1].data_ptr(), cand[2].data_ptr(), self.cand_cap
         _lib.call_desc("gnnlm_ivfpq_scan", s)
@@ -155,12 +163,19 @@ class IVFPQIndex:
             g.M, g.N, g.K, g.batch1 = nq, 256, self.dsub, self.M
             g.sA1, g.sW1, g.sC1 = self.dsub, 256 * self.dsub, 256
             _lib.call_desc("gnnlm_gemm_nt", g)
+            if self.packed_codes is not None:
+                lut_p = torch.empty_like(lut)
+                _lib.call("gnnlm_ivfpq_pack_lut", _lib.ptr(lut), lut.stride(0), nq, self.M, _lib.ptr(lut_p), _lib.stream())
+                lut = lut_p
             bv, bi = val[q0:q0 + nq], idx[q0:q0 + nq]
             # round 1: the best `dense` lists of every query, every score
             ov = torch.empty(nq, dense * self.max_list, device=dev, dtype=torch.float32)
-            oi = torch.empty(nq, dense * self.max_list, device=dev, dtype=torch.int64)
-            self._scan(lut, pv, pi, 0, dense, out=(ov, oi))
-            ops.topk_merge(ov, bv, bi, ids=oi, largest=True, init=True)
+            self._scan(lut, pv, pi, 0, dense, out=ov)
+            ops.topk_merge(ov, bv, bi, largest=True, init=True)                     # ids = columns of ov
+            # the columns kept -> key ids: column = probe slot * max_list + position in the list (-inf: beyond a list)
+            lst = torch.gather(pi, 1, torch.div(bi, self.max_list, rounding_mode="floor").clamp_(0, dense - 1))
+            pos = self.list_off[lst.clamp(min=0)] + bi % self.max_list
+            bi.copy_(torch.where(torch.isinf(bv) | (lst < 0), torch.full_like(bi, -1), self.list_ids[pos.clamp_(0, max(self.ntotal - 1, 0))]))
             if nprobe > dense:
                 # round 2: the other lists only emit scores above the query's k-th best so far
                 tau = torch.where(bi[:, k - 1] >= 0, bv[:, k - 1], torch.full_like(bv[:, k - 1], float("-inf"))).contiguous()

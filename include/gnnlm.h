@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNLM_ABI_VERSION 4
+#define GNNLM_ABI_VERSION 5
 #define GNNLM_OK 0
 #define GNNLM_E_INVALID (-22)
 #define GNNLM_E_NOMEM (-12)
@@ -274,10 +274,21 @@ typedef struct gnnlm_ivfpq_scan {
     const float* lut;  int64_t ld_lut;    /* [n, M*256] */
     const int64_t* probe_list;  const float* probe_bias;  int32_t ld_probe;   /* [n, ld_probe]: probed lists (-1: none) and <q', centroid> */
     const int32_t* task_q;  const int32_t* task_p;  int64_t n_tasks;
-    float* out_val;  int64_t* out_id;  int64_t ld_out;  int32_t p0, seg;      /* dense: column (p - p0) * seg + j, ids -1 beyond the list */
+    float* out_val;  int64_t* out_id;  int64_t ld_out;  int32_t p0, seg;      /* dense: column (p - p0) * seg + j, ids -1 beyond the list;
+                                                                               * out_id NULL (ABI 5): scores only, -inf beyond the list -- the
+                                                                               * caller maps the columns it keeps to ids[list_off[list] + j] */
     const float* tau;  float* cand_val;  int64_t* cand_id;  int32_t* cand_cnt;  int32_t cap;   /* filtered: rows of `cap` slots, cand_cnt[q] counts ALL survivors */
+    int32_t packed;                       /* ABI 5: nonzero = `codes` is the image of gnnlm_ivfpq_pack_codes and `lut` the tables of
+                                           * gnnlm_ivfpq_pack_lut (M = 32 or 64): the bank-conflict-free scan */
 } gnnlm_ivfpq_scan_t;
 int gnnlm_ivfpq_scan(const gnnlm_ivfpq_scan_t* desc, void* stream);
+
+/* The scan's own device layouts (M = 32 or 64).  Codes: blocks of 64 rows stored [M/16 pieces][64 rows][16 B], and inside a
+ * row byte s of half h holds sub-quantizer 32 h + (row + s) mod 32 -- `out` has ceil(N / 64) * 64 * M bytes, rows beyond N
+ * zero.  Tables: lut [n, M, 256] (row stride ld_lut) -> out [n, M/32, 256, 32].  With these a lane's look-up s goes to
+ * sub-quantizer (lane + s) mod 32 and the 32 lanes of an LDS access group always use 32 different banks. */
+int gnnlm_ivfpq_pack_codes(const uint8_t* codes, int64_t N, int32_t M, uint8_t* out, void* stream);
+int gnnlm_ivfpq_pack_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M, float* out, void* stream);
 
 /* out[0] += sum_i x[i] * (mask ? mask[i] != 0 : 1), accumulated in f64 (score_sum of
  * fairseq_cli/eval_lm.py:273; the reference accumulates in f32 on the CPU) */

@@ -135,6 +135,45 @@ def test_ivfpq_search_matches_oracle(dev):
         assert np.array_equal(i2, ia)
 
 
+@pytest.mark.parametrize("M", [64, 32])
+def test_ivfpq_packed_scan_matches_oracle(dev, M):
+    """M = 32 / 64 (the reference's PQ64): the scan over the packed image (rotated code bytes, [half][code][sub-quantizer]
+    tables) against the numpy IVFADC over the plain index arrays; uneven lists, a list shorter than a 64-row block."""
+    from gnnlm_amd import _lib
+    from gnnlm_amd.ivfpq import IVFPQIndex
+    from oracle import ivfpq as oivf
+    rs = np.random.RandomState(21 + M)
+    N, d, nlist = 150_001, 256, 24
+    centres = rs.randn(60, d).astype(np.float32)
+    keys = (centres[rs.randint(0, 60, N)] + 0.6 * rs.randn(N, d).astype(np.float32)).astype(np.float16)
+    index = IVFPQIndex.build(keys, nlist, M, device=dev, cosine=True, nprobe=9, iters=5, seed=3)
+    assert index.packed_codes is not None and index.packed_codes.numel() == -(-N // 64) * 64 * M
+    # the packed image, restated: block of 64 rows, piece-major, byte s of half h = sub-quantizer 32 h + (row + s) mod 32
+    codes = index.list_codes.cpu().numpy()
+    pk = index.packed_codes.cpu().numpy().reshape(-1, M // 16, 64, 16)
+    for r in (0, 1, 31, 63, 64, 12345, N - 1):
+        row = pk[r // 64, :, r % 64, :].reshape(M)
+        want = np.array([codes[r, 32 * (i // 32) + (r + i % 32) % 32] for i in range(M)], dtype=np.uint8)
+        assert np.array_equal(row, want), r
+    assert not pk[-1, :, N % 64:, :].any()                                    # rows beyond N are zero
+    q = (centres[rs.randint(0, 60, 33)] + 0.6 * rs.randn(33, d)).astype(np.float32)
+    qn = q / np.sqrt((q ** 2).sum(1, keepdims=True))
+    arrs = [getattr(index, a).cpu().numpy() for a in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")]
+    for k in (1024, 64):
+        v, i = index.search(qn, k)
+        v_ref, i_ref = oivf.search(qn, *arrs, k=k, nprobe=9)
+        same = np.mean([len(set(a) & set(b)) / k for a, b in zip(i, i_ref)])
+        assert same > 0.998, same
+        np.testing.assert_allclose(v, v_ref, rtol=2e-5, atol=2e-5)
+        assert (np.diff(v, axis=1) <= 0).all() and (i >= 0).all()
+    # the same index searched by the row-major kernels gives the same neighbours
+    plain = IVFPQIndex(index.R, index.coarse, index.pq, index.list_off, index.list_ids, index.list_codes, nprobe=9)
+    plain.packed_codes = None
+    v2, i2 = plain.search(qn, 64)
+    np.testing.assert_allclose(v2, v, rtol=1e-5, atol=1e-5)
+    assert np.mean([len(set(a) & set(b)) / 64 for a, b in zip(i, i2)]) > 0.998
+
+
 def test_ivfpq_small_lists_and_padding(dev):
     from gnnlm_amd.ivfpq import IVFPQIndex
     from oracle import ivfpq as oivf

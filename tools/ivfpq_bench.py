@@ -10,7 +10,9 @@ from gnnlm_amd.synthetic import synthetic_ivfpq_index
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     N = int(os.environ.get("N", 103227021)); n = int(os.environ.get("NQ", 8192)); k = int(os.environ.get("K", 1024))
-    idx = synthetic_ivfpq_index(N, 1024, 4096, 64, dev, dense_probes=int(os.environ.get("DENSE", 4)))
+    idx = synthetic_ivfpq_index(N, 1024, 4096, 64, dev, dense_probes=int(os.environ.get("DENSE", 2)), cand_cap=int(os.environ.get("CAP", 32768)))
+    if os.environ.get("PLAIN"):
+        idx.packed_codes = None                            # the row-major kernels (A/B)
     q = torch.randn(n, 1024, device=dev); q = q / q.norm(dim=1, keepdim=True)
     from gnnlm_amd import _lib
     idx.search_device(q, k); torch.cuda.synchronize()      # same shapes as the timed call

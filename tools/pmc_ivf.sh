@@ -1,0 +1,22 @@
+# PMC passes of the IVF-PQ list scan (tools/ivfpq_bench.py, NQ = 2048): run on the GPU box, prints per-dispatch averages
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+export NQ=${NQ:-2048}
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_ivf1 --output-format csv -- python3 $R/tools/ivfpq_bench.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU -d $R/gpurun_out/pmc_ivf2 --output-format csv -- python3 $R/tools/ivfpq_bench.py > /dev/null 2>&1
+python3 - <<'PY'
+import csv,glob,os,collections
+R=os.environ['GRAFT_REPO_ROOT']
+for d in ('pmc_ivf1','pmc_ivf2'):
+    for f in glob.glob(f'{R}/gpurun_out/{d}/**/*counter_collection.csv', recursive=True):
+        acc=collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(f)):
+            if 'ivfpq_scan' in r['Kernel_Name']:
+                acc[r['Dispatch_Id']][r['Counter_Name']] += float(r['Counter_Value'])
+        for disp in sorted(acc, key=int)[-4:]:
+            print(d, disp, {k: f'{v:.4g}' for k, v in acc[disp].items()})
+    for f in glob.glob(f'{R}/gpurun_out/{d}/**/*kernel_trace.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'ivfpq_scan' in r['Kernel_Name']:
+                print(d, 'dispatch', r.get('Dispatch_Id'), 'us', (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, 'grid', r.get('Grid_Size'))
+PY
