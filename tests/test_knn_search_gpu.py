@@ -174,13 +174,17 @@ def test_ivfpq_packed_scan_matches_oracle(dev, M):
     assert np.mean([len(set(a) & set(b)) / 64 for a, b in zip(i, i2)]) > 0.998
 
 
-def test_ivfpq_small_lists_and_padding(dev):
+@pytest.mark.parametrize("d,M", [(64, 16), (128, 32), (256, 64)])
+def test_ivfpq_small_lists_and_padding(dev, d, M):
+    """Lists shorter than a 64-row block, fewer stored keys than k (-1 padding), an odd query count (a workgroup with one
+    task); M = 32 / 64 take the packed-image kernels."""
     from gnnlm_amd.ivfpq import IVFPQIndex
     from oracle import ivfpq as oivf
     rs = np.random.RandomState(2)
-    keys = rs.randn(300, 64).astype(np.float32)
-    index = IVFPQIndex.build(keys, 8, 16, device=dev, cosine=False, nprobe=3, iters=4, seed=0)
-    q = rs.randn(5, 64).astype(np.float32)
+    keys = rs.randn(300, d).astype(np.float32)
+    index = IVFPQIndex.build(keys, 8, M, device=dev, cosine=False, nprobe=3, iters=4, seed=0)
+    assert (index.packed_codes is not None) == (M in (32, 64))
+    q = rs.randn(5, d).astype(np.float32)
     v, i = index.search(q, 200)                                           # more than 3 lists hold: -1 padding
     arrs = [getattr(index, a).cpu().numpy() for a in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")]
     v_ref, i_ref = oivf.search(q, *arrs, k=200, nprobe=3)
