@@ -120,6 +120,22 @@ class IVFPQIndex:
         kw.setdefault("nprobe", int(z["meta"][0]))
         return cls(t("R"), t("coarse"), t("pq"), t("list_off"), t("list_ids"), t("list_codes"), cosine=bool(z["meta"][1]), **kw)
 
+    @classmethod
+    def from_faiss_file(cls, path, device="cuda", cosine=True, **kw):
+        """The reference's own index file (``faiss.write_index`` of ``OPQ64_1024,IVF4096,PQ64``, knn/index_builder.py:79-150;
+        ``--index-file``) read without faiss (faiss_io.read_ivfpq_index) -- inner-product indexes with residual codes."""
+        from . import faiss_io
+        z = faiss_io.read_ivfpq_index(path)
+        if z["metric"] != "ip" or z["coarse_metric"] != "ip" or not z["by_residual"]:
+            raise ValueError(f"{path}: the on-device search covers inner-product IVF-PQ with residual codes (the cosine / ip "
+                             f"indexes of knn/index_builder.py), found metric={z['metric']} coarse={z['coarse_metric']} "
+                             f"by_residual={z['by_residual']}")
+        d = z["coarse"].shape[1]
+        R = z["R"] if z["R"] is not None else np.eye(d, dtype=np.float32)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        kw.setdefault("nprobe", z["nprobe"])
+        return cls(t(R), t(z["coarse"]), t(z["pq"]), t(z["list_off"]), t(z["list_ids"]), t(z["list_codes"]), cosine=cosine, **kw)
+
     # ------------------------------------------------------------------------------------------ search
     def _scan(self, lut, probe_val, probe_id, p_lo, p_hi, out=None, tau=None, cand=None):
         n = lut.shape[0]

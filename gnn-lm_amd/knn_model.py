@@ -120,13 +120,25 @@ class KNNModel(object):
     def setup_faiss(self):
         """The index behind ``get_knns`` (knn_model.py:59-64,78-82), in this order: an IVF-PQ index in this package's
         own format next to ``index_file`` (``<index_file>.gnnlm.npz``, written by ``python -m gnnlm_amd.run_index_build``:
-        searched on the GPU, the hot-path choice at datastore scale); a faiss index if faiss is importable; else an
+        searched on the GPU, the hot-path choice at datastore scale); ``index_file`` itself if it is a faiss
+        ``[OPQ,]IVF,PQ`` inner-product index (read by faiss_io, searched on the GPU); a faiss index if faiss is importable; else an
         exact index over the keys resident in HBM (chunked search, fine up to a few 10^7 keys)."""
         own = self.index_file if self.index_file.endswith(".gnnlm.npz") else self.index_file + ".gnnlm.npz"
         if os.path.exists(own):
             from .ivfpq import IVFPQIndex
             LOGGING.info("IVF-PQ index %s searched on %s", own, self.device)
             return IVFPQIndex.load(own, device=self.device, nprobe=self.probe)
+        if os.path.isfile(self.index_file):
+            from . import faiss_io
+            if faiss_io.sniff(self.index_file) in ("IxPT", "IwPQ"):
+                # the reference's own faiss file (knn/index_builder.py): read without faiss, searched on the GPU
+                from .ivfpq import IVFPQIndex
+                try:
+                    index = IVFPQIndex.from_faiss_file(self.index_file, device=self.device, cosine=self.cosine, nprobe=self.probe)
+                    LOGGING.info("faiss IVF-PQ file %s searched on %s", self.index_file, self.device)
+                    return index
+                except ValueError as e:
+                    LOGGING.warning("%s", e)
         try:
             import faiss
         except ImportError:

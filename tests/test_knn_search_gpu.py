@@ -224,3 +224,38 @@ def test_knn_model_over_built_index(dev, tmp_path):
     p_ref, rec_ref = oknn.knn_target_prob(v_ref.astype(np.float32), i_ref, vals, targets, 1.0)
     np.testing.assert_allclose(p.cpu().numpy(), p_ref.numpy(), rtol=2e-4, atol=1e-6)
     assert np.abs(rec.cpu().numpy() - rec_ref.numpy()).max() <= 1              # a near-tie at the k-th place may swap one neighbour
+
+
+def test_knn_model_reads_faiss_index_file(dev, tmp_path):
+    """`--index-file` pointing at a faiss `[OPQ,]IVF,PQ` file (what knn/index_builder.py writes): KNNModel reads it without
+    faiss (faiss_io.read_ivfpq_index) and searches it on the device -- same neighbours as the index it was written from."""
+    import json, os
+    from gnnlm_amd import faiss_io
+    from gnnlm_amd.ivfpq import IVFPQIndex
+    from gnnlm_amd.knn_model import KNNModel
+    rs = np.random.RandomState(14)
+    N, d, V, M = 30000, 128, 40, 32
+    centres = rs.randn(30, d).astype(np.float32)
+    keys = (centres[rs.randint(0, 30, N)] + 0.5 * rs.randn(N, d)).astype(np.float16)
+    vals = rs.randint(0, V, N).astype(np.int16)
+    dd = tmp_path / "train_dstore"
+    os.makedirs(dd)
+    keys.tofile(dd / "keys.npy"); vals.tofile(dd / "vals.npy")
+    json.dump({"dstore_size": N, "hidden_size": d, "vocab_size": V, "dstore_fp16": True, "val_size": 1}, open(dd / "info.json", "w"))
+    built = IVFPQIndex.build(keys, 48, M, device=dev, cosine=True, nprobe=6, iters=5, seed=2)
+    arrs = {a: getattr(built, a).cpu().numpy() for a in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")}
+    f = str(dd / "faiss_store.cosine")
+    faiss_io.write_ivfpq_index(f, arrs["R"], arrs["coarse"], arrs["pq"], arrs["list_off"], arrs["list_ids"], arrs["list_codes"], nprobe=1)
+    m = KNNModel(f, str(dd), k=64, probe=6, no_load_keys=True, metric_type="do_not_recomp_ip", device=dev)
+    assert isinstance(m.index, IVFPQIndex) and m.index.nprobe == 6 and m.index.packed_codes is not None
+    q = (centres[rs.randint(0, 30, 17)] + 0.5 * rs.randn(17, d)).astype(np.float32)
+    qn = q / np.sqrt((q ** 2).sum(1, keepdims=True))
+    v0, i0 = built.search(qn, 64)
+    v1, i1 = m.index.search(qn, 64)
+    assert np.array_equal(i0, i1) and np.array_equal(v0, v1)
+    # an L2 index is refused by the on-device search (and, without faiss or keys, by KNNModel)
+    faiss_io.write_ivfpq_index(f, arrs["R"], arrs["coarse"], arrs["pq"], arrs["list_off"], arrs["list_ids"], arrs["list_codes"], metric="l2")
+    with pytest.raises(ValueError):
+        IVFPQIndex.from_faiss_file(f, device=dev)
+    with pytest.raises(ValueError):
+        KNNModel(f, str(dd), k=64, probe=6, no_load_keys=True, metric_type="do_not_recomp_ip", device=dev)

@@ -114,3 +114,38 @@ def test_faiss_quantizer_file_round_trip(tmp_path):
     open(f, "wb").write(b"IxHN" + raw[4:])
     with pytest.raises(ValueError):
         read_pq_quantizer(f)
+
+
+def test_faiss_ivfpq_index_file_round_trip(tmp_path):
+    """The kNN index file layout (faiss IndexPreTransform(OPQ) -> IndexIVFPQ over an IndexFlatIP, index_builder.py:79-150)
+    restated in faiss_io.py: byte-level spot checks of the layout, writer and reader agree (dense and sparse list-size
+    tables, with and without the OPQ matrix), other index kinds are refused."""
+    import pytest
+    from gnnlm_amd.faiss_io import read_ivfpq_index, sniff, write_ivfpq_index
+    rs = np.random.RandomState(1)
+    d, M, nlist = 32, 8, 6
+    R = rs.randn(d, d).astype(np.float32)
+    coarse = rs.randn(nlist, d).astype(np.float32)
+    pq = rs.randn(M, 256, d // M).astype(np.float32)
+    f = str(tmp_path / "faiss_store.cosine")
+    for sizes in ([5, 0, 70, 1, 3, 64], [0, 0, 9, 0, 0, 0]):                                   # "full" and "sprs" size tables
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        N = int(off[-1])
+        ids = rs.permutation(N).astype(np.int64)
+        codes = rs.randint(0, 256, (N, M)).astype(np.uint8)
+        for R_ in (R, None):
+            write_ivfpq_index(f, R_, coarse, pq, off, ids, codes, nprobe=3)
+            assert sniff(f) == ("IxPT" if R_ is not None else "IwPQ")
+            z = read_ivfpq_index(f)
+            assert (z["R"] is None) == (R_ is None) and (R_ is None or np.array_equal(z["R"], R_))
+            assert np.array_equal(z["coarse"], coarse) and np.array_equal(z["pq"], pq)
+            assert np.array_equal(z["list_off"], off) and np.array_equal(z["list_ids"], ids) and np.array_equal(z["list_codes"], codes)
+            assert z["nprobe"] == 3 and z["metric"] == "ip" and z["coarse_metric"] == "ip" and z["by_residual"]
+    raw = open(f, "rb").read()
+    # IwPQ | header (int32 d, int64 ntotal, 2 x int64, bool, int32 metric) | uint64 nlist | uint64 nprobe | IxFI ...
+    assert raw[:4] == b"IwPQ" and struct.unpack_from("<iq", raw, 4) == (d, 9)
+    assert struct.unpack_from("<QQ", raw, 4 + 33) == (nlist, 3) and raw[4 + 33 + 16:4 + 33 + 20] == b"IxFI"
+    assert b"ilar" in raw and b"sprs" in raw
+    open(f, "wb").write(b"IxHN" + raw[4:])
+    with pytest.raises(ValueError):
+        read_ivfpq_index(f)
