@@ -157,12 +157,12 @@ int linear(const float* A, int64_t lda, const float* W, const float* bias, float
 
 // the same on a subset of rows: logical row r reads A row rows[r] and writes C row rows[r] (both in their full layouts)
 int linear_rows(const float* A, int64_t lda, const float* W, const float* bias, float* C, int64_t ldc, const int32_t* rows,
-                int64_t n_rows, int N, int K, float alpha, hipStream_t s) {
+                int64_t n_rows, int N, int K, float alpha, hipStream_t s, int64_t rows_bound = 0) {
     GemmParams g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = ldc;
     g.bias = bias; g.bias_mode = bias ? 1 : 0;
     g.alpha = alpha;
-    g.a_rows = rows; g.c_rows = rows;
+    g.a_rows = rows; g.c_rows = rows; g.a_rows_bound = rows_bound;
     g.M = (int)n_rows; g.N = N; g.K = K;
     return gemm_nt(g, s);
 }
@@ -389,17 +389,17 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
                 TRY(group_rows(b.rows_out, G, n_g, sel_out, n_out, s));
                 TRY(group_rows(b.rows_kv, G, n_g, sel_kv, n_kv, s));
                 const int64_t R_out = G * n_out, R_kv = G * n_kv;
-                if (f0) TRY(linear_rows(b.hn[1], dpq, m.opq_at, m.opq_nba, b.hn[0], d, b.rows_out, R_out, d, dpq, 1.f, s));   // residual rows only
-                TRY(linear_rows(pin, ld_pin, Wq, Bq, b.nq, d, b.rows_out, R_out, d, kin, 1.f, s));
-                TRY(linear_rows(pin, ld_pin, Wk, Bk, b.nk, d, b.rows_kv, R_kv, d, kin, 1.f, s));
-                TRY(linear_rows(pin, ld_pin, Wv, Bv, b.nv, d, b.rows_kv, R_kv, d, kin, 1.f, s));
+                if (f0) TRY(linear_rows(b.hn[1], dpq, m.opq_at, m.opq_nba, b.hn[0], d, b.rows_out, R_out, d, dpq, 1.f, s, S));   // residual rows only
+                TRY(linear_rows(pin, ld_pin, Wq, Bq, b.nq, d, b.rows_out, R_out, d, kin, 1.f, s, S));
+                TRY(linear_rows(pin, ld_pin, Wk, Bk, b.nk, d, b.rows_kv, R_kv, d, kin, 1.f, s, S));
+                TRY(linear_rows(pin, ld_pin, Wv, Bv, b.nv, d, b.rows_kv, R_kv, d, kin, 1.f, s, S));
                 ChainAttnParams ca{};
                 ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
                 ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
                 ca.out = b.nq; ca.ldo = d;
                 ca.radius_p1 = rad + 1;
                 TRY(chain_attn(ca, s));
-                TRY(linear_rows(b.nq, d, w.wa_n, w.ba_n, b.nk, d, b.rows_out, R_out, d, d, 1.f, s));
+                TRY(linear_rows(b.nq, d, w.wa_n, w.ba_n, b.nk, d, b.rows_out, R_out, d, d, 1.f, s, S));
                 TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, R_out, d, m.ln_eps, valid, s, hn_cur, ld_hn, b.rows_out));
             }
             hn_cur = hn_out;

@@ -385,6 +385,7 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     // 128x128 tiles unless they would leave CUs without a workgroup (256 CUs)
     const int64_t tiles128 = cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
     const bool small = !p.lse_part && tiles128 < 256;
+    if (!small && gemm_sched_eligible(p)) return gemm_nt_sched(p, stream);   // hand-placed main loop (gemm_f32_sched.hip)
     if (!small && gemm_dma_eligible(p)) return gemm_nt_dma(p, stream);   // LDS-DMA staged main loop (gemm_f32_dma.hip)
     const int BMN = small ? 64 : 128;
     const int64_t tiles = cdiv(p.M, BMN) * cdiv(p.N, BMN) * nb;

@@ -23,6 +23,8 @@ int gemm_nt_split(const GemmParams& p, hipStream_t stream);
 // f32 MFMA kernel with LDS-DMA staging (gemm_f32_dma.hip): taken by gemm_nt for 128x128-tile problems with K % 16 == 0
 bool gemm_dma_eligible(const GemmParams& p);
 int gemm_nt_dma(const GemmParams& p, hipStream_t stream);
+bool gemm_sched_eligible(const GemmParams& p);
+int gemm_nt_sched(const GemmParams& p, hipStream_t stream);
 // precision used by gemm_nt for descriptors that leave `precision` at 0 (set by the orchestrators)
 extern thread_local int g_default_gemm_precision;
 struct GemmPrecisionScope {

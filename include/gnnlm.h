@@ -73,6 +73,8 @@ typedef struct gnnlm_gemm {
     float* lse_part;           /* [M, 2*ceil(N/128), 2] */
     const int32_t* lse_pick;   /* optional [M] */
     float* lse_picked;         /* [M] (with lse_pick) */
+    int64_t a_rows_bound;      /* ABI 5, optional with a_rows: every a_rows[r] < a_rows_bound (0: unknown) -- lets the kernels with
+                                  32-bit row offsets take a gathered problem */
 } gnnlm_gemm_t;
 int gnnlm_gemm_nt(const gnnlm_gemm_t* desc, void* stream);
 /* lse[row] = log sum exp over the row, from the partial pairs of the LSE epilogue */
