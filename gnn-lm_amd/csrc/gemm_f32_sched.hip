@@ -127,26 +127,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
         int cnt = nk >> 1;
         int koff = nk > 1 ? BK * 4 : 0;
         const int inc = BK * 4;
+#ifdef GNNLM_SCHED_AGPR
+#define GNNLM_ACC_RC "+a"
+#else
+#define GNNLM_ACC_RC "+v"
+#endif
 #define GNNLM_SCHED_OPERANDS                                                                                                    \
-            : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]), [cnt] "+s"(cnt), [koff] "+s"(koff) \
+            : [c00] GNNLM_ACC_RC(acc[0][0]), [c01] GNNLM_ACC_RC(acc[0][1]), [c10] GNNLM_ACC_RC(acc[1][0]), [c11] GNNLM_ACC_RC(acc[1][1]), [cnt] "+s"(cnt), [koff] "+s"(koff) \
             : [sa] "s"(sa), [sw] "s"(sw), [inc] "s"(inc),                                                                             \
               [oa0] "v"(cur.oa[0]), [oa1] "v"(cur.oa[1]), [oa2] "v"(cur.oa[2]), [oa3] "v"(cur.oa[3]),                                                  \
               [ow0] "v"(cur.ow[0]), [ow1] "v"(cur.ow[1]), [ow2] "v"(cur.ow[2]), [ow3] "v"(cur.ow[3]), [lw] "v"(lw),                                    \
               [ra0] "v"(ra[0]), [ra1] "v"(ra[1]), [ra2] "v"(ra[2]), [ra3] "v"(ra[3]),                                                  \
               [rb0] "v"(rb[0]), [rb1] "v"(rb[1]), [rb2] "v"(rb[2]), [rb3] "v"(rb[3])                                                   \
-            : "memory", "vcc", "scc",                                                                                                  \
-              "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", \
-              "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", \
-              "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", \
-              "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223"
+            : "memory", "vcc", "scc",
         if constexpr (EPI == EPI_LSE) {          // operands swapped: transposed accumulators (gemm_epilogue.inc)
             asm volatile(
 #include "gemm_sched_loop_t.inc"
-                GNNLM_SCHED_OPERANDS);
+                GNNLM_SCHED_OPERANDS
+#include "gemm_sched_clobbers.inc"
+            );
         } else {
             asm volatile(
 #include "gemm_sched_loop.inc"
-                GNNLM_SCHED_OPERANDS);
+                GNNLM_SCHED_OPERANDS
+#include "gemm_sched_clobbers.inc"
+            );
         }
 #undef GNNLM_SCHED_OPERANDS
         __syncthreads();                                               // every wave left the loop: the LDS image is free
