@@ -178,11 +178,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
 // Where the scheduled kernel is taken: exact f32, K a multiple of 64 (the loop runs stage pairs), 128x128 tiles filling the
 // chip, rows addressed with 32-bit byte offsets inside the panel.  GNNLM_GEMM_SCHED=0 sends everything to the other kernels.
 bool gemm_sched_eligible(const GemmParams& p) {
-    // GNNLM_GEMM_SCHED (A/B runs): 0 = never, 1 = store-epilogue problems only, 3 (default) = log-sum-exp problems too
+    // GNNLM_GEMM_SCHED (A/B runs): 0 = never, 1 = store-epilogue problems only, 3 (default) = log-sum-exp problems too, 7 = the head as well
     static const int on = [] { const char* e = getenv("GNNLM_GEMM_SCHED"); return e ? atoi(e) : 3; }();
     if (!on) return false;
     if (p.precision != 0) return false;
     if (p.lse_part && !(on & 2)) return false;
+    // the softmax head (>= 2048 tiles of 256x256) runs in the same time here as on the 256x256 LDS-DMA kernel (2.47 ms), but
+    // with 128-wide W panels it pulls the A panel through the fabric twice as often (PMC FETCH_SIZE 2.9 vs 1.4 GB): stays there
+    if (p.lse_part && !p.m_dev && !(on & 4) && cdiv(p.M, 256) * cdiv(p.N, 256) >= 2048) return false;
     if (p.K % 64 != 0 || p.K < 256) return false;                       // K = 128 (absorbed queries): 191 us on the register-staged kernel, 206 here
     const int64_t nb = (int64_t)p.batch1 * p.batch2;
     if (cdiv(p.M, 128) * cdiv(p.N, 128) * nb < 256) return false;
