@@ -76,3 +76,13 @@ def test_integration_c_snippet_compiles(tmp_path):
         r = subprocess.run([cc, std, "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(_lib.ROOT, "include"), str(f)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_generated_gemm_loop_is_current(tmp_path):
+    """csrc/gemm_sched_loop*.inc / gemm_sched_clobbers.inc are written by tools/gen_gemm_sched.py: the committed files are
+    what the generator emits (an edit of one without the other would ship a stale main loop)."""
+    import subprocess, sys
+    root = _lib.ROOT
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_gemm_sched.py"), str(tmp_path)], check=True, capture_output=True)
+    for f in ("gemm_sched_loop.inc", "gemm_sched_loop_t.inc", "gemm_sched_clobbers.inc"):
+        assert open(tmp_path / f).read() == open(os.path.join(root, "gnn-lm_amd", "csrc", f)).read(), f

@@ -74,11 +74,17 @@ def stage(b, last_of_pair):
 SWAP = False
 
 
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnn-lm_amd", "csrc")
+
+
 def main():
-    global SWAP
+    global SWAP, OUT_DIR
+    import sys
+    if len(sys.argv) > 1:                      # tools/gen_gemm_sched.py <dir>: write there (tests compare with csrc/)
+        OUT_DIR = sys.argv[1]
     for SWAP, fname in ((False, "gemm_sched_loop.inc"), (True, "gemm_sched_loop_t.inc")):
         emit(fname)
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnn-lm_amd", "csrc", "gemm_sched_clobbers.inc")
+    out = os.path.join(OUT_DIR, "gemm_sched_clobbers.inc")
     with open(out, "w") as f:
         f.write("// generated by tools/gen_gemm_sched.py -- do not edit: the fixed registers of gemm_sched_loop*.inc\n")
         regs = [f'"v{BASE + i}"' for i in range(64)]
@@ -94,7 +100,7 @@ def emit(fname):
     L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b",
           "s_waitcnt lgkmcnt(0)", "s_nop 15", "s_nop 7"]
     txt = "\n".join(L)
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnn-lm_amd", "csrc", fname)
+    out = os.path.join(OUT_DIR, fname)
     with open(out, "w") as f:
         f.write("// generated by tools/gen_gemm_sched.py -- do not edit\n")
         for l in txt.split("\n"):
