@@ -315,8 +315,16 @@ def driver_path(args, eng, batches, dev):
     from gnnlm_amd.model import GnnLmModel
     st = eng.store
     T, nblk = args.tokens_per_sample, min(args.blocks, 32)
-    b0 = batches[0]
-    n = nblk * T
+    nb = nblk * T                                                             # tokens of one bench batch
+    n = nb * len(batches)                                                     # the whole input pool: several batches per run
+
+    class _Pool:                               # the pool's batches back to back (the driver slices blocks out of flat tables)
+        tgt_feats = torch.cat([b.tgt_feats[:nb] for b in batches])
+        targets = torch.cat([b.targets[:nb] for b in batches])
+        ids = torch.cat([b.ids[:nb] for b in batches])
+        knn_sims = torch.cat([b.knn_sims[:nb] for b in batches])
+        knn_ids = torch.cat([b.knn_ids[:nb] for b in batches])
+    b0 = _Pool
     model = GnnLmModel(eng.hgt, eng.asm, None)
     model.make_store = lambda codes, n_store, device: st                      # resident store, codec already folded
 
@@ -343,12 +351,12 @@ def driver_path(args, eng, batches, dev):
     tabs = {"n_tok": n, "d": eng.hgt.hidden_dim, "vocab": None, "n_store": st.n_store, "feats": b0.tgt_feats[:n],
             "targets": b0.targets[:n].clamp(min=4), "nbrs": b0.ids[:n], "codes": st.codes, "no_pad": True}
     out = {}
-    for name, max_tokens in (("one_block_per_batch", T), ("bench_batch", n)):
+    for name, max_tokens in (("one_block_per_batch", T), ("bench_batch", nb)):
         a = eval_lm.get_parser().parse_args(
             ["-", "--path", "-", "--graph", "--use-precompute-feat", "--neighbor-context", "2", "--gcn-k", str(args.gcn_k),
              "--tokens-per-sample", str(T), "--max-tokens", str(max_tokens), "--knnlm", "--k", str(args.k), "--lmbda",
              str(args.lmbda), "--temperature", str(args.temperature), "--knn-keytype", "gcn_feat", "--softmax-batch",
-             str(n + 1), "--device", str(dev)])
+             str(nb + 1), "--device", str(dev)])
         a.knn_model = Knn()
         import contextlib
         import io
