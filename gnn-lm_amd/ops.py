@@ -54,6 +54,7 @@ def gemm_nt(A, W, bias=None, residual=None, alpha=1.0, out=None, bias_mode=1, ga
     g.C, g.ldc = out.data_ptr(), out.stride(0)
     if a_rows is not None:
         g.a_rows = a_rows.data_ptr()
+        g.a_rows_bound = A.shape[0]                    # every gathered row lies inside A
     if c_rows is not None:
         assert c_rows.dtype == torch.int32 and c_rows.shape[0] == M
         g.c_rows = c_rows.data_ptr()

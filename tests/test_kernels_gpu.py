@@ -85,7 +85,8 @@ def test_gemm_options(ops, dev):
 
 @pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("bf16x6", 2e-5), ("bf16x3", 3e-4)])
 @pytest.mark.parametrize("M,N,K", [(2100, 20002, 256),    # 256x256 plane tiles for the bf16 modes, LDS-DMA kernel for f32
-                                   (1000, 5000, 288)])    # 128x128 plane tiles
+                                   (1000, 5000, 288),     # 128x128 plane tiles
+                                   (1000, 5000, 320)])    # f32: the hand-placed-loop kernel, transposed accumulators
 def test_gemm_lse_large(ops, dev, precision, tol, M, N, K):
     """LSE epilogue (transposed accumulators) of every large-problem kernel, ragged last n-tile, device-side M."""
     g = torch.Generator().manual_seed(M + K)
@@ -143,6 +144,7 @@ def test_gemm_lse_head_sized(ops, dev):
 @pytest.mark.parametrize("M,N,K", [(2100, 2050, 96),     # 128x128 tiles, register-staged kernel (K < 128)
                                    (2100, 2050, 160),    # 128x128 tiles, LDS-DMA kernel (f32) / in-kernel split
                                    (2100, 2050, 288),    # + the pre-split plane kernel for the bf16 modes
+                                   (2100, 2050, 320),    # f32: the kernel with the hand-placed main loop (K % 64 == 0, >= 256 tiles)
                                    (700, 300, 100)])     # 64x64 tiles
 def test_gemm_full_contract(ops, dev, precision, tol, M, N, K):
     """Every epilogue option at once on each kernel variant: row gather with zero rows, scattered store +
@@ -181,7 +183,12 @@ def test_gemm_batched_strides(ops, dev):
     many tiles per batch so the flattened (batch, tile) walk of the resident pool is exercised."""
     from gnnlm_amd import _lib
     g = torch.Generator().manual_seed(11)
-    b1, b2, M, N, K = 3, 2, 520, 390, 64
+    _batched_case(dev, g, 3, 2, 520, 390, 64)
+    _batched_case(dev, g, 3, 2, 1300, 390, 256)      # >= 256 tiles, K % 64 == 0: the hand-placed-loop kernel walks (batch, tile) pairs
+
+
+def _batched_case(dev, g, b1, b2, M, N, K):
+    from gnnlm_amd import _lib
     A = torch.randn(b1, b2, M, K + 4, generator=g).to(dev)
     W = torch.randn(b2, b1, N, K, generator=g).to(dev)
     C = torch.zeros(b1, M, b2, N + 4, device=dev)
