@@ -159,6 +159,21 @@ class IVFPQIndex:
         _lib.call_desc("gnnlm_ivfpq_scan", s)
 
     def search_device(self, q, k, query_block=1024):
+        """The search, on device tensors.  The thresholded round keeps at most ``cand_cap`` survivors per query; a query with
+        more would lose neighbours, so the survivor counts are read back once per call (the only host sync) and the call is
+        repeated with room for the largest count -- and, past 2^18 slots, with every probed list scored in full."""
+        while True:
+            self._overflow = None
+            out = self._search_once(q, k, query_block)
+            ov = int(self._overflow.item()) if self._overflow is not None else 0
+            if ov <= self.cand_cap:
+                return out
+            if ov > (1 << 18):
+                self.dense_probes = self.nprobe
+            else:
+                self.cand_cap = 1 << (ov - 1).bit_length()
+
+    def _search_once(self, q, k, query_block):
         q = q.to(self.device, torch.float32).contiguous()
         n, dev = q.shape[0], self.device
         nprobe = min(self.nprobe, self.nlist)
@@ -204,7 +219,8 @@ class IVFPQIndex:
         return val, idx
 
     def check(self):
-        """Raise if a query had more round-2 survivors than candidate slots (its result may miss neighbours)."""
+        """Raise if a query had more round-2 survivors than candidate slots (cannot happen after search_device returned: it
+        repeats such a call with more room; kept for callers of the one-pass search)."""
         ov = getattr(self, "_overflow", None)
         if ov is not None and int(ov.item()) > self.cand_cap:
             raise RuntimeError(f"IVFPQIndex: {int(ov.item())} candidates for one query exceed cand_cap={self.cand_cap}; "

@@ -166,6 +166,16 @@ def test_ivfpq_packed_scan_matches_oracle(dev, M):
         assert same > 0.998, same
         np.testing.assert_allclose(v, v_ref, rtol=2e-5, atol=2e-5)
         assert (np.diff(v, axis=1) <= 0).all() and (i >= 0).all()
+    # too few candidate slots for the thresholded round: the search notices (survivor counts) and repeats itself with room
+    tight = IVFPQIndex(index.R, index.coarse, index.pq, index.list_off, index.list_ids, index.list_codes, nprobe=9,
+                       dense_probes=1, cand_cap=2)
+    qr = rs.randn(9, d).astype(np.float32)                                   # unclustered queries: neighbours in every probed list
+    qr /= np.sqrt((qr ** 2).sum(1, keepdims=True))
+    vf, jf = index.search(qr, 1024)
+    v3, i3 = tight.search(qr, 1024)
+    assert tight.cand_cap > 2
+    np.testing.assert_allclose(v3, vf, rtol=1e-5, atol=1e-5)
+    assert np.mean([len(set(a) & set(b)) / 1024 for a, b in zip(jf, i3)]) > 0.998
     # the same index searched by the row-major kernels gives the same neighbours
     plain = IVFPQIndex(index.R, index.coarse, index.pq, index.list_off, index.list_ids, index.list_codes, nprobe=9)
     plain.packed_codes = None
