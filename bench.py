@@ -37,8 +37,8 @@ KERNEL_BOUND = {"gemm_nt_f32_kernel": "mfma", "causal_attn_kernel": "mfma"}     
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--blocks", type=int, default=32, help="256-token blocks per step per GPU")
     ap.add_argument("--layers", type=int, default=1, help="HGT layers (configs[1]: 1; the shipped recipe: 3)")
     ap.add_argument("--n-store", type=int, default=103227021)
