@@ -57,6 +57,10 @@ def get_parser():
     p.add_argument("--tokens-per-sample", default=1024, type=int)
     p.add_argument("--max-tokens", default=None, type=int)
     p.add_argument("--max-sentences", default=None, type=int)
+    p.add_argument("--batch-blocks", default=0, type=int,
+                   help="(this build) score at least this many blocks per launch whatever --max-tokens says: blocks are independent, "
+                        "so the hypotheses, their order and the scores are those of the one-block batches of the recipe; "
+                        "32 turns the recipe's `--max-tokens 256` run from launch-bound into the bench's batch")
     p.add_argument("--softmax-batch", default=sys.maxsize, type=int)
     p.add_argument("--context-window", default=0, type=int)
     p.add_argument("--model-overrides", default="{}")
@@ -164,6 +168,7 @@ def main(args, tables=None, model=None):
     per_batch = max(1, (args.max_tokens or 36000) // max(1, T + args.gcn_context_window))
     if args.max_sentences:
         per_batch = min(per_batch, args.max_sentences)
+    per_batch = max(per_batch, args.batch_blocks)
     scorer = SequenceScorer(_Dict(), args.softmax_batch, args=args)
     knn_dstore = None
     if args.knnlm:
@@ -215,6 +220,8 @@ def main(args, tables=None, model=None):
                   "target": target, "start_indices": [s - c for c, s, _ in group]}
         if tabs.get("no_pad") is not None:
             sample["no_pad_in_target"] = tabs["no_pad"]
+        if args.batch_blocks > 0:
+            sample["blockwise_knn"] = True                       # kNN pairing of one-block batches (sequence_scorer.py)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         hypos = scorer.generate([model], sample, knn_dstore=knn_dstore, temperature=args.temperature) if args.knnlm \

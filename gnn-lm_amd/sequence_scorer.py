@@ -50,7 +50,10 @@ class SequenceScorer(object):
             kt = getattr(self.args, "knn_keytype", None)
             queries = extra[kt] if kt in extra else extra["inner_states"][-1]          # [T, B, C]  (:105)
             seq_len, b2, hidden = queries.shape
-            tq = orig_target.permute(0, 1).reshape(seq_len * b2)                        # as written (:117)
+            # as written (:117): targets in [B, T] order against queries in [T, B] order -- only right for B = 1, the recipe.
+            # The driver's --batch-blocks (several of the recipe's one-block batches per launch) asks for the pairing those
+            # one-block batches have: targets in the queries' order.
+            tq = (orig_target.transpose(0, 1) if sample.get("blockwise_knn") else orig_target.permute(0, 1)).reshape(seq_len * b2)
             lm_flat = probs.transpose(0, 1).reshape(-1)                                 # [T*B] like the queries
             mixed, _, rec = knn_model.interpolate(queries.contiguous().view(-1, hidden), tq.clamp(min=0),
                                                   lm_flat, temperature, lmbda)
