@@ -2,6 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export NQ=${NQ:-2048}
+rm -rf $R/gpurun_out/pmc_ivf1 $R/gpurun_out/pmc_ivf2
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_ivf1 --output-format csv -- python3 $R/tools/ivfpq_bench.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU -d $R/gpurun_out/pmc_ivf2 --output-format csv -- python3 $R/tools/ivfpq_bench.py > /dev/null 2>&1
 python3 - <<'PY'
