@@ -41,3 +41,43 @@ def test_star_attn_tab_repeatable_under_load():
         if it % 25 == 0 or it == 299:
             assert torch.equal(Z, Z0) and torch.equal(has, has0), it
     torch.cuda.synchronize()
+
+
+def test_gemm_hand_placed_loop_repeatable_under_load():
+    """The GEMM kernel whose k-loop is one inline-asm statement orders its LDS traffic with hand-written s_waitcnt / s_barrier
+    (staging registers written by buffer loads the compiler does not see, two LDS buffers, fragment reads a k-group ahead):
+    200 launches of a store problem and of a log-sum-exp problem must reproduce the first result bit for bit, with other
+    work queued in between -- and agree with the kernels that leave the schedule to the compiler (GNNLM_GEMM_SCHED=0)."""
+    import torch
+    from gnnlm_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    A = torch.randn(4099, 1024, generator=g, device=dev)
+    W = torch.randn(2100, 1024, generator=g, device=dev)
+    bias = torch.randn(2100, generator=g, device=dev)
+    pick = torch.randint(0, 2100, (4099,), generator=g, device=dev, dtype=torch.int32)
+    m_dev = torch.tensor([4000], dtype=torch.int32, device=dev)
+    C0 = ops.gemm_nt(A, W, bias=bias).clone()
+    l0, p0 = ops.gemm_lse(A, W, pick, alpha=0.05, m_dev=m_dev)
+    l0, p0 = l0.clone(), p0.clone()
+    noise = torch.randn(2048, 2048, device=dev)
+    for it in range(200):
+        if it % 5 == 0:
+            noise = noise @ noise.t() * 1e-4
+        C = ops.gemm_nt(A, W, bias=bias)
+        l, p = ops.gemm_lse(A, W, pick, alpha=0.05, m_dev=m_dev)
+        if it % 20 == 0 or it == 199:
+            assert torch.equal(C, C0), it
+            assert torch.equal(l[:4000], l0[:4000]) and torch.equal(p[:4000], p0[:4000]), it
+    torch.cuda.synchronize()
+    # same problem on the compiler-scheduled kernels (a fresh process: the switch is read once)
+    code = ("import torch, sys; sys.path.insert(0, %r); from gnnlm_amd import ops; g = torch.Generator(device='cuda:0'); g.manual_seed(11); "
+            "A = torch.randn(4099, 1024, generator=g, device='cuda:0'); W = torch.randn(2100, 1024, generator=g, device='cuda:0'); "
+            "bias = torch.randn(2100, generator=g, device='cuda:0'); torch.save(ops.gemm_nt(A, W, bias=bias).cpu(), sys.argv[1])" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "c.pt")
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=dict(os.environ, GNNLM_GEMM_SCHED="0"), timeout=600, cwd=ROOT)
+        ref = torch.load(f)
+    assert (C0.cpu() - ref).abs().max().item() < 2e-3             # same products, another summation order inside a stage
