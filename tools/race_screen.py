@@ -51,4 +51,14 @@ cen = R(M, 256, dsub)
 U = R(Tn, H, M * dsub) / 32
 ids = torch.randint(0, N, (Tn, kg), generator=g, device=dev)
 bad += screen("star attention (wave roles)", lambda: ops.star_attn(U, ids, codes=codes, centroids=cen))
+A6, W6, b6 = R(4099, 1024), R(2100, 1024), R(2100)
+pick6 = torch.randint(0, 2100, (4099,), generator=g, device=dev, dtype=torch.int32)
+bad += screen("store, hand-placed main loop (K = 1024)", lambda: ops.gemm_nt(A6, W6, bias=b6))
+bad += screen("LSE, hand-placed main loop (K = 1024)", lambda: ops.gemm_lse(A6, W6, pick6, alpha=0.05))
+# IVF-PQ search over the packed image: survivors are appended by atomics in any order, the selected neighbours may not depend on it
+from gnnlm_amd.synthetic import synthetic_ivfpq_index
+idx = synthetic_ivfpq_index(400_000, 256, 64, 64, dev, nprobe=8)
+q = R(300, 256)
+q = q / q.norm(dim=1, keepdim=True)
+bad += screen("IVF-PQ search, packed scan (M = 64)", lambda: idx.search_device(q, 256))
 sys.exit(1 if bad else 0)
