@@ -381,6 +381,7 @@ int gemm_nt(const GemmParams& desc, hipStream_t stream) {
     if (p.tile_order == 0)      // share the larger operand's panel between consecutive tiles
         p.tile_order = (!p.m_dev && (double)p.M > (double)p.N) ? 1 : 2;
     if (gemm_split_eligible(p)) return gemm_nt_split(p, stream);      // pre-split planes + LDS-DMA (gemm_split.hip)
+    if (gemm_skinny_eligible(p)) return gemm_nt_skinny(p, stream);    // narrow outputs: 32x32 tiles, k split over the waves (chosen from N, K only)
     const int64_t nb = (int64_t)p.batch1 * p.batch2;
     // 128x128 tiles unless they would leave CUs without a workgroup (256 CUs)
     const int64_t tiles128 = cdiv(p.M, 128) * cdiv(p.N, 128) * nb;

@@ -25,6 +25,8 @@ bool gemm_dma_eligible(const GemmParams& p);
 int gemm_nt_dma(const GemmParams& p, hipStream_t stream);
 bool gemm_sched_eligible(const GemmParams& p);
 int gemm_nt_sched(const GemmParams& p, hipStream_t stream);
+bool gemm_skinny_eligible(const GemmParams& p);
+int gemm_nt_skinny(const GemmParams& p, hipStream_t stream);
 // precision used by gemm_nt for descriptors that leave `precision` at 0 (set by the orchestrators)
 extern thread_local int g_default_gemm_precision;
 struct GemmPrecisionScope {

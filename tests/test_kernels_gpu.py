@@ -146,6 +146,8 @@ def test_gemm_lse_head_sized(ops, dev):
                                    (2100, 2050, 288),    # + the pre-split plane kernel for the bf16 modes
                                    (2100, 2050, 320),    # f32: the kernel with the hand-placed main loop (K % 64 == 0, >= 256 tiles)
                                    (250, 2050, 320),     # few tiles: the 64x64-tile kernel
+                                   (2100, 200, 512),     # f32: narrow output (N <= 256, K >= 512): 32x32 tiles, k split over the waves
+                                   (300, 64, 1024),      # the same on the shape of a tail projection with few live rows
                                    (700, 300, 100)])     # 64x64 tiles
 def test_gemm_full_contract(ops, dev, precision, tol, M, N, K):
     """Every epilogue option at once on each kernel variant: row gather with zero rows, scattered store +

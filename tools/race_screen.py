@@ -55,6 +55,9 @@ A6, W6, b6 = R(4099, 1024), R(2100, 1024), R(2100)
 pick6 = torch.randint(0, 2100, (4099,), generator=g, device=dev, dtype=torch.int32)
 bad += screen("store, hand-placed main loop (K = 1024)", lambda: ops.gemm_nt(A6, W6, bias=b6))
 bad += screen("LSE, hand-placed main loop (K = 1024)", lambda: ops.gemm_lse(A6, W6, pick6, alpha=0.05))
+A7, W7, b7 = R(1500, 1024), R(256, 1024), R(256)
+rows7 = torch.randint(0, 1500, (900,), generator=g, device=dev, dtype=torch.int32)
+bad += screen("store, narrow output, k split over waves", lambda: ops.gemm_nt(A7, W7, bias=b7, a_rows=rows7))
 # IVF-PQ search over the packed image: survivors are appended by atomics in any order, the selected neighbours may not depend on it
 from gnnlm_amd.synthetic import synthetic_ivfpq_index
 idx = synthetic_ivfpq_index(400_000, 256, 64, 64, dev, nprobe=8)
