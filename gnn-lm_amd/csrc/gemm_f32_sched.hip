@@ -98,6 +98,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
     GNNLM_LOAD_STAGE0(cur)
     while (true) {
         const int m0 = cur.m0, n0 = cur.n0, b1 = cur.b1, b2 = cur.b2;
+        // the tile's row maps (gathered problems): one row per thread, loaded now, landed long before the epilogue reads them
+        int map_c = 0, map_a = 0;
+        if (EPI == EPI_STORE && tid < BM && m0 + tid < M) {
+            if (p.c_rows) map_c = p.c_rows[m0 + tid];
+            if (p.a_rows) map_a = p.a_rows[m0 + tid];
+        }
         // stage 0 -> LDS buffer 0
 #define GNNLM_ST16(off_, v_) *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + lw + (off_)) = v_;
         GNNLM_ST16(0, sa0) GNNLM_ST16(4096, sa1) GNNLM_ST16(8192, sa2) GNNLM_ST16(12288, sa3)
@@ -155,6 +161,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
         }
 #undef GNNLM_SCHED_OPERANDS
         __syncthreads();                                               // every wave left the loop: the LDS image is free
+        int* rowmap_c = reinterpret_cast<int*>(lds) + 256;             // behind the LSE epilogue's pick staging (BM ints)
+        int* rowmap_a = rowmap_c + BM;
+        if (EPI == EPI_STORE && (p.c_rows || p.a_rows)) {
+            if (tid < BM) { rowmap_c[tid] = map_c; rowmap_a[tid] = map_a; }
+            __syncthreads();
+        }
 
         // the next tile's first stage travels under this tile's epilogue
         const unsigned vn = v + gridDim.x;
@@ -164,7 +176,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
             setup(vn, nxt);
             GNNLM_LOAD_STAGE0(nxt)
         }
+#define GNNLM_EPI_ROWMAP
 #include "gemm_epilogue.inc"
+#undef GNNLM_EPI_ROWMAP
         __syncthreads();
         if (!more) break;
         cur = nxt;
