@@ -100,9 +100,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
         const int m0 = cur.m0, n0 = cur.n0, b1 = cur.b1, b2 = cur.b2;
         // the tile's row maps (gathered problems): one row per thread, loaded now, landed long before the epilogue reads them
         int map_c = 0, map_a = 0;
+        float map_g = 1.f;
         if (EPI == EPI_STORE && tid < BM && m0 + tid < M) {
             if (p.c_rows) map_c = p.c_rows[m0 + tid];
             if (p.a_rows) map_a = p.a_rows[m0 + tid];
+            if (p.gate) map_g = p.gate[m0 + tid];
+        }
+        // ... and the per-column bias of this lane's two columns: with both in hand the store epilogue issues no load of its
+        // own, so it does not wait (in-order vmcnt) for the next tile's first stage that is requested just before it
+        float bias_reg[TN] = {0.f, 0.f};
+        if (EPI == EPI_STORE && p.bias && p.bias_mode == 1) {
+            const float* bp = p.bias + b1 * p.sB1 + b2 * p.sB2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WCOLS + j * 32 + l32;
+                bias_reg[j] = col < p.N ? bp[col] : 0.f;
+            }
         }
         // stage 0 -> LDS buffer 0
 #define GNNLM_ST16(off_, v_) *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds) + lw + (off_)) = v_;
@@ -163,8 +176,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
         __syncthreads();                                               // every wave left the loop: the LDS image is free
         int* rowmap_c = reinterpret_cast<int*>(lds) + 256;             // behind the LSE epilogue's pick staging (BM ints)
         int* rowmap_a = rowmap_c + BM;
-        if (EPI == EPI_STORE && (p.c_rows || p.a_rows)) {
-            if (tid < BM) { rowmap_c[tid] = map_c; rowmap_a[tid] = map_a; }
+        float* rowmap_g = reinterpret_cast<float*>(rowmap_a + BM);
+        if (EPI == EPI_STORE && (p.c_rows || p.a_rows || p.gate)) {
+            if (tid < BM) { rowmap_c[tid] = map_c; rowmap_a[tid] = map_a; rowmap_g[tid] = map_g; }
             __syncthreads();
         }
 
@@ -177,7 +191,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
             GNNLM_LOAD_STAGE0(nxt)
         }
 #define GNNLM_EPI_ROWMAP
+#define GNNLM_EPI_BIAS_REG
 #include "gemm_epilogue.inc"
+#undef GNNLM_EPI_BIAS_REG
 #undef GNNLM_EPI_ROWMAP
         __syncthreads();
         if (!more) break;
