@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
         }
 #undef GNNLM_SCHED_OPERANDS
         __syncthreads();                                               // every wave left the loop: the LDS image is free
-        int* rowmap_c = reinterpret_cast<int*>(lds) + 256;             // behind the LSE epilogue's pick staging (BM ints)
+        // in LDS buffer 1: the next tile's stage 0 goes to buffer 0 and buffer 1 is first written at the end of its stage 0, behind
+        // the barrier every wave passes after its own epilogue -- so the store epilogue needs no barrier of its own behind it
+        int* rowmap_c = reinterpret_cast<int*>(lds) + 8192;
         int* rowmap_a = rowmap_c + BM;
         float* rowmap_g = reinterpret_cast<float*>(rowmap_a + BM);
         if (EPI == EPI_STORE && (p.c_rows || p.a_rows || p.gate)) {
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
 #include "gemm_epilogue.inc"
 #undef GNNLM_EPI_BIAS_REG
 #undef GNNLM_EPI_ROWMAP
-        __syncthreads();
+        if (EPI == EPI_LSE) __syncthreads();                          // its pick staging sits in buffer 0
         if (!more) break;
         cur = nxt;
         v = vn;
