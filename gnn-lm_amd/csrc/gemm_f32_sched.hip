@@ -218,7 +218,8 @@ bool gemm_sched_eligible(const GemmParams& p) {
     // the softmax head (>= 2048 tiles of 256x256) runs in the same time here as on the 256x256 LDS-DMA kernel (2.47 ms), but
     // with 128-wide W panels it pulls the A panel through the fabric twice as often (PMC FETCH_SIZE 2.9 vs 1.4 GB): stays there
     if (p.lse_part && !p.m_dev && !(on & 4) && cdiv(p.M, 256) * cdiv(p.N, 256) >= 2048) return false;
-    if (p.K % 64 != 0 || p.K < 256) return false;                       // K = 128 (absorbed queries): 191 us on the register-staged kernel, 206 here
+    static const int min_k = [] { const char* e = getenv("GNNLM_GEMM_SCHED_MINK"); return e ? atoi(e) : 256; }();
+    if (p.K % 64 != 0 || p.K < min_k) return false;                       // K = 128 (absorbed queries): 191 us on the register-staged kernel, 206 here
     const int64_t nb = (int64_t)p.batch1 * p.batch2;
     if (cdiv(p.M, 128) * cdiv(p.N, 128) * nb < 256) return false;
     // rows are addressed by 32-bit byte offsets from the panel base of the tile's batch
