@@ -566,3 +566,19 @@ def test_star_attn_mapped_shards(ops, dev):
     keep = (ids >= lo) & (ids < hi)
     Z3, _ = ops.star_attn(U, torch.where(keep, ids, torch.full_like(ids, -1)), codes=codes, centroids=cen)
     assert torch.equal(Z2, Z3)
+
+
+def test_gemm_per_row_bias_on_large_tiles(ops, dev):
+    """bias_mode 2 (one bias per row, gated) and a residual on a problem that takes the hand-placed-loop kernel: its store
+    epilogue keeps per-column biases in registers and row maps / gates in LDS, the per-row bias and the residual are still
+    read from memory."""
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 2200, 2100, 320
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    bias = torch.randn(M, generator=g)
+    gate = (torch.rand(M, generator=g) < 0.6).float() * 0.5
+    R = torch.randn(M, N, generator=g)
+    out = ops.gemm_nt(A.to(dev), W.to(dev), bias=bias.to(dev), bias_mode=2, gate=gate.to(dev), residual=R.to(dev), alpha=1.25).cpu()
+    ref = 1.25 * (A.double() @ W.double().t()) + (gate.double() * bias.double())[:, None] + R.double()
+    scale = 1.25 * (A.abs().double() @ W.abs().double().t()) + R.abs().double() + 1.0
+    assert ((out.double() - ref).abs() / scale).max() < 5e-7
