@@ -91,6 +91,10 @@ __global__ __launch_bounds__(BT == 256 ? 512 : 256, BT == 256 ? 1 : (BK == 16 ? 
             tm = band * GM + r % m_in;
         }
         const int m0 = tm * BM, n0 = tn * BN;
+        // log-sum-exp problems: the tile's pick columns are requested now and staged in LDS behind the k-loop -- loaded in the
+        // epilogue they cost the whole workgroup a memory round trip per tile
+        int pick_reg = -1;
+        if (EPI == EPI_LSE && tid < BM && p.lse_pick && m0 + tid < M) pick_reg = p.lse_pick[m0 + tid];
         const float* A = p.A + b1 * p.sA1 + b2 * p.sA2;
         const float* W = p.W + b1 * p.sW1 + b2 * p.sW2;
 
@@ -162,7 +166,13 @@ __global__ __launch_bounds__(BT == 256 ? 512 : 256, BT == 256 ? 1 : (BK == 16 ? 
         }
 #undef GNNLM_ISSUE
 
+        if (EPI == EPI_LSE) {
+            if (tid < BM) reinterpret_cast<int*>(lds)[tid] = pick_reg;          // the k-loop's last barrier freed the buffer
+            __syncthreads();
+        }
+#define GNNLM_LSE_PICK_STAGED
 #include "gemm_epilogue.inc"
+#undef GNNLM_LSE_PICK_STAGED
         __syncthreads();
     }
 #undef GNNLM_SWZ

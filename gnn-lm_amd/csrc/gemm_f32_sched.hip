@@ -108,6 +108,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
         }
         // ... and the per-column bias of this lane's two columns: with both in hand the store epilogue issues no load of its
         // own, so it does not wait (in-order vmcnt) for the next tile's first stage that is requested just before it
+        int pick_reg = -1;                                             // log-sum-exp problems: the tile's pick columns, likewise
+        if (EPI == EPI_LSE && tid < BM && p.lse_pick && m0 + tid < M) pick_reg = p.lse_pick[m0 + tid];
         float bias_reg[TN] = {0.f, 0.f};
         if (EPI == EPI_STORE && p.bias && p.bias_mode == 1) {
             const float* bp = p.bias + b1 * p.sB1 + b2 * p.sB2;
@@ -192,9 +194,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_sched_kernel(const GemmPar
             setup(vn, nxt);
             GNNLM_LOAD_STAGE0(nxt)
         }
+        if (EPI == EPI_LSE) {
+            if (tid < BM) reinterpret_cast<int*>(lds)[tid] = pick_reg;
+            __syncthreads();
+        }
 #define GNNLM_EPI_ROWMAP
 #define GNNLM_EPI_BIAS_REG
+#define GNNLM_LSE_PICK_STAGED
 #include "gemm_epilogue.inc"
+#undef GNNLM_LSE_PICK_STAGED
 #undef GNNLM_EPI_BIAS_REG
 #undef GNNLM_EPI_ROWMAP
         if (EPI == EPI_LSE) __syncthreads();                          // its pick staging sits in buffer 0
