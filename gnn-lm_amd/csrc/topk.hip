@@ -102,18 +102,74 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(TopkParams p) {
 
     const float* srow = p.scores + row * p.ld;
     const int ncols = p.row_ncols ? min(p.ncols, p.row_ncols[row]) : p.ncols;
+    // Wide first chunks (the dense round of an IVF search: k = 1024 of ~50 k scores) would pass ~k (1 + ln(n / k)) candidates
+    // through ~8 sort-and-merge rounds before the running threshold tightens.  A counting pre-pass bounds the threshold
+    // first: a histogram of the row over NB value bins (range from a sample, out-of-range values clamp: the bin function is
+    // monotone whatever the sample says), b* = the highest bin with at least k values in bins >= b*; the selection pass then
+    // only admits values of bins >= b* -- every one of the k best is among them, ~k plus one bin's population in all.
+    constexpr int NB = 1024;
+    __shared__ int hist[NB];
+    __shared__ int rng[2];                           // order-preserving integer images of the sample's min / max
+    __shared__ int bstar_s;
+    const bool presel = p.init && ncols >= 8 * KP;
+    float b_lo = 0.f, b_scale = 0.f;
+    int bstar = 0;
+    auto value_of = [&](int c, float& v, int64_t& cid) {
+        v = srow[c] * p.alpha;
+        if (p.col_scale) v *= p.col_scale[c];
+        if (p.col_bias) v += p.col_bias[c];
+        v *= sign;
+        cid = p.ids ? p.ids[row * p.ld_ids + c] : (p.col_ids ? p.col_ids[c] : p.col0 + c);
+    };
+    auto bin_of = [&](float v) { return (int)fminf(fmaxf((v - b_lo) * b_scale, 0.f), (float)(NB - 1)); };
+    if (presel) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int c = tid; c < min(ncols, 4096); c += NT) {
+            float v; int64_t cid;
+            value_of(c, v, cid);
+            if (cid >= 0 && v > NEG && v < INFINITY) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+        }
+        for (int e = tid; e < NB; e += NT) hist[e] = 0;
+        if (tid == 0) { rng[0] = 0x7fffffff; rng[1] = (int)0x80000000; }
+        __syncthreads();
+        // order-preserving integer image of a float: atomicMin / atomicMax on it
+        auto ord = [](float x) { const int i = __float_as_int(x); return i >= 0 ? i : i ^ 0x7fffffff; };
+        if (lo <= hi) {
+            atomicMin(&rng[0], ord(lo));
+            atomicMax(&rng[1], ord(hi));
+        }
+        __syncthreads();
+        auto unord = [](int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); };
+        const bool have_range = rng[0] <= rng[1];
+        const float r_lo = have_range ? unord(rng[0]) : 0.f, r_hi = have_range ? unord(rng[1]) : 0.f;
+        b_lo = r_lo;
+        b_scale = (r_hi > r_lo) ? (float)NB / (r_hi - r_lo) : 0.f;
+        for (int c = tid; c < ncols; c += NT) {
+            float v; int64_t cid;
+            value_of(c, v, cid);
+            if (cid >= 0 && v > NEG) atomicAdd(&hist[bin_of(v)], 1);
+        }
+        __syncthreads();
+        // b*: the highest bin whose suffix count reaches k (0 if the row has fewer than k values): thread t owns bins
+        // [4 t, 4 t + 4), suffix sums of the per-thread totals by a scan over LDS
+        if (tid == 0) {
+            int acc_ = 0, b = NB - 1;
+            for (; b > 0; --b) { acc_ += hist[b]; if (acc_ >= p.k) break; }
+            bstar_s = b;
+        }
+        __syncthreads();
+        bstar = bstar_s;
+    }
     static_assert(KP >= NT, "a sub-block of NT columns must fit the candidate half");
     constexpr int SB = KP / 2 >= NT ? KP / 2 : NT;                      // columns per sub-block: at most SB new candidates
     for (int c0 = 0; c0 < ncols; c0 += SB) {
         if (cnt + SB > KP) flush();                                     // uniform: cnt is read after a barrier
         for (int c = c0 + tid; c < min(ncols, c0 + SB); c += NT) {
-            float v = srow[c] * p.alpha;
-            if (p.col_scale) v *= p.col_scale[c];
-            if (p.col_bias) v += p.col_bias[c];
-            v *= sign;
-            const int64_t cid = p.ids ? p.ids[row * p.ld_ids + c] : (p.col_ids ? p.col_ids[c] : p.col0 + c);
+            float v;
+            int64_t cid;
+            value_of(c, v, cid);
             // strictly better than the k-th best, or tied with it and earlier (tau's id is not tracked: keep ties, the merge decides)
-            if (cid >= 0 && v >= tau && v > NEG) {
+            if (cid >= 0 && v >= tau && v > NEG && (!presel || bin_of(v) >= bstar)) {
                 const int pos = atomicAdd(&cnt, 1);
                 val[KP + pos] = v;
                 id[KP + pos] = cid;

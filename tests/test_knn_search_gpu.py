@@ -48,6 +48,36 @@ def test_topk_merge_chunked(dev, k, largest):
     np.testing.assert_allclose(bv.cpu().numpy(), v_ref, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("k", [70, 1024])
+@pytest.mark.parametrize("largest", [True, False])
+def test_topk_merge_wide_first_chunk(dev, k, largest):
+    """One wide first chunk (the dense round of an IVF search): the counting pre-pass (value histogram -> admitted bins)
+    may not change the selection -- exact ids with ties by ascending id, heavy ties at the k-th place, a constant row, a
+    row with fewer valid columns than k, values far outside the sampled range."""
+    from gnnlm_amd import ops
+    rs = np.random.RandomState(7 * k + largest)
+    n, N = 9, 20000
+    scores = rs.randn(n, N).astype(np.float32)
+    scores[:, ::40] = scores[:, 1::40]                                   # exact ties across columns
+    scores[1] = np.round(scores[1] * 2) / 2                               # a few distinct values: thousands of ties at the k-th place
+    scores[2] = 0.25                                                      # constant row
+    scores[3, 5000:] *= 1000.0                                            # the first 4096 columns (the sampled range) miss the tail
+    col_ids = np.arange(N, dtype=np.int64) + 7
+    ncols = np.full(n, N, dtype=np.int32)
+    ncols[4] = k // 2                                                     # fewer columns than k
+    bv = torch.empty(n, k, device=dev)
+    bi = torch.empty(n, k, device=dev, dtype=torch.int64)
+    ops.topk_merge(torch.from_numpy(scores).to(dev), bv, bi, col_ids=torch.from_numpy(col_ids).to(dev), largest=largest, init=True,
+                   row_ncols=torch.from_numpy(ncols).to(dev))
+    bv, bi = bv.cpu().numpy(), bi.cpu().numpy()
+    for r in range(n):
+        m = min(k, int(ncols[r]))
+        v, i = ref_topk(scores[r, :ncols[r]], col_ids[:ncols[r]], k, largest)
+        assert np.array_equal(bi[r, :m], i[:m]), r
+        np.testing.assert_array_equal(bv[r, :m], v[:m])
+        assert (bi[r, m:] == -1).all()
+
+
 def test_topk_merge_fewer_than_k_and_explicit_ids(dev):
     from gnnlm_amd import ops
     rs = np.random.RandomState(3)
