@@ -310,7 +310,7 @@ def driver_path(args, eng, batches, dev):
     """tokens/s of the DROP-IN path: `eval_lm.main` -> `SequenceScorer.generate` -> hypotheses -> score sum, the
     reference's own loop and timer (fairseq_cli/eval_lm.py:208-331: `seconds` = time inside generate, `wall` = the
     whole loop), one 256-token block per batch as in the recipe (--max-tokens 256), `--max-tokens` = the bench's
-    batch, and the recipe's command plus `--batch-blocks 32` (this build's flag: the one-block batches, 32 per launch).  The tables are the bench's HBM-resident ones (the driver normally uploads them from the data directory)."""
+    batch, and the recipe's command as it stands (`--batch-blocks` at its default: the one-block batches, 32 per launch).  The tables are the bench's HBM-resident ones (the driver normally uploads them from the data directory)."""
     from gnnlm_amd import eval_lm
     from gnnlm_amd.model import GnnLmModel
     st = eng.store
@@ -351,7 +351,7 @@ def driver_path(args, eng, batches, dev):
     tabs = {"n_tok": n, "d": eng.hgt.hidden_dim, "vocab": None, "n_store": st.n_store, "feats": b0.tgt_feats[:n],
             "targets": b0.targets[:n].clamp(min=4), "nbrs": b0.ids[:n], "codes": st.codes, "no_pad": True}
     out = {}
-    for name, max_tokens, coalesce in (("one_block_per_batch", T, 0), ("bench_batch", nb, 0), ("one_block_batches_coalesced", T, nblk)):
+    for name, max_tokens, coalesce in (("one_block_per_batch", T, 0), ("bench_batch", nb, 0), ("one_block_batches_coalesced", T, -1)):
         a = eval_lm.get_parser().parse_args(
             ["-", "--path", "-", "--graph", "--use-precompute-feat", "--neighbor-context", "2", "--gcn-k", str(args.gcn_k),
              "--tokens-per-sample", str(T), "--max-tokens", str(max_tokens), "--knnlm", "--k", str(args.k), "--lmbda",
@@ -365,7 +365,7 @@ def driver_path(args, eng, batches, dev):
             a.knn_model = Knn()
             r = eval_lm.main(a, tables=tabs, model=model)
         out[name] = {"tokens": r["tokens"], "tokens_per_s_generate_timer": round(r["tokens"] / r["seconds"], 1),
-                     "tokens_per_s_wall": round(r["tokens"] / r["wall_seconds"], 1), "blocks_per_batch": max(max_tokens // T, coalesce)}
+                     "tokens_per_s_wall": round(r["tokens"] / r["wall_seconds"], 1), "blocks_per_batch": max(max_tokens // T, 32 if coalesce < 0 else coalesce)}
     return out
 
 

@@ -57,10 +57,11 @@ def get_parser():
     p.add_argument("--tokens-per-sample", default=1024, type=int)
     p.add_argument("--max-tokens", default=None, type=int)
     p.add_argument("--max-sentences", default=None, type=int)
-    p.add_argument("--batch-blocks", default=0, type=int,
-                   help="(this build) score at least this many blocks per launch whatever --max-tokens says: blocks are independent, "
-                        "so the hypotheses, their order and the scores are those of the one-block batches of the recipe; "
-                        "32 turns the recipe's `--max-tokens 256` run from launch-bound into the bench's batch")
+    p.add_argument("--batch-blocks", default=-1, type=int,
+                   help="(this build) score this many of the batches' blocks per launch whatever --max-tokens says: blocks are "
+                        "independent, so the hypotheses, their order and the scores are those of the one-block batches of the "
+                        "recipe (`--max-tokens 256`), which alone are launch-bound on this part.  -1 (default): 32 when "
+                        "--max-tokens gives one block per batch, else off; 0: off")
     p.add_argument("--softmax-batch", default=sys.maxsize, type=int)
     p.add_argument("--context-window", default=0, type=int)
     p.add_argument("--model-overrides", default="{}")
@@ -168,6 +169,8 @@ def main(args, tables=None, model=None):
     per_batch = max(1, (args.max_tokens or 36000) // max(1, T + args.gcn_context_window))
     if args.max_sentences:
         per_batch = min(per_batch, args.max_sentences)
+    if args.batch_blocks < 0:                       # auto: only the one-block batches of the recipe are coalesced -- with B > 1 per
+        args.batch_blocks = 32 if per_batch == 1 else 0     # batch the reference's scorer has its own target / query pairing
     per_batch = max(per_batch, args.batch_blocks)
     scorer = SequenceScorer(_Dict(), args.softmax_batch, args=args)
     knn_dstore = None

@@ -264,8 +264,10 @@ def test_eval_lm_end_to_end(dev, tmp_path):
     # --batch-blocks (this build): several of those one-block batches per launch, same scores (incl. the kNN pairing)
     knn_args = ["--knnlm", "--k", str(k), "--lmbda", str(lam), "--dstore-dir", str(data / "train_dstore"),
                 "--index-file", str(data / "train_dstore" / "faiss_store.cosine"), "--temperature", str(temp), "--knn-sim-func", "ip"]
-    res4 = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", "4"])
-    assert res4["count"] == n_test and abs(res4["score_sum"] - res["score_sum"]) < 1e-6 * n_test
+    # (default: one-block batches are scored 32 per launch -- `res` above; 0 switches that off, N sets the group size)
+    for nb_ in ("0", "4"):
+        res4 = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", nb_])
+        assert res4["count"] == n_test and abs(res4["score_sum"] - res["score_sum"]) < 1e-6 * n_test
     # --num-shards / --shard-id partition the blocks (eval_lm.py:131-132)
     parts = [eval_lm.cli_main(base + ["--num-shards", "2", "--shard-id", str(i)]) for i in range(2)]
     assert sum(p["count"] for p in parts) == n_test
