@@ -61,7 +61,7 @@ def get_parser():
                    help="(this build) score this many of the batches' blocks per launch whatever --max-tokens says: blocks are "
                         "independent, so the hypotheses, their order and the scores are those of the one-block batches of the "
                         "recipe (`--max-tokens 256`), which alone are launch-bound on this part.  -1 (default): 32 when "
-                        "--max-tokens gives one block per batch, else off; 0: off")
+                        "--max-tokens gives one block per batch (4 for models with more than one HGT layer), else off; 0: off")
     p.add_argument("--softmax-batch", default=sys.maxsize, type=int)
     p.add_argument("--context-window", default=0, type=int)
     p.add_argument("--model-overrides", default="{}")
@@ -170,7 +170,10 @@ def main(args, tables=None, model=None):
     if args.max_sentences:
         per_batch = min(per_batch, args.max_sentences)
     if args.batch_blocks < 0:                       # auto: only the one-block batches of the recipe are coalesced -- with B > 1 per
-        args.batch_blocks = 32 if per_batch == 1 else 0     # batch the reference's scorer has its own target / query pairing
+        # batch the reference's scorer has its own target / query pairing.  32 blocks at one HGT layer (the step is launch-bound
+        # below that); deeper models carry (1 + l + r) k_g rows of state per token and layer and fill the chip from 4 blocks on
+        deep = getattr(getattr(model, "hgt_decoder", None), "n_layers", 1) > 1
+        args.batch_blocks = (4 if deep else 32) if per_batch == 1 else 0
     per_batch = max(per_batch, args.batch_blocks)
     scorer = SequenceScorer(_Dict(), args.softmax_batch, args=args)
     knn_dstore = None
