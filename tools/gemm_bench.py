@@ -33,7 +33,7 @@ for name, M, N, K, b1, b2 in [s_ for s_ in SHAPES if sel in s_[0]]:
     W = torch.randn(nb * N, K, device=dev)
     C = torch.empty(nb * M, N, device=dev)
     g = _lib.gnnlm_gemm_t()
-    g.A, g.lda, g.W, g.ldw, g.C, g.ldc = A.data_ptr(), (0 if os.environ.get("LDA0") else K), W.data_ptr(), K, C.data_ptr(), N   # LDA0=1: every row reads row 0 (a cache-resident A panel: what streaming A costs)
+    g.A, g.lda, g.W, g.ldw, g.C, g.ldc = A.data_ptr(), (0 if os.environ.get("LDA0") else K), W.data_ptr(), K, C.data_ptr(), (0 if os.environ.get("LDC0") else N)   # LDC0=1: every row is stored to row 0 (no HBM write stream: what the stores cost); LDA0=1: every row reads row 0 (a cache-resident A panel: what streaming A costs)
     g.M, g.N, g.K, g.batch1, g.batch2 = M, N, K, b1, b2
     g.tile_order = ORDER
     g.precision = PREC
