@@ -104,6 +104,7 @@ def lib():
         L.gnnlm_causal_attn.argtypes = [vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]
         L.gnnlm_layernorm.argtypes = [vp, i64, vp, vp, vp, i64, i64, i32, f32, vp, vp]
         L.gnnlm_half_to_float.argtypes = [vp, vp, i64, vp]
+        L.gnnlm_filter_neighbors.argtypes = [vp, vp, i64, i32, i64, vp, vp]
         L.gnnlm_gelu.argtypes = [vp, i64, vp]
         L.gnnlm_row_lse_pick.argtypes = [vp, i64, i64, vp, i32, vp, vp, vp, vp]
         L.gnnlm_lse_reduce.argtypes = [vp, i32, i64, vp, vp, vp]

@@ -188,6 +188,11 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
                   "hgt: ntgt_feats needs ntgt_valid, ld_ntgt >= d (a multiple of 4) and no fetched_codes");
     const bool ntgt = needs_ntgt(m, io);
     GNNLM_REQUIRE(!(io.fetched_centres_only && ntgt), "hgt: fetched_centres_only needs n_layers == 1 and no out_ntgt");
+    // the ntgt update keeps a context group in registers / on the stack (chain attention, the row-subset selections) and
+    // addresses slot rows with 32-bit indices
+    GNNLM_REQUIRE(!ntgt || (m.left >= 0 && m.right >= 0 && 1 + m.left + m.right <= 8), "hgt: ntgt update needs 1 + left + right <= 8");
+    GNNLM_REQUIRE(!ntgt || (int64_t)io.n_blocks * io.T * io.kg * (1 + m.left + m.right) < (1ll << 31),
+                  "hgt: ntgt update needs n_blocks * T * k_g * (1 + left + right) < 2^31 slot rows per call");
     GNNLM_REQUIRE(!io.fetched_codes || io.fetched_valid || io.fetched_centres_only, "hgt: fetched_codes needs fetched_valid");
     const int64_t Tt = (int64_t)io.n_blocks * io.T;
     if (Tt == 0) return OK;
@@ -559,6 +564,10 @@ int gnnlm_layernorm(const float* x, int64_t ldx, const float* gamma, const float
     return layernorm(x, ldx, gamma, beta, out, ldo, rows, d, eps, valid, (hipStream_t)stream);
 }
 int gnnlm_gelu(float* x, int64_t n, void* stream) { return gelu(x, n, (hipStream_t)stream); }
+int gnnlm_filter_neighbors(const int64_t* ids, const int64_t* tok_pos, int64_t n_tok, int32_t kg, int64_t invalid_ctx, int64_t* out,
+                           void* stream) {
+    return filter_neighbors(ids, tok_pos, n_tok, kg, invalid_ctx, out, (hipStream_t)stream);
+}
 int gnnlm_half_to_float(const void* src, float* dst, int64_t n, void* stream) {
     return half_to_float(src, dst, n, (hipStream_t)stream);
 }

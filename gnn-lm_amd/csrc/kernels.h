@@ -101,6 +101,9 @@ int mean2(const float* a, const float* b, float* out, int64_t n, hipStream_t str
 
 int gelu(float* x, int64_t n, hipStream_t stream);
 
+// the --invalid-neighbor-context rule of token_block_dataset.py:360-362 applied to a batch of neighbour-id rows
+int filter_neighbors(const int64_t* ids, const int64_t* pos, int64_t n, int kg, int64_t ctx, int64_t* out, hipStream_t stream);
+
 // fp16 -> fp32 row convert
 int half_to_float(const void* src, float* dst, int64_t n, hipStream_t stream);
 

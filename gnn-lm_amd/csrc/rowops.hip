@@ -88,6 +88,14 @@ __global__ void half_to_float_kernel(const __half* src, float* dst, int64_t n) {
     if (i < n) dst[i] = __half2float(src[i]);
 }
 
+// out[i, j] = -1 where the neighbour lies inside its own token's context (|pos[i] - ids[i, j]| < ctx), else ids[i, j]
+__global__ void filter_neighbors_kernel(const int64_t* ids, const int64_t* pos, int64_t n, int kg, int64_t ctx, int64_t* out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * kg) return;
+    const int64_t id = ids[e], dlt = pos[e / kg] - id;
+    out[e] = (id != -1 && (dlt < 0 ? -dlt : dlt) < ctx) ? (int64_t)-1 : id;
+}
+
 // one workgroup per row: lse = logsumexp(row[:n]), picked = row[pick]
 __global__ __launch_bounds__(256) void row_lse_pick_kernel(const float* logits, int64_t ld, int64_t rows,
                                                            const int32_t* m_dev, int n, const int32_t* pick,
@@ -367,6 +375,16 @@ int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta
 int mean2(const float* a, const float* b, float* out, int64_t n, hipStream_t stream) {
     if (n == 0) return OK;
     hipLaunchKernelGGL(mean2_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, a, b, out, n);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int filter_neighbors(const int64_t* ids, const int64_t* pos, int64_t n, int kg, int64_t ctx, int64_t* out, hipStream_t stream) {
+    GNNLM_REQUIRE(n >= 0 && kg > 0 && ctx >= 0, "filter_neighbors: bad shape");
+    if (n == 0) return OK;
+    GNNLM_REQUIRE(ids && pos && out, "filter_neighbors: null");
+    GNNLM_REQUIRE(cdiv(n * kg, (int64_t)256) < (1ll << 31), "filter_neighbors: too many ids for one launch");
+    hipLaunchKernelGGL(filter_neighbors_kernel, dim3((unsigned)cdiv(n * kg, (int64_t)256)), dim3(256), 0, stream, ids, pos, n, kg, ctx, out);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

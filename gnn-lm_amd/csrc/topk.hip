@@ -163,7 +163,12 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(TopkParams p) {
     static_assert(KP >= NT, "a sub-block of NT columns must fit the candidate half");
     constexpr int SB = KP / 2 >= NT ? KP / 2 : NT;                      // columns per sub-block: at most SB new candidates
     for (int c0 = 0; c0 < ncols; c0 += SB) {
-        if (cnt + SB > KP) flush();                                     // uniform: cnt is read after a barrier
+        // every thread takes its copy of cnt BEFORE any thread of this iteration can bump it (the barrier below separates the
+        // read from the atomicAdds): a wave that runs late would otherwise see a larger count, take flush() alone and pair its
+        // barriers with the wrong ones
+        const int cur = cnt;
+        __syncthreads();
+        if (cur + SB > KP) flush();
         for (int c = c0 + tid; c < min(ncols, c0 + SB); c += NT) {
             float v;
             int64_t cid;

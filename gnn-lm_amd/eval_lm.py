@@ -147,9 +147,6 @@ def main(args, tables=None, model=None):
         # LMContextWindowDataset (fairseq/data/lm_context_window_dataset.py) prepends context tokens and scores only the
         # new ones; shrinking the block without the prefix would silently give another ppl
         raise NotImplementedError("--context-window > 0 is not built (the GNN-LM recipes use --gcn-context-window)")
-    if args.gen_subset == "train" and args.invalid_neighbor_context > 0:
-        raise NotImplementedError("--gen-subset train with --invalid-neighbor-context > 0 (neighbours inside the token's "
-                                  "own context are dropped, token_block_dataset.py:361-368) is not built")
     if args.fp16:
         logger.warning("--fp16 ignored: the HIP path computes in float32")
     device = torch.device(args.device)
@@ -175,6 +172,9 @@ def main(args, tables=None, model=None):
         deep = getattr(getattr(model, "hgt_decoder", None), "n_layers", 1) > 1
         args.batch_blocks = (4 if deep else 32) if per_batch == 1 else 0
     per_batch = max(per_batch, args.batch_blocks)
+    # neighbours inside the token's own context are dropped on the TRAIN split only (language_modeling.py:299,
+    # token_block_dataset.py:360-362): the split whose GNN features the kNN index is built over (find_knn.sh:7)
+    invalid_ctx = args.invalid_neighbor_context if args.gen_subset == "train" else 0
     scorer = SequenceScorer(_Dict(), args.softmax_batch, args=args)
     knn_dstore = None
     if args.knnlm:
@@ -186,7 +186,12 @@ def main(args, tables=None, model=None):
     # (`--knn-keytype`, here the HGT output "gcn_feat") and the target tokens, written as the split's datastore
     save = None
     if args.save_knnlm_dstore:
-        dstore_size, dim = int(tabs["n_tok"]), int(tabs["d"])              # dataset.sizes.sum() (:104)
+        dstore_size = int(tabs["n_tok"])                                   # dataset.sizes.sum() (:104)
+        # key dimension = what the scorer hands back for --knn-keytype: the HGT output ("gcn_feat", out_dim of the output
+        # adapter if there is one) or the precomputed features (the inner_states[-1] fallback, sequence_scorer.py:105)
+        hd = getattr(model, "hgt_decoder", None)
+        dim = int(getattr(hd, "out_dim", tabs["d"])) if (args.knn_keytype == "gcn_feat" and not getattr(model, "short_cut", False)) \
+            else int(tabs["d"])
         fp16 = bool(args.dstore_fp16)
         suffix = "" if not args.knn_keytype else f"-{args.knn_keytype}"
         save_dir = os.path.join(args.dstore_mmap, f"{args.gen_subset}_dstore{suffix}")
@@ -219,7 +224,11 @@ def main(args, tables=None, model=None):
         else:
             idx = torch.cat([torch.arange(c, e, device=device) for c, _, e in group])
         target = tabs["targets"][idx].view(len(group), L)
-        graph = NeighborGraph(ids=tabs["nbrs"][idx].contiguous(), n_blocks=len(group), T=L, left=left, right=right,
+        nb_ids = tabs["nbrs"][idx].contiguous()
+        if invalid_ctx > 0:
+            tok_pos = torch.arange(idx.start, idx.stop, device=device) if isinstance(idx, slice) else idx     # global offsets in the split
+            nb_ids = ops.filter_neighbors(nb_ids, tok_pos.contiguous(), invalid_ctx)
+        graph = NeighborGraph(ids=nb_ids, n_blocks=len(group), T=L, left=left, right=right,
                               store=store, tgt_h=tabs["feats"][idx].contiguous(), max_intra_context=args.intra_context)
         sample = {"id": torch.arange(len(group)), "nsentences": len(group), "ntokens": len(group) * L,
                   "net_input": {"src_tokens": target, "src_lengths": torch.full((len(group),), L), "graph": graph},
@@ -236,7 +245,10 @@ def main(args, tables=None, model=None):
         timers.append((ev0, ev1))
         ntok += sample["ntokens"]
         if save is not None:                                     # one device -> host copy per batch (this run is a writer anyway)
-            keys = torch.cat([h[0]["dstore_keys"].reshape(-1, save["dim"]) for h in hypos])
+            kd = hypos[0][0]["dstore_keys"].shape[-1]
+            if kd != save["dim"]:
+                raise ValueError(f"--save-knnlm-dstore: the scorer returned {kd}-dimensional keys, the datastore was opened for {save['dim']}")
+            keys = torch.cat([h[0]["dstore_keys"].reshape(-1, kd) for h in hypos])
             toks = torch.cat([h[0]["tokens"].reshape(-1) for h in hypos])
             n_new = min(keys.shape[0], save["size"] - save["idx"])
             if n_new < keys.shape[0]:

@@ -255,6 +255,18 @@ def half_to_float(x):
     return out
 
 
+def filter_neighbors(ids, tok_pos, invalid_ctx, out=None):
+    """``--invalid-neighbor-context`` (token_block_dataset.py:360-362): ids [n, kg] i64, tok_pos [n] i64 -> ids with the
+    neighbours inside their own token's context replaced by -1 (the graph consumers skip -1 ids)."""
+    _dev(ids, tok_pos)
+    _dtype(ids, torch.int64, "ids"), _dtype(tok_pos, torch.int64, "tok_pos")
+    n, kg = ids.shape
+    assert tok_pos.shape == (n,) and ids.is_contiguous() and tok_pos.is_contiguous()
+    out = torch.empty_like(ids) if out is None else out
+    call("gnnlm_filter_neighbors", ptr(ids), ptr(tok_pos), n, kg, int(invalid_ctx), ptr(out), stream())
+    return out
+
+
 def row_lse_pick(logits, pick=None):
     rows, n = logits.shape
     lse = torch.empty(rows, device=logits.device, dtype=torch.float32)

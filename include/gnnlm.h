@@ -189,6 +189,14 @@ int gnnlm_causal_attn(const float* Q, const float* K, const float* V, int64_t ld
 int gnnlm_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,
                     int64_t ldo, int64_t rows, int32_t d, float eps, const uint8_t* valid, void* stream);
 
+/* `--invalid-neighbor-context c` (fairseq/data/token_block_dataset.py:360-362, switched on for the train split only:
+ * fairseq/tasks/language_modeling.py:299): a neighbour whose datastore row lies within c positions of its own token
+ * (`abs(offsets[tgt_idx] - offset) < c`) is skipped exactly like a -1 id -- so the rule is an id rewrite in front of the
+ * graph consumers: out[i, j] = -1 if ids[i, j] != -1 and |tok_pos[i] - ids[i, j]| < c, else ids[i, j].
+ * ids / out [n_tok, kg] int64 (out may alias ids), tok_pos [n_tok] int64 = the tokens' global offsets in the split. */
+int gnnlm_filter_neighbors(const int64_t* ids, const int64_t* tok_pos, int64_t n_tok, int32_t kg, int64_t invalid_ctx,
+                           int64_t* out, void* stream);
+
 /* fp16 -> fp32 (precompute_feats[offsets].astype(np.float32), token_block_dataset.py:328) */
 int gnnlm_half_to_float(const void* src, float* dst, int64_t n, void* stream);
 

@@ -123,12 +123,13 @@ def build_graph(neighbor_idxs, tgt_offsets, n_store, left, right,
     }
 
 
-def slot_layout(neighbor_idxs, n_store, left, right):
+def slot_layout(neighbor_idxs, n_store, left, right, tgt_offsets=None, invalid_neighbor_context=0):
     """Vectorised padded-slot view of the same graph (what the HIP path uses).
 
     Slot ``(i, j, c)`` with ``c = 0`` the centre ``o = nb[i, j]``, ``c = 1..left`` the rows
     ``o-left .. o-1`` and ``c = left+1 .. left+right`` the rows ``o+1 .. o+right``.  A slot is
-    valid iff its group is valid (``o != -1``) and its row lies in ``[0, n_store)``.  Walking
+    valid iff its group is valid (``o != -1`` and, with ``invalid_neighbor_context = c > 0``,
+    ``|tgt_offsets[i] - o| >= c``: token_block_dataset.py:358-362) and its row lies in ``[0, n_store)``.  Walking
     the valid slots in (i, j, c) order reproduces the reference node order of
     :func:`build_graph` exactly.
 
@@ -137,7 +138,10 @@ def slot_layout(neighbor_idxs, n_store, left, right):
     n_g = 1 + left + right
     delta = np.concatenate([[0], np.arange(-left, 0), np.arange(1, right + 1)]).astype(np.int64)
     rows = nb[:, :, None] + delta[None, None, :]
-    valid = (nb[:, :, None] != -1) & (rows >= 0) & (rows < n_store)
+    group_ok = nb != -1
+    if invalid_neighbor_context > 0:
+        group_ok &= np.abs(np.asarray(tgt_offsets, dtype=np.int64)[:, None] - nb) >= invalid_neighbor_context
+    valid = group_ok[:, :, None] & (rows >= 0) & (rows < n_store)
     rows = np.where(valid, rows, -1)
     assert rows.shape[-1] == n_g
     return rows, valid

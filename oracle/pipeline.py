@@ -17,18 +17,21 @@ from . import knn as oknn
 from . import pq as opq
 
 
-def gather_block(neighbor_idxs, codes, vals, n_store, left, right, reference_loop=False):
+def gather_block(neighbor_idxs, codes, vals, n_store, left, right, reference_loop=False, tgt_offsets=None,
+                 invalid_neighbor_context=0):
     """Row gathers of one block: node codes / labels in reference node order + the graph.
 
     ``reference_loop=True`` uses the per-row Python loop of token_block_dataset.py:354-400;
     otherwise the vectorised slot layout (identical result, test_oracle_graph checks it)."""
     T = neighbor_idxs.shape[0]
+    pos = np.zeros(T, np.int64) if tgt_offsets is None else np.asarray(tgt_offsets, dtype=np.int64)
+    c = invalid_neighbor_context if tgt_offsets is not None else 0         # :361 (train split only, language_modeling.py:299)
     if reference_loop:
-        g = og.build_graph(neighbor_idxs, np.zeros(T, np.int64), n_store, left, right)
+        g = og.build_graph(neighbor_idxs, pos, n_store, left, right, invalid_neighbor_context=c)
         rows = g["ntgt_offsets"]
         return g, codes[rows], vals[rows]
-    g = og.build_graph(neighbor_idxs, np.zeros(T, np.int64), n_store, left, right)
-    rows, valid = og.slot_layout(neighbor_idxs, n_store, left, right)
+    g = og.build_graph(neighbor_idxs, pos, n_store, left, right, invalid_neighbor_context=c)
+    rows, valid = og.slot_layout(neighbor_idxs, n_store, left, right, pos, c)
     flat = rows[valid]
     return g, codes[flat], vals[flat]          # codes / vals: anything indexable by global rows (array, memmap, HostRows)
 
@@ -45,11 +48,13 @@ def hgt_block(sd, n_layers, n_heads, tgt_feats, ntgt_codes, graph, centroids, A,
 
 def eval_block(blk, model, lmbda, temperature, dtype=torch.float32):
     """Score one block.  ``blk``: dict(neighbor_idxs [T,kg], tgt_feats [T,d] fp16/fp32,
-    targets [T], knn_sims [T,k], knn_ids [T,k]); ``model``: dict(sd, n_layers, n_heads,
-    centroids, A, b, codes, vals, n_store, left, right, asm).
+    targets [T], knn_sims [T,k], knn_ids [T,k][, tgt_offsets [T]: the tokens' global offsets, train split]);
+    ``model``: dict(sd, n_layers, n_heads, centroids, A, b, codes, vals, n_store, left, right, asm
+    [, invalid_neighbor_context]).
     Returns per-token dict(gcn_feat, lm_logp, p_knn, recall, logp)."""
     g, ncodes, _ = gather_block(blk["neighbor_idxs"], model["codes"], model["vals"],
-                                model["n_store"], model["left"], model["right"])
+                                model["n_store"], model["left"], model["right"], tgt_offsets=blk.get("tgt_offsets"),
+                                invalid_neighbor_context=model.get("invalid_neighbor_context", 0))
     h = hgt_block(model["sd"], model["n_layers"], model["n_heads"], blk["tgt_feats"], ncodes, g,
                   model["centroids"], model["A"], model["b"], dtype)
     x = h["tgt"]

@@ -209,9 +209,9 @@ class _Len:
         return self.n
 
 
-def ref_build_graph(GB, nb, tgt_offsets, codes, vals, left, right, n_store):
+def ref_build_graph(GB, nb, tgt_offsets, codes, vals, left, right, n_store, invalid_neighbor_context=0):
     self = GB.__new__(GB)
-    self.invalid_neighbor_context = 0
+    self.invalid_neighbor_context = invalid_neighbor_context
     self.quant_neighbor_feats = codes
     self.neighbor_tokens = vals.reshape(-1, 1)
     self.left_neighbor_context, self.right_neighbor_context = left, right
@@ -494,6 +494,36 @@ def gen_graph_and_hgt():
     np.savez_compressed(os.path.join(OUT, "hgt.npz"), **out_h)
 
 
+def gen_graph_invalid_context():
+    """new_build_graph with ``invalid_neighbor_context`` in {0, 3, 3072} (token_block_dataset.py:360-362; switched on for
+    the train split, language_modeling.py:299): neighbours placed on both sides of the |pos - id| < c boundary."""
+    GB = load_graph_builder()
+    rs = np.random.RandomState(77)
+    n_store, M = 9000, 4
+    codes = rs.randint(0, 256, size=(n_store, M)).astype(np.uint8)
+    vals = rs.randint(0, 30, size=n_store).astype(np.int32)
+    out = {"codes": codes, "vals": vals}
+    for c in (0, 3, 3072):
+        for T, k, l, r, start in [(8, 4, 2, 2, 4000), (6, 3, 1, 0, 0), (7, 5, 0, 2, n_store - 7)]:
+            pos = (start + np.arange(T)).astype(np.int64)
+            nb = rs.randint(0, n_store, size=(T, k)).astype(np.int64)
+            nb[0, 0] = pos[0]                                   # the token itself
+            nb[1, 1] = min(n_store - 1, pos[1] + max(c - 1, 0)) # last row inside the window
+            nb[2, 0] = max(0, pos[2] - max(c - 1, 0))
+            nb[2, 1] = min(n_store - 1, pos[2] + c)             # first row outside it
+            nb[3, 2 % k] = max(0, pos[3] - c)
+            nb[4, 0] = -1
+            nb[5, :] = np.clip(pos[5] + np.arange(k) - 1, 0, n_store - 1)   # a token whose neighbours are all its own context (c >= k)
+            g = ref_build_graph(GB, nb, pos, codes, vals, l, r, n_store, invalid_neighbor_context=c)
+            tag = f"c{c}.T{T}k{k}l{l}r{r}"
+            out[tag + ".nb"], out[tag + ".pos"] = nb, pos
+            for et, (u, v) in g._edges.items():
+                out[tag + "." + "_".join(et)] = np.stack([u.numpy(), v.numpy()])
+            out[tag + ".ntgt_codes"] = g.nodes["ntgt"].data["h"].numpy() if "h" in g.nodes["ntgt"].data else np.zeros((0, M), np.uint8)
+            out[tag + ".ntgt_labels"] = g.nodes["ntgt"].data["labels"].numpy()
+    np.savez_compressed(os.path.join(OUT, "graph_ctx.npz"), **out)
+
+
 def gen_hgt_adapters():
     """HGT with in_dim != hidden_dim != out_dim: the reference's own forward incl. `F.gelu(adapt_ws[ntype](feat))`
     (hgt.py:505-507) and the output Linear (:513).  Own random stream: the fixtures above do not move."""
@@ -628,6 +658,7 @@ if __name__ == "__main__":
     gen_graph_and_hgt()
     gen_adaptive_and_scorer()
     gen_hgt_adapters()
+    gen_graph_invalid_context()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -330,3 +330,52 @@ def test_eval_lm_save_knnlm_dstore(dev, tmp_path, fp16):
     with pytest.raises(ValueError):
         eval_lm.cli_main(c["base"] + ["--save-knnlm-dstore", "--dstore-mmap", str(out), "--knnlm", "--lmbda", "0.25",
                                       "--dstore-dir", str(c["data"] / "train_dstore")])
+
+
+def test_eval_lm_train_split_invalid_neighbor_context(dev, tmp_path):
+    """`--gen-subset train --save-knnlm-dstore --knn-keytype gcn_feat` (the datastore the kNN index of the GNN features is
+    built over: gnnlm_scripts/wiki103/find_knn.sh:7): on the train split neighbours within --invalid-neighbor-context
+    positions of their own token are dropped (token_block_dataset.py:360-362, language_modeling.py:299).  Keys == the
+    oracle with the filter; the same run on the test split (filter off) and the oracle without it differ."""
+    from gnnlm_amd import eval_lm, ops
+    from oracle import pipeline
+    c = make_data_dir(tmp_path)
+    data, T, n_train, kg, ctx = c["data"], c["T"], c["n_train"], 6, 10
+    rs = np.random.RandomState(11)
+    pos = np.arange(n_train, dtype=np.int64)
+    nb = rs.randint(0, n_train, size=(n_train, kg)).astype(np.int64)
+    near = rs.random_sample(nb.shape) < 0.5                                   # half of the neighbours sit around the token itself
+    nb = np.where(near, np.clip(pos[:, None] + rs.randint(-2 * ctx, 2 * ctx + 1, size=nb.shape), 0, n_train - 1), nb)
+    nb[rs.random_sample(nb.shape) < 0.02] = -1
+    nb[5] = pos[5] + np.arange(kg) - 2                                        # every neighbour inside the window: no star edges left
+    nb.tofile(str(data / "train_dstore" / f"neighbors.mmap.{kg}"))
+    train_vals = np.maximum(c["prob"]["vals"], 4).astype(np.int32)           # ids 0-3 are fairseq's specials (pad is stripped by the scorer)
+    train_vals.astype(np.int16).tofile(str(data / "train_dstore" / "vals.npy"))
+    # the HIP id rewrite == the rule, on the whole table
+    got = ops.filter_neighbors(torch.from_numpy(nb).to(dev), torch.from_numpy(pos).to(dev), ctx).cpu().numpy()
+    want = np.where((nb != -1) & (np.abs(pos[:, None] - nb) < ctx), -1, nb)
+    assert np.array_equal(got, want) and (want != nb).mean() > 0.2
+    same = ops.filter_neighbors(torch.from_numpy(nb).to(dev), torch.from_numpy(pos).to(dev), 0).cpu().numpy()
+    assert np.array_equal(same, nb)
+    base = list(c["base"])
+    base[base.index("--gen-subset") + 1] = "train"
+    out = tmp_path / "dstores"
+    n_blocks = 4
+    res = eval_lm.cli_main(base + ["--invalid-neighbor-context", str(ctx), "--first", str(n_blocks), "--save-knnlm-dstore",
+                                   "--dstore-mmap", str(out)])
+    n_tok = n_blocks * T
+    assert res["count"] == n_tok
+    d = c["prob"]["d"]
+    keys = np.array(np.memmap(out / "train_dstore-gcn_feat" / "keys.npy", dtype=np.float32, mode="r", shape=(n_train, d))[:n_tok])
+    vals = np.array(np.memmap(out / "train_dstore-gcn_feat" / "vals.npy", dtype=np.int32, mode="r", shape=(n_train, 1))[:n_tok, 0])
+    train_keys = c["train_keys"]
+    assert np.array_equal(vals, train_vals[:n_tok])
+    ref, ref_nofilter = [], []
+    for s in range(0, n_tok, T):
+        one = {"neighbor_idxs": nb[s:s + T], "tgt_feats": train_keys[s:s + T], "targets": train_vals[s:s + T].astype(np.int64),
+               "knn_sims": None, "knn_ids": None, "tgt_offsets": pos[s:s + T]}
+        ref.append(pipeline.eval_block(one, dict(c["model"], invalid_neighbor_context=ctx), 0.0, 1.0)["gcn_feat"].float().numpy())
+        ref_nofilter.append(pipeline.eval_block(one, c["model"], 0.0, 1.0)["gcn_feat"].float().numpy())
+    ref, ref_nofilter = np.concatenate(ref), np.concatenate(ref_nofilter)
+    assert np.abs(keys - ref).max() < 1e-4
+    assert np.abs(ref - ref_nofilter).max() > 1e-2                            # the filter changes the features: the test bites

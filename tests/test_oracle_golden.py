@@ -127,6 +127,34 @@ def test_build_graph(golden, tag):
     assert np.array_equal(rows[valid], gr["ntgt_offsets"])
 
 
+CTX_TAGS = [f"c{c}.{t}" for c in (0, 3, 3072) for t in ("T8k4l2r2", "T6k3l1r0", "T7k5l0r2")]
+
+
+@pytest.mark.parametrize("tag", CTX_TAGS)
+def test_build_graph_invalid_neighbor_context(golden, tag):
+    """``--invalid-neighbor-context`` (token_block_dataset.py:360-362, train split): the reference's own new_build_graph
+    with c in {0, 3, 3072} -- oracle loop and padded slot layout; the rule equals rewriting the filtered ids to -1."""
+    g = golden("graph_ctx")
+    c = int(tag.split(".")[0][1:])
+    l, r = _lr(tag.split(".")[1])
+    nb, pos, codes, vals = g[tag + ".nb"], g[tag + ".pos"], g["codes"], g["vals"]
+    n_store = codes.shape[0]
+    gr = og.build_graph(nb, pos, n_store, l, r, invalid_neighbor_context=c)
+    assert np.array_equal(np.stack(gr["inter"]), g[tag + ".ntgt_inter_tgt"])
+    assert np.array_equal(np.stack(gr["intra_ntgt"]), g[tag + ".ntgt_intra_ntgt"])
+    assert np.array_equal(np.stack(gr["intra_tgt"]), g[tag + ".tgt_intra_tgt"])
+    assert np.array_equal(codes[gr["ntgt_offsets"]], g[tag + ".ntgt_codes"])
+    assert np.array_equal(vals[gr["ntgt_offsets"]], g[tag + ".ntgt_labels"])
+    rows, valid = og.slot_layout(nb, n_store, l, r, pos, c)
+    assert np.array_equal(rows[valid], gr["ntgt_offsets"])
+    # what the HIP path does (gnnlm_filter_neighbors): filtered ids -> -1, then the c = 0 graph
+    masked = np.where((nb != -1) & (np.abs(pos[:, None] - nb) < c), -1, nb)
+    if c:
+        assert (masked != nb).any()                                      # the fixture exercises the filter
+    rows2, valid2 = og.slot_layout(masked, n_store, l, r)
+    assert np.array_equal(valid2, valid) and np.array_equal(rows2, rows)
+
+
 # ---------------------------------------------------------------- HGT (hgt.py under the DGL stand-in)
 def hgt_cases(g):
     keys = sorted({k.split(".tgt_in")[0] for k in g.files if k.endswith(".tgt_in")})

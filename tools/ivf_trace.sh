@@ -1,5 +1,7 @@
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT=$R
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/ivf_trace
 NQ=2048 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/ivf_trace -- python3 $R/tools/ivfpq_bench.py > /dev/null 2>&1
 python3 - <<'PY'

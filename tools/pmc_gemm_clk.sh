@@ -1,6 +1,8 @@
 # effective shader clock and MFMA-pipe occupancy of the GEMM kernels (gemm_bench shapes): GRBM_GUI_ACTIVE / duration
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT=$R
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_gemm_clk
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $R/gpurun_out/pmc_gemm_clk --output-format csv -- python3 $R/tools/gemm_bench.py "${1:-sq 4096}" > /dev/null 2>&1
 python3 - <<'PY'

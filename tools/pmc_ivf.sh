@@ -1,6 +1,8 @@
 # PMC passes of the IVF-PQ list scan (tools/ivfpq_bench.py, NQ = 2048): run on the GPU box, prints per-dispatch averages
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT=$R
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 export NQ=${NQ:-2048}
 rm -rf $R/gpurun_out/pmc_ivf1 $R/gpurun_out/pmc_ivf2
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_ivf1 --output-format csv -- python3 $R/tools/ivfpq_bench.py > /dev/null 2>&1

@@ -1,5 +1,7 @@
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT=$R
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_l3
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $R/gpurun_out/pmc_l3 --output-format csv -- python3 $R/bench.py --layers 3 --blocks 4 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-parity > /dev/null 2>&1
 python3 - <<'PY'

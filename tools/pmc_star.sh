@@ -1,5 +1,7 @@
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT=$R
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 for e in 5 6 7 8; do echo EXP $e; GNNLM_LIB=$R/gnn-lm_amd/build/exp/libstab$e.so T=8192 python3 $R/tools/star_bench.py; done
 T=8192 python3 $R/tools/star_bench.py
 cd /tmp

@@ -1,6 +1,8 @@
 # effective clock and matrix-pipe occupancy of the star kernel (tools/star_bench.py, T = 8192)
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT=$R
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_star_clk
 T=8192 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU -d $R/gpurun_out/pmc_star_clk --output-format csv -- python3 $R/tools/star_bench.py > /dev/null 2>&1
 python3 - <<'PY'

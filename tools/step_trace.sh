@@ -1,6 +1,8 @@
 # per-dispatch trace of the last bench step (on the GPU box): tools/step_trace.sh [bench args] -> stdout
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT=$R
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/step_trace
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/step_trace -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-parity "$@" > /dev/null 2>&1
 python3 - <<'PY'
