@@ -515,7 +515,7 @@ size_t gnnlm_sizeof(const char* name) {
 #define GNNLM_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
     GNNLM_SZ(gnnlm_gemm_t) GNNLM_SZ(gnnlm_gather_t) GNNLM_SZ(gnnlm_star_attn_t) GNNLM_SZ(gnnlm_chain_attn_t)
     GNNLM_SZ(gnnlm_adaptive_softmax_t) GNNLM_SZ(gnnlm_knn_interp_t) GNNLM_SZ(gnnlm_hgt_layer_t)
-    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t) GNNLM_SZ(gnnlm_peer_gather_t) GNNLM_SZ(gnnlm_shards_t)
+    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t) GNNLM_SZ(gnnlm_ivfpq_scan8_t) GNNLM_SZ(gnnlm_ivfpq_rescore_t) GNNLM_SZ(gnnlm_peer_gather_t) GNNLM_SZ(gnnlm_shards_t)
 #undef GNNLM_SZ
     return 0;
 }
@@ -596,6 +596,14 @@ int gnnlm_ivfpq_pack_codes(const uint8_t* codes, int64_t N, int32_t M, uint8_t* 
 int gnnlm_ivfpq_pack_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M, float* out, void* stream) {
     return ivfpq_pack_lut(lut, ld_lut, n, M, out, (hipStream_t)stream);
 }
+int gnnlm_ivfpq_pack_tiles(const uint8_t* codes, int64_t N, int32_t M, uint8_t* out, void* stream) {
+    return ivfpq_pack_tiles(codes, N, M, out, (hipStream_t)stream);
+}
+int gnnlm_ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M, uint8_t* qlut, float* qmeta, void* stream) {
+    return ivfpq_quantize_lut(lut, ld_lut, n, M, qlut, qmeta, (hipStream_t)stream);
+}
+int gnnlm_ivfpq_scan8(const gnnlm_ivfpq_scan8_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_scan8(*d, (hipStream_t)stream); }
+int gnnlm_ivfpq_rescore(const gnnlm_ivfpq_rescore_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_rescore(*d, (hipStream_t)stream); }
 int gnnlm_masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, void* stream) {
     return masked_sum_f64(x, mask, n, out, (hipStream_t)stream);
 }

@@ -1,0 +1,397 @@
+// IVF-PQ list scan on the int8 matrix cores, M = 64 (the reference's kNN index `OPQ64_1024,IVF4096,PQ64`, nprobe 32:
+// gnnlm_scripts/wiki103/find_knn.sh:8-13, searched by faiss on the CPU at knn/knn_model.py:100).
+//
+// The f32 scan of ivfpq.hip does one 8-byte LDS read per (two queries, key, sub-quantizer) and one packed add: it runs at
+// the LDS read rate with 4 bytes per (query, key, sub-quantizer).  Here the scan is a FILTER followed by an exact
+// re-score of what passes, and the filter needs one BYTE per (query, key, sub-quantizer):
+//
+//   * a query's ADC table is quantised to 8 bits with a guaranteed one-sided bound (quantize_lut_kernel):
+//         u[m][c] = min(255, floor((L[m][c] - lo_m) * inv)),   lo_m = min_c L[m][c],   L[m][c] < lo_m + (u + 1) delta
+//     (stored as the signed byte u - 128: v_mfma_i32_*_i8 reads signed operands, the threshold absorbs the 128 * 64)
+//     so that   score(q, x) = bias + sum_m L[m][code_m(x)]  <  bias + sum_lo + (sum_m u + M) delta + eps  =: UB(x);
+//   * EIGHT queries that probe the same list share a workgroup; the LDS table entry of (sub-quantizer, code) is the 8
+//     queries' bytes, so one ds_read_b64 serves 8 (query, key) pairs (LDS: 128 KiB of tables);
+//   * the sums over the 64 sub-quantizers are taken by v_mfma_i32_16x16x64_i8: a lane's two look-ups ARE its 16-byte A
+//     operand (row = key, k = (look-up, query)), B is the constant selector B[(look-up, query)][j] = [query == j]: one MFMA
+//     adds 16 keys x 8 sub-quantizers x 8 queries -- the integer sums are exact, the matrix core is the adder;
+//   * a key survives for query j iff its integer sum reaches T_j = the integer image of the query's threshold tau (its
+//     k-th best exact score after the dense round): UB(x) <= tau  =>  score(x) <= tau, so no key of the exact
+//     one-pass scan (score > tau) is lost; survivors (row, list) are staged in LDS and appended to the query's list;
+//   * ivfpq_rescore_kernel then recomputes the survivors' scores in float32 IN THE SUMMATION ORDER OF THE f32 SCAN
+//     (ivfpq.hip, scan_rot), keeps score > tau and emits (score, payload[row]): the candidate set and every candidate's
+//     bits are those of the one-pass f32 scan -- the search result is identical, by construction and by test.
+//
+// Look-ups are bank-conflict free by the same rotation idea as ivfpq.hip: a tile is 16 keys; lane (g = lane / 16,
+// i = lane % 16) owns sub-quantizers 16 g .. 16 g + 15 of key i and reads them in the order 16 g + (i + p) % 16, the table
+// is stored [half][code][32 slots] x 8 B, so the 32 lanes of an LDS access group hit 32 different slots; the key bytes are
+// stored in that rotated order (gnnlm_ivfpq_pack_tiles), and the LDS address of a look-up is one v_perm_b32.
+#include "kernels.h"
+
+namespace gnnlm {
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int QG = 8;                                   // queries per workgroup
+constexpr int TAB_BYTES = 2 * 256 * 32 * QG;            // [half][code][slot][query]: 128 KiB
+constexpr int STAGE_CAP = 640;                          // survivors staged per query and task
+constexpr int SCAN_LDS = TAB_BYTES + 64 + QG * STAGE_CAP * 4;
+constexpr int QLUT_BYTES = 64 * 256;                    // one query's quantised table
+
+// codes [N, 64] row-major -> tiles of 16 rows, [tile][g 0..3][i 0..15][p 0..15] = code[16 tile + i][16 g + (i + p) % 16];
+// rows beyond N are zero.  One thread per (row, g).
+__global__ __launch_bounds__(256) void pack_tiles_kernel(const uint8_t* __restrict__ codes, int64_t N, uint8_t* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = e >> 2;
+    const int g = (int)(e & 3);
+    if (row >= ((N + 15) >> 4 << 4)) return;
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    if (row < N) {
+        const uint8_t* src = codes + row * 64 + 16 * g;
+        const int i = (int)(row & 15);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) v[p >> 2] |= (uint32_t)src[(i + p) & 15] << (8 * (p & 3));
+    }
+    *reinterpret_cast<uint4*>(out + (((row >> 4) * 4 + g) * 16 + (row & 15)) * 16) = uint4{v[0], v[1], v[2], v[3]};
+}
+
+// One workgroup per query: L [64][256] f32 -> u8 [half][code][32 slots] + {delta, sum_lo, absmax, 0}.
+__global__ __launch_bounds__(256) void quantize_lut_kernel(const float* __restrict__ lut, int64_t ld, uint8_t* __restrict__ qlut,
+                                                           float* __restrict__ qmeta) {
+    __shared__ __attribute__((aligned(16))) float tab[64 * 256];
+    __shared__ float lo_s[64], rng_s[64], amax_s[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q = blockIdx.x;
+    {
+        const float4* src = reinterpret_cast<const float4*>(lut + q * ld);
+        float4* dst = reinterpret_cast<float4*>(tab);
+        for (int e = tid; e < 64 * 64; e += 256) dst[e] = src[e];
+    }
+    __syncthreads();
+    for (int m = wave; m < 64; m += 4) {
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float v = tab[m * 256 + lane + 64 * x];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+        mn = -wave_max(-mn);
+        mx = wave_max(mx);
+        if (lane == 0) { lo_s[m] = mn; rng_s[m] = mx - mn; amax_s[m] = fmaxf(fabsf(mn), fabsf(mx)); }
+    }
+    __syncthreads();
+    float maxrange = 0.f, sum_lo = 0.f, amax = 0.f;
+    for (int m = 0; m < 64; ++m) {                       // every thread, same order: sum_lo is one fixed f32 chain
+        maxrange = fmaxf(maxrange, rng_s[m]);
+        sum_lo += lo_s[m];
+        amax = fmaxf(amax, amax_s[m]);
+    }
+    // inv a little below 255 / maxrange, delta a little above maxrange / 255: (u + 1) delta bounds L - lo from above whatever
+    // the rounding of the two float operations of the quantisation did (see the header comment; delta * inv >= 1 + 2^-19)
+    const bool flat = !(maxrange > 0.f);
+    const float inv = flat ? 0.f : (255.f / maxrange) * (1.f - 3.8146973e-6f);          // 1 - 2^-18
+    const float delta = flat ? 1e-30f : (maxrange / 255.f) * (1.f + 7.6293945e-6f);     // 1 + 2^-17
+    if (tid == 0) {
+        qmeta[q * 4 + 0] = delta;
+        qmeta[q * 4 + 1] = sum_lo;
+        qmeta[q * 4 + 2] = amax;
+        qmeta[q * 4 + 3] = 0.f;
+    }
+    uint8_t* dst = qlut + q * QLUT_BYTES;
+    for (int hc = tid; hc < 512; hc += 256) {           // row (half, code): 32 slots = 32 bytes
+        const int h = hc >> 8, c = hc & 255;
+        uint32_t o[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int m = 32 * h + 4 * w + b;
+                const float y = (tab[m * 256 + c] - lo_s[m]) * inv;
+                const int u = min(255, max(0, (int)floorf(y)));
+                pk |= (uint32_t)(u ^ 0x80) << (8 * b);            // stored as the SIGNED byte u - 128: the i8 MFMA reads signed operands
+            }
+            o[w] = pk;
+        }
+        uint4* d4 = reinterpret_cast<uint4*>(dst + hc * 32);
+        d4[0] = uint4{o[0], o[1], o[2], o[3]};
+        d4[1] = uint4{o[4], o[5], o[6], o[7]};
+    }
+}
+
+#define GNNLM_PERM(hi_, lo_, sel_) __builtin_amdgcn_perm((hi_), (lo_), (sel_))
+#ifndef GNNLM_IVF8_EXP
+#define GNNLM_IVF8_EXP 0        // ablation builds: 1 no code loads, 2 no table fill, 4 no look-ups (MFMAs on constants), 8 no MFMAs
+#endif
+
+__global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // tables at LDS address 0 (look-up addresses are absolute)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // consecutive workgroups go to consecutive XCDs: give each XCD a contiguous range of the list-sorted groups
+    const int n_groups = min(*p.n_groups, p.max_groups);
+    const int per_xcd = (n_groups + 7) >> 3;
+    if ((int)(blockIdx.x >> 3) >= per_xcd) return;
+    const int grp = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (grp >= n_groups) return;
+    const int list = p.grp_list[grp];
+    if (list < 0) return;
+    const int64_t lo = p.list_off[list], hi = p.list_off[list + 1];
+    if (hi <= lo) return;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
+    int* scnt = reinterpret_cast<int*>(smem + TAB_BYTES);                     // [8] survivor counts, [8] output bases
+    uint32_t* sbuf = reinterpret_cast<uint32_t*>(smem + TAB_BYTES + 64);      // [8][STAGE_CAP] row - lo
+    const int* gq = p.grp_q + (int64_t)grp * QG;
+    uint2* surv = reinterpret_cast<uint2*>(p.surv);                           // {row, list} per survivor
+    int qs[QG];
+#pragma unroll
+    for (int j = 0; j < QG; ++j) qs[j] = gq[j];
+
+    // ---- the 8 queries' byte tables -> [half][code][slot] x 8 B: a 4 x 8 byte transpose per thread and step
+#if !(GNNLM_IVF8_EXP & 2)
+    for (int e4 = tid; e4 < QLUT_BYTES / 4; e4 += 1024) {
+        uint32_t w[QG];
+#pragma unroll
+        for (int j = 0; j < QG; ++j)
+            w[j] = qs[j] >= 0 ? reinterpret_cast<const uint32_t*>(p.qlut + (int64_t)qs[j] * QLUT_BYTES)[e4] : 0u;
+        uint32_t o[8];
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {                 // queries 4 hq .. 4 hq + 3 -> dword hq of the four entries
+            const uint32_t a = w[4 * hq], b = w[4 * hq + 1], c = w[4 * hq + 2], d = w[4 * hq + 3];
+            const uint32_t t0 = GNNLM_PERM(b, a, 0x05010400u), t1 = GNNLM_PERM(b, a, 0x07030602u);
+            const uint32_t t2 = GNNLM_PERM(d, c, 0x05010400u), t3 = GNNLM_PERM(d, c, 0x07030602u);
+            o[0 + hq] = GNNLM_PERM(t2, t0, 0x05040100u);
+            o[2 + hq] = GNNLM_PERM(t2, t0, 0x07060302u);
+            o[4 + hq] = GNNLM_PERM(t3, t1, 0x05040100u);
+            o[6 + hq] = GNNLM_PERM(t3, t1, 0x07060302u);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(smem) + 2 * e4;
+        dst[0] = uint4{o[0], o[1], o[2], o[3]};
+        dst[1] = uint4{o[4], o[5], o[6], o[7]};
+    }
+#endif
+    // ---- integer thresholds: lane column j = lane % 16 (the D layout of the MFMA: D[key 4 g + r][query j])
+    const int j = lane & 15, g = lane >> 4;
+    int T = 0x7fffffff;
+    const int qj = j < QG ? gq[j] : -1;                                   // (a register array may not be indexed by the lane)
+    if (qj >= 0) {
+        const int64_t q = qj;
+        const float delta = p.qmeta[q * 4], sum_lo = p.qmeta[q * 4 + 1], amax = p.qmeta[q * 4 + 2];
+        const float bias = p.coarse[q * p.ld_coarse + list], tau = p.tau[q];
+        // eps: rounding of the f32 score chain (65 adds), of sum_lo and of this formula's subtractions: (M + 2) 2^-22 sum |terms|
+        const float eps = 66.f * 2.3841858e-7f * (64.f * amax + fabsf(bias) + (fabsf(tau) < INFINITY ? fabsf(tau) : 0.f));
+        const float thr = ((tau - bias) - sum_lo - eps) / delta - 64.f;     // survive iff sum_u + 64 > thr' with thr' in (thr - 1, thr + 1)
+        // the table bytes are u - 128 (signed): the MFMA's sums are sum_u - 128 * 64
+        T = !(thr == thr) || thr <= -1.0e9f ? -(1 << 30) : (thr >= 1.0e9f ? 0x7fffffff : (int)floorf(thr) - 128 * 64);
+    }
+    if (tid < 16) scnt[tid] = 0;
+    __syncthreads();
+
+    // ---- look-up constants of the lane: slot byte offsets of look-ups 2 s / 2 s + 1 and the table half in byte 2
+    uint32_t tc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const uint32_t s0 = (uint32_t)(16 * (g & 1) + ((j + 2 * s) & 15)) << 3, s1 = (uint32_t)(16 * (g & 1) + ((j + 2 * s + 1) & 15)) << 3;
+        tc[s] = s0 | s1 << 8 | (uint32_t)(g >> 1) << 16;
+    }
+    const uint32_t b0 = j < 4 ? 1u << (8 * j) : 0u, b1 = (j >= 4 && j < 8) ? 1u << (8 * (j - 4)) : 0u;
+    const v4i Bc = {(int)b0, (int)b1, (int)b0, (int)b1};                    // B[(look-up, query)][j] = [query == j]
+
+    const int64_t t_hi = (hi - 1) >> 4;
+    const uint4* img = reinterpret_cast<const uint4*>(p.tiles);
+    int64_t t = (lo >> 4) + wave;
+    uint4 cw = uint4{0u, 0u, 0u, 0u}, n1 = cw;          // this tile's code bytes, the next one's; the one after is requested in the loop
+#if !(GNNLM_IVF8_EXP & 1)
+    if (t <= t_hi) cw = img[t * 64 + lane];
+    if (t + 16 <= t_hi) n1 = img[(t + 16) * 64 + lane];
+#endif
+    for (; t <= t_hi; t += 16) {
+        uint4 n2 = n1;
+#if !(GNNLM_IVF8_EXP & 1)
+        if (t + 32 <= t_hi) n2 = img[(t + 32) * 64 + lane];                 // two tiles ahead: an HBM round trip under two tiles of look-ups
+#else
+        cw.x += 0x01030507u; cw.y += 0x02040608u; cw.z += 0x0b0d0f11u; cw.w += 0x13171d1fu;
+        n1 = cw;
+#endif
+        const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+        // all 16 look-ups of the tile in flight, then the 8 MFMAs (the other waves of the SIMD fill the matrix pipe meanwhile)
+        u32x2 x[16];
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            // address = {0, half, code byte, slot offset}: byte 0 <- tc byte (pp & 1), byte 1 <- w byte (pp & 3), byte 2 <- tc byte 2
+            const uint32_t a = GNNLM_PERM(w[pp >> 2], tc[pp >> 1], 0x0c020000u | (uint32_t)(4 + (pp & 3)) << 8 | (uint32_t)(pp & 1));
+#if GNNLM_IVF8_EXP & 4
+            x[pp] = u32x2{a, a ^ 0x5a5a5a5au};
+#else
+            x[pp] = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(a);
+#endif
+        }
+        v4i acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const v4i A = {(int)x[2 * s].x, (int)x[2 * s].y, (int)x[2 * s + 1].x, (int)x[2 * s + 1].y};
+#if GNNLM_IVF8_EXP & 8
+            acc += A;
+#else
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, Bc, acc, 0, 0, 0);
+#endif
+        }
+        const int mx = max(max(acc[0], acc[1]), max(acc[2], acc[3]));
+        if (__builtin_amdgcn_ballot_w64(mx >= T) != 0ull) {                  // rare: a fraction of a percent of the keys survive
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = t * 16 + 4 * g + r;
+                if (acc[r] >= T && row >= lo && row < hi) {
+                    const int pos = atomicAdd(&scnt[j], 1);
+                    if (pos < STAGE_CAP) sbuf[j * STAGE_CAP + pos] = (uint32_t)(row - lo);
+                    else {                                                   // staging full: straight to the query's list
+                        const int gp = atomicAdd(&p.surv_cnt[qj], 1);
+                        if (gp < p.cap) surv[(int64_t)qj * p.cap + gp] = uint2{(uint32_t)row, (uint32_t)list};
+                    }
+                }
+            }
+        }
+        cw = n1;
+        n1 = n2;
+    }
+    __syncthreads();
+    if (tid < QG) {
+        const int n = min(scnt[tid], STAGE_CAP), qt = gq[tid];
+        scnt[8 + tid] = (n > 0 && qt >= 0) ? atomicAdd(&p.surv_cnt[qt], n) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        const int n = min(scnt[u], STAGE_CAP), base = scnt[8 + u];
+        for (int e = tid; e < n; e += 1024)
+            if (base + e < p.cap) surv[(int64_t)qs[u] * p.cap + base + e] = uint2{(uint32_t)(lo + sbuf[u * STAGE_CAP + e]), (uint32_t)list};
+    }
+}
+
+// Exact float32 scores of the survivors, in the summation order of the f32 scan (ivfpq.hip scan_rot: look-up s of half h
+// goes to sub-quantizer 32 h + (row + s) % 32, even look-ups into one chain, odd ones into the other, halves in order,
+// score = bias + (chain0 + chain1)).  One workgroup per query, its table in LDS.
+template <int M>
+__global__ __launch_bounds__(256) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore_t p) {
+    extern __shared__ __attribute__((aligned(16))) float rtab[];            // [M][256] f32, then 256 x (M + 16) code bytes
+    __shared__ int ccnt;
+    constexpr int RS = M + 16;                                              // row stride of the per-thread code bytes
+    uint8_t* cbuf = reinterpret_cast<uint8_t*>(rtab + M * 256);
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const int n = min(p.surv_cnt[q], p.cap);
+    if (tid == 0) ccnt = 0;
+    if (n > 0) {
+        const float4* src = reinterpret_cast<const float4*>(p.lut + q * p.ld_lut);
+        float4* dst = reinterpret_cast<float4*>(rtab);
+        for (int e = tid; e < M * 64; e += 256) dst[e] = src[e];
+    }
+    __syncthreads();
+    const float tau = p.tau[q];
+    for (int e = tid; e < n; e += 256) {
+        const uint2 sv = reinterpret_cast<const uint2*>(p.surv)[q * p.cap + e];
+        const int64_t row = sv.x;
+        const uint4* crow = reinterpret_cast<const uint4*>(p.codes + row * M);
+        uint4* mine = reinterpret_cast<uint4*>(cbuf + tid * RS);
+#pragma unroll
+        for (int c16 = 0; c16 < M / 16; ++c16) mine[c16] = crow[c16];
+        const uint8_t* cb = cbuf + tid * RS;
+        const int rot = (int)(row & 31);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int h = 0; h < M / 32; ++h) {
+#pragma unroll 4
+            for (int s = 0; s < 32; s += 2) {
+                const int m0 = 32 * h + ((rot + s) & 31), m1 = 32 * h + ((rot + s + 1) & 31);
+                a0 = a0 + rtab[m0 * 256 + cb[m0]];
+                a1 = a1 + rtab[m1 * 256 + cb[m1]];
+            }
+        }
+        const float score = p.coarse[q * p.ld_coarse + sv.y] + (a0 + a1);
+        if (score > tau) {
+            const int pos = atomicAdd(&ccnt, 1);
+            if (pos < p.cand_cap) {
+                p.cand_val[q * p.cand_cap + pos] = score;
+                p.cand_id[q * p.cand_cap + pos] = p.payload[row];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) p.cand_cnt[q] = ccnt;
+}
+
+}  // namespace
+
+int ivfpq_pack_tiles(const uint8_t* codes, int64_t N, int M, uint8_t* out, hipStream_t stream) {
+    GNNLM_REQUIRE(codes && out && N >= 0 && M == 64, "ivfpq_pack_tiles: need M = 64");
+    GNNLM_REQUIRE((uintptr_t)out % 16 == 0, "ivfpq_pack_tiles: 16-byte aligned output");
+    const int64_t threads = ((N + 15) >> 4 << 4) * 4;
+    if (threads == 0) return OK;
+    GNNLM_REQUIRE(cdiv(threads, (int64_t)256) < (1ll << 31), "ivfpq_pack_tiles: too many rows for one launch");
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)cdiv(threads, (int64_t)256)), dim3(256), 0, stream, codes, N, out);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int M, uint8_t* qlut, float* qmeta, hipStream_t stream) {
+    GNNLM_REQUIRE(lut && qlut && qmeta && n >= 0 && n < (1ll << 31) && M == 64 && ld_lut >= 64 * 256 && ld_lut % 4 == 0 &&
+                      (uintptr_t)lut % 16 == 0 && (uintptr_t)qlut % 16 == 0,
+                  "ivfpq_quantize_lut: need M = 64 and 16-byte aligned tables");
+    if (n == 0) return OK;
+    hipLaunchKernelGGL(quantize_lut_kernel, dim3((unsigned)n), dim3(256), 0, stream, lut, ld_lut, qlut, qmeta);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+// one hipFuncSetAttribute per (kernel, device): a process may drive several devices
+template <typename K>
+static int opt_in_lds(K kernel, int bytes, bool (&done)[16]) {
+    int dev = 0;
+    GNNLM_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 16 && done[dev]) return OK;
+    GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev >= 0 && dev < 16) done[dev] = true;
+    return OK;
+}
+
+int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream) {
+    GNNLM_REQUIRE(d.max_groups >= 0, "ivfpq_scan8: bad group count");
+    if (d.max_groups == 0) return OK;
+    GNNLM_REQUIRE(d.tiles && d.list_off && d.qlut && d.qmeta && d.coarse && d.tau && d.grp_list && d.grp_q && d.n_groups && d.surv &&
+                      d.surv_cnt && d.cap > 0,
+                  "ivfpq_scan8: null operand");
+    GNNLM_REQUIRE(d.M == 64 && (uintptr_t)d.tiles % 16 == 0 && (uintptr_t)d.qlut % 4 == 0, "ivfpq_scan8: need M = 64, aligned images");
+    static bool done[16] = {};
+    const int rc = opt_in_lds(&ivfpq_scan8_kernel, SCAN_LDS, done);
+    if (rc != OK) return rc;
+    ProfScope prof(K_IVF, stream, 0.0, 0.0);             // work figures are device-side (list lengths): bench.py computes them
+    const int64_t grid = 8 * cdiv((int64_t)d.max_groups, (int64_t)8);
+    hipLaunchKernelGGL(ivfpq_scan8_kernel, dim3((unsigned)grid), dim3(1024), SCAN_LDS, stream, d);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int ivfpq_rescore(const gnnlm_ivfpq_rescore_t& d, hipStream_t stream) {
+    GNNLM_REQUIRE(d.n >= 0 && d.n < (1ll << 31), "ivfpq_rescore: bad query count");
+    if (d.n == 0) return OK;
+    GNNLM_REQUIRE(d.codes && d.payload && d.lut && d.coarse && d.tau && d.surv && d.surv_cnt && d.cand_val && d.cand_id && d.cand_cnt &&
+                      d.cap > 0 && d.cand_cap > 0,
+                  "ivfpq_rescore: null operand");
+    GNNLM_REQUIRE((d.M == 64 || d.M == 32) && d.ld_lut >= (int64_t)d.M * 256 && d.ld_lut % 4 == 0 && (uintptr_t)d.lut % 16 == 0 &&
+                      (uintptr_t)d.codes % 16 == 0,
+                  "ivfpq_rescore: need M = 32 or 64, 16-byte aligned tables");
+    ProfScope prof(K_IVF, stream, 0.0, 0.0);
+    const size_t lds = (size_t)d.M * 256 * 4 + 256 * (size_t)(d.M + 16);
+    if (d.M == 64) {
+        static bool done[16] = {};
+        const int rc = opt_in_lds(&ivfpq_rescore_kernel<64>, (int)lds, done);
+        if (rc != OK) return rc;
+        hipLaunchKernelGGL(ivfpq_rescore_kernel<64>, dim3((unsigned)d.n), dim3(256), lds, stream, d);
+    } else {
+        hipLaunchKernelGGL(ivfpq_rescore_kernel<32>, dim3((unsigned)d.n), dim3(256), lds, stream, d);
+    }
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // namespace gnnlm

@@ -14,12 +14,22 @@ MFMA GEMM (``gnnlm_gemm_nt``), probe selection and k-selection by ``gnnlm_topk_m
 ``gnnlm_ivfpq_scan`` in two rounds -- the best ``dense_probes`` lists of every query are scored in full and give its
 k-th-best threshold, the remaining lists only emit scores above that threshold.
 
+At M = 64 (the reference's PQ64) the thresholded round is a FILTER on the int8 matrix cores followed by an exact re-score
+(``csrc/ivfpq_mfma.hip``: 8-bit tables with a guaranteed one-sided bound, eight queries of a list per workgroup, the
+sums taken by ``v_mfma_i32_16x16x64_i8``; survivors re-scored in float32 in the summation order of the float32 scan), so
+candidates and scores are those of the one-pass float32 scan -- ``GNNLM_IVF_SCAN=f32`` selects that scan for A/B runs.
+With ``attach_vals`` the index carries each key's label next to its id (one 8-byte payload per key), and the search
+returns ``vals[ids]`` with the neighbours: the label gather of knn/knn_model.py:198 disappears.
+
 ``IVFPQIndex.build`` is the offline producer (the reference delegates it to faiss: index_builder.py:79-150): plain
-Lloyd k-means for the coarse and the product quantizers, a random orthonormal matrix for R (faiss alternates OPQ
-updates; any orthonormal R gives a valid index).  It runs on the GPU with torch ops -- offline tooling, not the hot path.
+Lloyd k-means for the product quantizers, spherical k-means (unit-norm centroids, what faiss's index_factory sets for
+inner-product indexes) for the coarse one, a random orthonormal matrix for R (faiss alternates OPQ updates; any
+orthonormal R gives a valid index).  It runs on the GPU with torch ops -- offline tooling, not the hot path.
 
 PARITY UNPINNED against faiss itself (not in the image, no version pinned): the pin is the numpy restatement
 ``oracle/ivfpq.py`` over the SAME index arrays (tests/test_knn_search_gpu.py)."""
+import os
+
 import numpy as np
 import torch
 
@@ -27,7 +37,9 @@ from . import _lib, ops
 
 
 def _kmeans(x, k, iters, gen, spherical=False):
-    """Lloyd's algorithm (squared L2) on the device; empty clusters are re-seeded from random points."""
+    """Lloyd's algorithm (squared L2) on the device; empty clusters are re-seeded from random points.  ``spherical``: the
+    centroids are L2-normalised after every update (faiss ClusteringParameters.spherical, set by index_factory for
+    METRIC_INNER_PRODUCT coarse quantizers)."""
     n = x.shape[0]
     cen = x[torch.randperm(n, generator=gen, device=x.device)[:k]].clone()
     if cen.shape[0] < k:
@@ -45,17 +57,22 @@ def _kmeans(x, k, iters, gen, spherical=False):
         dead = (~live).nonzero().reshape(-1)
         if dead.numel():
             new[dead] = x[torch.randint(0, n, (dead.numel(),), generator=gen, device=x.device)]
-        cen = new
+        cen = new / new.norm(dim=1, keepdim=True).clamp_min(1e-20) if spherical else new
     return cen
 
 
 class IVFPQIndex:
     """faiss ``search`` contract: ``search(queries [n, d] f32, k) -> (scores [n, k] descending, ids [n, k], -1 padded)``."""
 
-    def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=2, cand_cap=32768):
+    LABEL_BITS = 24                                                          # payload = id << 24 | label (ids < 2^39, labels < 2^24)
+
+    def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=2, cand_cap=16384,
+                 score_bytes=6 << 30, scan=None):
         self.R, self.coarse, self.pq = R, coarse, pq                         # [d, d], [nlist, d], [M, 256, dsub]  f32
         self.list_off, self.list_ids, self.list_codes = list_off, list_ids, list_codes   # i64 [nlist+1], i64 [N], u8 [N, M]
         self.nprobe, self.cosine, self.dense_probes, self.cand_cap = nprobe, cosine, dense_probes, cand_cap
+        self.score_bytes = score_bytes                                       # budget of the dense round's score rows per query block
+        self.payload, self.has_vals, self.val_last = list_ids, False, 0      # what a candidate carries through the selection
         self.device = R.device
         self.d, self.nlist = coarse.shape[1], coarse.shape[0]
         self.M, _, self.dsub = pq.shape
@@ -67,6 +84,26 @@ class IVFPQIndex:
         if self.M in (32, 64) and self.ntotal:
             self.packed_codes = torch.empty(-(-self.ntotal // 64) * 64 * self.M, dtype=torch.uint8, device=self.device)
             _lib.call("gnnlm_ivfpq_pack_codes", _lib.ptr(self.list_codes), self.ntotal, self.M, _lib.ptr(self.packed_codes), _lib.stream())
+        # M = 64: the int8-MFMA filter's image of the code rows (tiles of 16 rows, rotated byte order; csrc/ivfpq_mfma.hip)
+        self.tiles = None
+        scan = scan or os.environ.get("GNNLM_IVF_SCAN", "mfma")              # "f32": the one-pass float32 scan everywhere (A/B, tests)
+        if self.M == 64 and self.ntotal and self.ntotal < (1 << 32) and scan != "f32":
+            self.tiles = ops.ivfpq_pack_tiles(self.list_codes)
+        self.stats = {}                                                      # device-side work counters of the last search (bench.py)
+
+    def attach_vals(self, vals):
+        """Carry the keys' labels with the index: payload[r] = id << 24 | vals[id] for the key at list position r (the reference
+        reads ``self.vals[knns]`` after the search, knn/knn_model.py:198: k random 4-byte reads per query).  ``vals``: the
+        datastore's label table on the device ([N] or [N, 1], int16 / int32); -1 ids of the result read ``vals[-1]`` as numpy's
+        wrap-around does there."""
+        v = vals.reshape(-1).to(self.device)
+        if self.ntotal == 0:
+            return self
+        if int(v.max().item()) >= (1 << self.LABEL_BITS) or int(v.min().item()) < 0 or int(self.list_ids.max().item()) >= (1 << (63 - self.LABEL_BITS)):
+            raise ValueError("attach_vals: labels must fit 24 bits and key ids 39 bits")
+        self.payload = (self.list_ids << self.LABEL_BITS) | v[self.list_ids].to(torch.int64)
+        self.has_vals, self.val_last = True, int(v[-1].item())
+        return self
 
     # ------------------------------------------------------------------------------------------ offline producer
     @classmethod
@@ -86,10 +123,9 @@ class IVFPQIndex:
         cpu_gen = torch.Generator().manual_seed(seed)
         R = torch.linalg.qr(torch.randn(d, d, generator=cpu_gen, dtype=torch.float64))[0].to(torch.float32).to(device)
         pick = np.sort(np.random.RandomState(seed).choice(N, size=min(N, train_size), replace=False))
-        xt = torch.cat([rows(int(i), int(i) + 1) for i in pick[:0]] + [rows(0, 0)]) if False else None
         xt = torch.cat([rows(int(s), int(min(N, s + chunk)))[torch.from_numpy(pick[(pick >= s) & (pick < s + chunk)] - s).to(device)]
                         for s in range(0, N, chunk)]) @ R.t()
-        coarse = _kmeans(xt, nlist, iters, gen)
+        coarse = _kmeans(xt, nlist, iters, gen, spherical=cosine)
         resid = xt - coarse[(xt @ coarse.t()).argmax(1)]                      # inner-product assignment (IndexFlatIP quantizer)
         pq = torch.stack([_kmeans(resid[:, m * dsub:(m + 1) * dsub].contiguous(), 256, iters, gen) for m in range(M)])
         # add every key: list assignment + residual PQ codes (HIP argmin kernel of TorchPQCodec.encode)
@@ -146,7 +182,7 @@ class IVFPQIndex:
         task_q = torch.div(order, p_hi - p_lo, rounding_mode="floor").to(torch.int32)
         task_p = (order % (p_hi - p_lo) + p_lo).to(torch.int32)
         s = _lib.gnnlm_ivfpq_scan_t()
-        s.codes, s.ids, s.list_off, s.M = self.list_codes.data_ptr(), self.list_ids.data_ptr(), self.list_off.data_ptr(), self.M
+        s.codes, s.ids, s.list_off, s.M = self.list_codes.data_ptr(), self.payload.data_ptr(), self.list_off.data_ptr(), self.M
         if self.packed_codes is not None:
             s.codes, s.packed = self.packed_codes.data_ptr(), 1                 # `lut` is then the packed table set
         s.lut, s.ld_lut = lut.data_ptr(), lut.stride(0)
@@ -158,75 +194,146 @@ class IVFPQIndex:
             s.tau, s.cand_val, s.cand_id, s.cand_cnt, s.cap = tau.data_ptr(), cand[0].data_ptr(), cand[1].data_ptr(), cand[2].data_ptr(), self.cand_cap
         _lib.call_desc("gnnlm_ivfpq_scan", s)
 
-    def search_device(self, q, k, query_block=1024):
-        """The search, on device tensors.  The thresholded round keeps at most ``cand_cap`` survivors per query; a query with
-        more would lose neighbours, so the survivor counts are read back once per call (the only host sync) and the call is
-        repeated with room for the largest count -- and, past 2^18 slots, with every probed list scored in full."""
-        while True:
-            self._overflow = None
-            out = self._search_once(q, k, query_block)
-            ov = int(self._overflow.item()) if self._overflow is not None else 0
-            if ov <= self.cand_cap:
-                return out
-            if ov > (1 << 18):
-                self.dense_probes = self.nprobe
-            else:
-                self.cand_cap = 1 << (ov - 1).bit_length()
+    def _groups(self, pl):
+        """(query, probe) pairs of ``pl`` [nq, P] (list ids, -1 = none) -> groups of up to 8 queries that probe the same list,
+        sorted by list: grp_list [G], grp_q [G, 8] (-1 padded), the number of groups in use as a DEVICE scalar.  Torch ops
+        on the device, no host round trip; G is the upper bound pairs / 8 + nlist + 1."""
+        nq, P = pl.shape
+        dev = self.device
+        n = nq * P
+        key = torch.where(pl < 0, torch.full_like(pl, self.nlist), pl).reshape(-1)
+        skey, order = torch.sort(key, stable=True)
+        idx = torch.arange(n, device=dev)
+        start = torch.ones(n, dtype=torch.bool, device=dev)
+        start[1:] = skey[1:] != skey[:-1]
+        run0 = torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0).values
+        pos = idx - run0                                                      # position inside the run of one list
+        gid = torch.cumsum((pos % 8 == 0).to(torch.int64), 0) - 1
+        G = n // 8 + self.nlist + 1
+        grp_list = torch.full((G,), -1, dtype=torch.int32, device=dev)
+        grp_list[gid] = torch.where(skey >= self.nlist, torch.full_like(skey, -1), skey).to(torch.int32)
+        grp_q = torch.full((G, 8), -1, dtype=torch.int32, device=dev)
+        grp_q[gid, pos % 8] = torch.div(order, P, rounding_mode="floor").to(torch.int32)
+        n_groups = (gid[-1:] + 1).to(torch.int32)
+        return grp_list, grp_q, n_groups, G
 
-    def _search_once(self, q, k, query_block):
+    def search_device(self, q, k, query_block=None, return_vals=False):
+        """The search, on device tensors: (scores [n, k] descending, ids [n, k], -1 padded[, vals [n, k] int32 with
+        ``attach_vals``]).  The thresholded round keeps at most ``cand_cap`` survivors per query; the survivor counts are read
+        back once per call (the only host sync).  Queries with more (a query whose dense lists hold fewer than k keys has no
+        threshold) are searched again on their own with every probed list scored in full; if many overflow, the capacity is
+        doubled for good and the call repeated."""
         q = q.to(self.device, torch.float32).contiguous()
+        while True:
+            val, idx, over = self._search_once(q, k, query_block, self.dense_probes)
+            if over is None:
+                break
+            bad = (over > self.cand_cap).nonzero().reshape(-1)                # host sync
+            if bad.numel() == 0:
+                break
+            if bad.numel() * 8 > q.shape[0] and self.cand_cap < (1 << 18):
+                self.cand_cap *= 2
+                continue
+            v2, i2, _ = self._search_once(q[bad].contiguous(), k, query_block, self.nprobe)
+            val[bad], idx[bad] = v2, i2
+            break
+        self._overflow = None
+        if not self.has_vals:
+            return (val, idx, None) if return_vals else (val, idx)
+        ids = idx >> self.LABEL_BITS                                          # -1 stays -1
+        if not return_vals:
+            return val, ids
+        vals = torch.where(idx < 0, torch.full_like(idx, self.val_last), idx & ((1 << self.LABEL_BITS) - 1)).to(torch.int32)
+        return val, ids, vals
+
+    def _search_once(self, q, k, query_block, dense_probes):
         n, dev = q.shape[0], self.device
         nprobe = min(self.nprobe, self.nlist)
-        dense = min(self.dense_probes, nprobe)
+        dense = max(1, min(dense_probes, nprobe))
         val = torch.empty(n, k, device=dev, dtype=torch.float32)
         idx = torch.empty(n, k, device=dev, dtype=torch.int64)
-        for q0 in range(0, n, query_block):
-            qs = q[q0:q0 + query_block]
-            nq = qs.shape[0]
-            qr = ops.gemm_nt(qs, self.R)                                            # q' = R q
-            cs = ops.gemm_nt(qr, self.coarse)                                       # <q', c_l>
-            pv = torch.empty(nq, nprobe, device=dev, dtype=torch.float32)
-            pi = torch.empty(nq, nprobe, device=dev, dtype=torch.int64)
-            ops.topk_merge(cs, pv, pi, largest=True, init=True)                     # the nprobe best lists, best first
-            lut = torch.empty(nq, self.M * 256, device=dev, dtype=torch.float32)    # lut[q][m][c] = <q'_m, p_mc>: M small GEMMs
-            g = _lib.gnnlm_gemm_t()
-            g.A, g.lda, g.W, g.ldw, g.C, g.ldc = qr.data_ptr(), qr.stride(0), self.pq.data_ptr(), self.dsub, lut.data_ptr(), self.M * 256
-            g.M, g.N, g.K, g.batch1 = nq, 256, self.dsub, self.M
-            g.sA1, g.sW1, g.sC1 = self.dsub, 256 * self.dsub, 256
-            _lib.call_desc("gnnlm_gemm_nt", g)
-            if self.packed_codes is not None:
-                lut_p = torch.empty_like(lut)
-                _lib.call("gnnlm_ivfpq_pack_lut", _lib.ptr(lut), lut.stride(0), nq, self.M, _lib.ptr(lut_p), _lib.stream())
-                lut = lut_p
-            bv, bi = val[q0:q0 + nq], idx[q0:q0 + nq]
-            # round 1: the best `dense` lists of every query, every score
-            ov = torch.empty(nq, dense * self.max_list, device=dev, dtype=torch.float32)
-            self._scan(lut, pv, pi, 0, dense, out=ov)
-            ops.topk_merge(ov, bv, bi, largest=True, init=True)                     # ids = columns of ov
-            # the columns kept -> key ids: column = probe slot * max_list + position in the list (-inf: beyond a list)
-            lst = torch.gather(pi, 1, torch.div(bi, self.max_list, rounding_mode="floor").clamp_(0, dense - 1))
-            pos = self.list_off[lst.clamp(min=0)] + bi % self.max_list
-            bi.copy_(torch.where(torch.isinf(bv) | (lst < 0), torch.full_like(bi, -1), self.list_ids[pos.clamp_(0, max(self.ntotal - 1, 0))]))
-            if nprobe > dense:
-                # round 2: the other lists only emit scores above the query's k-th best so far
-                tau = torch.where(bi[:, k - 1] >= 0, bv[:, k - 1], torch.full_like(bv[:, k - 1], float("-inf"))).contiguous()
-                cv = torch.empty(nq, self.cand_cap, device=dev, dtype=torch.float32)
-                ci = torch.empty(nq, self.cand_cap, device=dev, dtype=torch.int64)
-                cc = torch.zeros(nq, device=dev, dtype=torch.int32)
-                self._scan(lut, pv, pi, dense, nprobe, tau=tau, cand=(cv, ci, cc))
-                self._overflow = cc.max() if getattr(self, "_overflow", None) is None else torch.maximum(self._overflow, cc.max())
-                ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=False, row_ncols=cc.clamp(max=self.cand_cap))
-        return val, idx
+        if query_block is None:                                               # groups of 8 queries per list want many queries per block
+            query_block = 8192 if self.tiles is not None else 1024
+        # the dense round's score rows: query_block * dense * max_list floats, bounded (a skewed index has long lists)
+        qb = max(1, min(query_block, self.score_bytes // max(1, 4 * dense * max(self.max_list, 1))))
+        over = None
+        self.stats = {"pairs": torch.zeros((), device=dev, dtype=torch.float64), "survivors": torch.zeros((), device=dev, dtype=torch.float64),
+                      "candidates": torch.zeros((), device=dev, dtype=torch.float64), "queries": n, "M": self.M}
+        for q0 in range(0, n, qb):
+            o = self._search_block(q[q0:q0 + qb], k, val[q0:q0 + qb], idx[q0:q0 + qb], nprobe, dense)
+            if o is not None:
+                over = o if over is None else torch.cat([over, o])
+        return val, idx, over
+
+    def _search_block(self, qs, k, bv, bi, nprobe, dense):
+        dev = self.device
+        nq = qs.shape[0]
+        qr = ops.gemm_nt(qs, self.R)                                            # q' = R q
+        cs = ops.gemm_nt(qr, self.coarse)                                       # <q', c_l>
+        pv = torch.empty(nq, nprobe, device=dev, dtype=torch.float32)
+        pi = torch.empty(nq, nprobe, device=dev, dtype=torch.int64)
+        ops.topk_merge(cs, pv, pi, largest=True, init=True)                     # the nprobe best lists, best first
+        lens = self.list_off[1:] - self.list_off[:-1]
+        self.stats["pairs"] += lens[pi.clamp(min=0)].masked_fill(pi < 0, 0).sum()
+        lut = torch.empty(nq, self.M * 256, device=dev, dtype=torch.float32)    # lut[q][m][c] = <q'_m, p_mc>: M small GEMMs
+        g = _lib.gnnlm_gemm_t()
+        g.A, g.lda, g.W, g.ldw, g.C, g.ldc = qr.data_ptr(), qr.stride(0), self.pq.data_ptr(), self.dsub, lut.data_ptr(), self.M * 256
+        g.M, g.N, g.K, g.batch1 = nq, 256, self.dsub, self.M
+        g.sA1, g.sW1, g.sC1 = self.dsub, 256 * self.dsub, 256
+        _lib.call_desc("gnnlm_gemm_nt", g)
+        lut_s = lut
+        if self.packed_codes is not None:
+            lut_s = torch.empty_like(lut)
+            _lib.call("gnnlm_ivfpq_pack_lut", _lib.ptr(lut), lut.stride(0), nq, self.M, _lib.ptr(lut_s), _lib.stream())
+        # round 1: the best `dense` lists of every query, every score
+        ov = torch.empty(nq, dense * self.max_list, device=dev, dtype=torch.float32)
+        self._scan(lut_s, pv, pi, 0, dense, out=ov)
+        ops.topk_merge(ov, bv, bi, largest=True, init=True)                     # ids = columns of ov
+        # the columns kept -> payloads: column = probe slot * max_list + position in the list (-inf: beyond a list)
+        lst = torch.gather(pi, 1, torch.div(bi, self.max_list, rounding_mode="floor").clamp_(0, dense - 1))
+        pos = self.list_off[lst.clamp(min=0)] + bi % self.max_list
+        bi.copy_(torch.where(torch.isinf(bv) | (lst < 0), torch.full_like(bi, -1), self.payload[pos.clamp_(0, max(self.ntotal - 1, 0))]))
+        if nprobe <= dense:
+            return None
+        # round 2: the other lists only emit scores above the query's k-th best so far
+        cap = self.cand_cap
+        tau = torch.where(bi[:, k - 1] >= 0, bv[:, k - 1], torch.full_like(bv[:, k - 1], float("-inf"))).contiguous()
+        cv = torch.empty(nq, cap, device=dev, dtype=torch.float32)
+        ci = torch.empty(nq, cap, device=dev, dtype=torch.int64)
+        cc = torch.zeros(nq, device=dev, dtype=torch.int32)
+        if self.tiles is None:
+            self._scan(lut_s, pv, pi, dense, nprobe, tau=tau, cand=(cv, ci, cc))
+            over = cc
+        else:
+            # filter on the int8 matrix cores (a superset of {score > tau}), then the exact float32 scores of what passed
+            qlut, qmeta = ops.ivfpq_quantize_lut(lut, self.M)
+            grp_list, grp_q, n_groups, G = self._groups(pi[:, dense:nprobe])
+            surv = torch.empty(nq, cap, 2, device=dev, dtype=torch.int32)
+            sc = torch.zeros(nq, device=dev, dtype=torch.int32)
+            d = _lib.gnnlm_ivfpq_scan8_t()
+            d.tiles, d.list_off, d.M = self.tiles.data_ptr(), self.list_off.data_ptr(), self.M
+            d.qlut, d.qmeta, d.coarse, d.ld_coarse, d.tau = qlut.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0), tau.data_ptr()
+            d.grp_list, d.grp_q, d.n_groups, d.max_groups = grp_list.data_ptr(), grp_q.data_ptr(), n_groups.data_ptr(), G
+            d.surv, d.surv_cnt, d.cap = surv.data_ptr(), sc.data_ptr(), cap
+            _lib.call_desc("gnnlm_ivfpq_scan8", d)
+            r = _lib.gnnlm_ivfpq_rescore_t()
+            r.codes, r.payload, r.M = self.list_codes.data_ptr(), self.payload.data_ptr(), self.M
+            r.lut, r.ld_lut, r.coarse, r.ld_coarse, r.tau = lut.data_ptr(), lut.stride(0), cs.data_ptr(), cs.stride(0), tau.data_ptr()
+            r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), sc.data_ptr(), cap, nq
+            r.cand_val, r.cand_id, r.cand_cnt, r.cand_cap = cv.data_ptr(), ci.data_ptr(), cc.data_ptr(), cap
+            _lib.call_desc("gnnlm_ivfpq_rescore", r)
+            over = sc                                                          # every candidate is a survivor: sc >= cc
+            self.stats["survivors"] += sc.sum()
+        self.stats["candidates"] += cc.sum()
+        if getattr(self, "keep_candidates", False):                          # tests / debugging: the round-2 candidates of the last block
+            self.last_candidates = (cv, ci, cc, tau)
+        ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=False, row_ncols=cc.clamp(max=cap))
+        return over
 
     def check(self):
-        """Raise if a query had more round-2 survivors than candidate slots (cannot happen after search_device returned: it
-        repeats such a call with more room; kept for callers of the one-pass search)."""
-        ov = getattr(self, "_overflow", None)
-        if ov is not None and int(ov.item()) > self.cand_cap:
-            raise RuntimeError(f"IVFPQIndex: {int(ov.item())} candidates for one query exceed cand_cap={self.cand_cap}; "
-                               "raise cand_cap or dense_probes")
+        """Kept for callers of earlier versions: ``search_device`` itself re-searches queries whose survivors did not fit."""
+        return None
 
     def search(self, queries, k):
         d, i = self.search_device(torch.as_tensor(np.asarray(queries)), k)
-        self.check()
         return d.cpu().numpy(), i.cpu().numpy()

@@ -112,6 +112,10 @@ class KNNModel(object):
         self.device = torch.device(device if device is not None else "cuda")
         self.index = index if index is not None else self.setup_faiss()
         self._vals_dev = None
+        # an IVF-PQ index searched on the device carries the labels next to the key ids (one payload per key): the search
+        # hands `self.vals[knns]` (knn_model.py:198) back with the neighbours and the per-query label gather disappears
+        if getattr(self.index, "attach_vals", None) is not None and not self.index.has_vals and self.data_store.val_size == 1:
+            self.index.attach_vals(self.vals_device())
 
     @property
     def cosine(self):
@@ -184,10 +188,13 @@ class KNNModel(object):
         return self.index.search(queries.astype(np.float32), k)
 
     def _search(self, knn_queries, k):
+        """-> (dists, knns, knn_vals or None): knn_vals = vals[knns] when the index delivers the labels itself."""
+        if getattr(self.index, "has_vals", False):
+            return self.index.search_device(knn_queries, k, return_vals=True)
         if hasattr(self.index, "search_device"):
-            return self.index.search_device(knn_queries, k)
+            return tuple(self.index.search_device(knn_queries, k)) + (None,)
         d, i = self.get_knns(knn_queries, k)
-        return torch.from_numpy(d).to(self.device), torch.from_numpy(i).to(self.device)
+        return torch.from_numpy(d).to(self.device), torch.from_numpy(i).to(self.device), None
 
     def _sims(self, dists, knns, queries):
         """sim_func dispatch of knn_model.py:137-177 (device tensors)."""
@@ -210,14 +217,15 @@ class KNNModel(object):
             return (vecs * queries[:, None, :]).sum(dim=-1)
         raise ValueError("Invalid knn similarity function!")
 
-    def search_sims(self, queries, k=0):
-        """queries [n, d] (device) -> (sims [n,k] f32, knns [n,k] i64), before the -1 masking."""
+    def search_sims(self, queries, k=0, with_vals=False):
+        """queries [n, d] (device) -> (sims [n,k] f32, knns [n,k] i64[, knn_vals [n,k] i32 or None]), before the -1 masking."""
         k = k or self.k
         q = queries.float()
         if self.cosine:                                                                 # :181-184
             q = q / (q ** 2).sum(-1, keepdims=True).sqrt()
-        dists, knns = self._search(q, k)
-        return self._sims(dists, knns, q).contiguous(), knns.contiguous()
+        dists, knns, kvals = self._search(q, k)
+        out = (self._sims(dists, knns, q).contiguous(), knns.contiguous())
+        return out + (None if kvals is None else kvals.contiguous(),) if with_vals else out
 
     def get_knn_prob(self, queries, k: int = 0, output_size: int = None, return_knn: bool = False, t: float = 1.0,
                      targets: torch.Tensor = None, return_recall: bool = False):
@@ -227,7 +235,7 @@ class KNNModel(object):
             raise ValueError("DataStore.info does not have vocab_size, please set output_size manually")
         if not queries.is_cuda:
             raise _lib.GnnlmError("KNNModel.get_knn_prob runs on the GPU; there is no CPU fallback")
-        sims, knns = self.search_sims(queries, k)
+        sims, knns, kvals = self.search_sims(queries, k, with_vals=True)
         vals = self.vals_device()
         if targets is None:                     # dense [batch, V] variant: not on the eval path (torch ops)
             masked = sims.masked_fill(knns == -1, -1e10)
@@ -239,11 +247,11 @@ class KNNModel(object):
         n = sims.shape[0]
         zeros = torch.zeros(n, device=sims.device, dtype=torch.float32)
         _, p, recall = ops.knn_interp(zeros, sims, knns, targets.to(sims.device).long().contiguous(), t, 0.5,
-                                      vals=vals, n_store=self.dstore_size)
+                                      vals=vals if kvals is None else None, n_store=self.dstore_size, knn_vals=kvals)
         return (p, recall) if return_recall else p
 
     def interpolate(self, queries, targets, lm_logp, t, lmbda, k=0):
         """Fused hot-path form: search -> (interpolated log-prob [n], p_knn [n], recall [n])."""
-        sims, knns = self.search_sims(queries, k)
+        sims, knns, kvals = self.search_sims(queries, k, with_vals=True)
         return ops.knn_interp(lm_logp.contiguous(), sims, knns, targets.long().contiguous(), t, lmbda,
-                              vals=self.vals_device(), n_store=self.dstore_size)
+                              vals=self.vals_device() if kvals is None else None, n_store=self.dstore_size, knn_vals=kvals)

@@ -336,6 +336,30 @@ def topk_merge(scores, best_val, best_id, col0=0, col_ids=None, col_scale=None, 
     return best_val, best_id
 
 
+def ivfpq_pack_tiles(codes):
+    """codes [N, 64] u8 -> the int8-MFMA scan's image (csrc/ivfpq_mfma.hip): ceil(N / 16) tiles x [4 groups][16 rows][16 bytes],
+    byte p of (tile t, group g, row i) = codes[16 t + i][16 g + (i + p) % 16]; rows beyond N are zero."""
+    _dev(codes)
+    _dtype(codes, torch.uint8, "codes")
+    N, M = codes.shape
+    out = torch.empty(-(-N // 16) * 16 * M, dtype=torch.uint8, device=codes.device)
+    call("gnnlm_ivfpq_pack_tiles", ptr(codes), N, M, ptr(out), stream())
+    return out
+
+
+def ivfpq_quantize_lut(lut, M=64):
+    """lut [n, M * 256] f32 -> (qlut [n, 2, 256, 32] u8, qmeta [n, 4] f32 = {delta, sum_m lo_m, max |lut|, 0}) with
+    lut[m][c] < lo_m + (u + 1) * delta for every entry, u = qlut[m // 32][c][m % 32] ^ 0x80 (the table stores the signed
+    byte u - 128, what the i8 matrix instruction reads) -- the filter's one-sided bound."""
+    _dev(lut)
+    _f32(lut)
+    n = lut.shape[0]
+    qlut = torch.empty(n, 2, 256, 32, dtype=torch.uint8, device=lut.device)
+    qmeta = torch.empty(n, 4, dtype=torch.float32, device=lut.device)
+    call("gnnlm_ivfpq_quantize_lut", ptr(lut), lut.stride(0), n, M, ptr(qlut), ptr(qmeta), stream())
+    return qlut, qmeta
+
+
 def masked_sum_f64(x, mask=None, acc=None):
     if acc is None:
         acc = torch.zeros(1, device=x.device, dtype=torch.float64)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNLM_ABI_VERSION 5
+#define GNNLM_ABI_VERSION 6
 #define GNNLM_OK 0
 #define GNNLM_E_INVALID (-22)
 #define GNNLM_E_NOMEM (-12)
@@ -299,6 +299,45 @@ int gnnlm_ivfpq_scan(const gnnlm_ivfpq_scan_t* desc, void* stream);
  * sub-quantizer (lane + s) mod 32 and the 32 lanes of an LDS access group always use 32 different banks. */
 int gnnlm_ivfpq_pack_codes(const uint8_t* codes, int64_t N, int32_t M, uint8_t* out, void* stream);
 int gnnlm_ivfpq_pack_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ABI 6: the filtered scan on the int8 matrix cores, M = 64 (csrc/ivfpq_mfma.hip) -- the thresholded round of the same
+ * search (faiss IndexIVFPQ.search behind knn/knn_model.py:100), as a FILTER with a guaranteed bound followed by an exact
+ * float32 re-score, so that the candidates and their scores are those of the one-pass float32 scan above:
+ *   gnnlm_ivfpq_pack_tiles     codes [N, 64] -> the scan's image: tiles of 16 rows, [tile][g 0..3][i 0..15][p 0..15] =
+ *                              code[16 tile + i][16 g + (i + p) % 16], ceil(N / 16) * 1024 bytes, rows beyond N zero
+ *   gnnlm_ivfpq_quantize_lut   lut [n, 64, 256] f32 -> qlut [n][2 halves][256 codes][32 slots] u8 and qmeta [n, 4] f32 =
+ *                              {delta, sum_m lo_m, max |lut|, 0} with  lut[m][c] < lo_m + (u + 1) delta  for every entry; the
+ *                              table byte is the signed u - 128 (what the i8 matrix instruction reads)
+ *   gnnlm_ivfpq_scan8          one workgroup per GROUP = up to 8 queries probing one list; a key (row of the list-ordered
+ *                              index) is appended to surv[q] = {row, list} iff the integer sum of its 64 table bytes
+ *                              reaches the integer image of tau[q] -- a superset of {score > tau[q]}
+ *   gnnlm_ivfpq_rescore        exact scores of the survivors (summation order of gnnlm_ivfpq_scan's packed kernel),
+ *                              score > tau[q] -> (cand_val, cand_id = payload[row]); cand_cnt[q] counts all of them
+ * ---------------------------------------------------------------------------------------------- */
+int gnnlm_ivfpq_pack_tiles(const uint8_t* codes, int64_t N, int32_t M, uint8_t* out, void* stream);
+int gnnlm_ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M, uint8_t* qlut, float* qmeta, void* stream);
+typedef struct gnnlm_ivfpq_scan8 {
+    const uint8_t* tiles;  const int64_t* list_off;  int32_t M;
+    const uint8_t* qlut;  const float* qmeta;
+    const float* coarse;  int64_t ld_coarse;          /* [n, nlist] <q', centroid_l>: the bias of list l */
+    const float* tau;                                 /* [n] */
+    const int32_t* grp_list;  const int32_t* grp_q;   /* [max_groups] list (-1: none), [max_groups, 8] queries (-1: none), sorted by list */
+    const int32_t* n_groups;  int32_t max_groups;     /* DEVICE count of groups in use (no host round trip), capacity of the arrays */
+    uint32_t* surv;  int32_t* surv_cnt;  int32_t cap; /* [n, cap, 2] {row, list}; surv_cnt[q] counts ALL survivors (overflow check) */
+} gnnlm_ivfpq_scan8_t;
+int gnnlm_ivfpq_scan8(const gnnlm_ivfpq_scan8_t* desc, void* stream);
+typedef struct gnnlm_ivfpq_rescore {
+    const uint8_t* codes;  const int64_t* payload;    /* [N, M] list-ordered codes, [N] what a candidate carries (key id, or id << 24 | label) */
+    int32_t M;
+    const float* lut;  int64_t ld_lut;                /* [n, M * 256] f32 */
+    const float* coarse;  int64_t ld_coarse;
+    const float* tau;
+    const uint32_t* surv;  const int32_t* surv_cnt;  int32_t cap;
+    int64_t n;
+    float* cand_val;  int64_t* cand_id;  int32_t* cand_cnt;  int32_t cand_cap;
+} gnnlm_ivfpq_rescore_t;
+int gnnlm_ivfpq_rescore(const gnnlm_ivfpq_rescore_t* desc, void* stream);
 
 /* out[0] += sum_i x[i] * (mask ? mask[i] != 0 : 1), accumulated in f64 (score_sum of
  * fairseq_cli/eval_lm.py:273; the reference accumulates in f32 on the CPU) */
