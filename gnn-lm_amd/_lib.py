@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("GNNLM_LIB") or os.path.join(_HERE, "lib", "libgnnlm_h
 _SCALARS = {
     "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
     "double": ctypes.c_double, "size_t": ctypes.c_size_t, "uint8_t": ctypes.c_uint8, "int": ctypes.c_int,
+    "uint16_t": ctypes.c_uint16, "uint32_t": ctypes.c_uint32,
 }
 
 
@@ -123,7 +124,7 @@ def lib():
         L.gnnlm_hgt_forward.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
         for nm in ("gnnlm_gemm_nt", "gnnlm_pq_gather_decode", "gnnlm_star_attn", "gnnlm_chain_attn",
                    "gnnlm_knn_interp", "gnnlm_topk_merge", "gnnlm_ivfpq_scan", "gnnlm_gather_rows_peer",
-                   "gnnlm_ivfpq_scan8", "gnnlm_ivfpq_rescore"):
+                   "gnnlm_ivfpq_scan8", "gnnlm_ivfpq_rescore", "gnnlm_ivfpq_tau"):
             getattr(L, nm).argtypes = [vp, vp]
         if L.gnnlm_target_arch() != b"gfx950" or L.gnnlm_abi_version() != ABI_VERSION:
             raise GnnlmError(f"libgnnlm_hip.so is not the gfx950 / ABI-{ABI_VERSION} build")

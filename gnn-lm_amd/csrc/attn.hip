@@ -835,12 +835,7 @@ int causal_attn_fused(const float* Q, const float* K, const float* V, int64_t ld
                   "causal_attn: operands must be 16-byte aligned with ld % 4 == 0");
     if (n_blocks == 0) return OK;
     constexpr size_t lds_bytes = 2 * 64 * (128 + 8) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&causal_attn_256x128_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
-    }
+    GNNLM_LDS_OPT_IN(&causal_attn_256x128_kernel, lds_bytes);
     CausalAttnParams p{Q, K, V, out, ld, ldo, n_blocks, H, max_ctx, accumulate ? 1 : 0};
     const double pairs = (double)n_blocks * H;
     // algorithmic: the causal half of 2 * (T * T * dk) * 2 flops per (block, head)

@@ -31,7 +31,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // Opt-in per-kernel timing with HIP events on the launch stream (bench.py's live roofline).
 enum KernelId { K_GEMM = 0, K_GATHER = 1, K_STAR = 2, K_CHAIN = 3, K_CAUSAL = 4, K_LAYERNORM = 5, K_LSE = 6,
-                K_KNN = 7, K_MISC = 8, K_SPLIT = 9, K_TOPK = 10, K_IVF = 11, K_COUNT = 12 };
+                K_KNN = 7, K_MISC = 8, K_SPLIT = 9, K_TOPK = 10, K_IVF = 11, K_IVF8 = 12, K_RESCORE = 13, K_COUNT = 14 };
 extern unsigned g_prof_mask;
 void prof_start(int kid, hipStream_t s);
 // flops / bytes: algorithmic work of the launch; if scale_dev != null the work is multiplied by
@@ -52,6 +52,15 @@ struct ProfScope {
     }
     ~ProfScope() { if (on) prof_stop(kid, s, flops, bytes, sd, den, slot); }
 };
+
+// Dynamic LDS beyond 64 KiB has to be allowed per kernel function AND per device (hipFuncSetAttribute acts on the current
+// device's copy of the function): done once per (function, device), whichever thread or device comes first.
+int lds_opt_in(const void* kernel_fn, int bytes);
+#define GNNLM_LDS_OPT_IN(fn, bytes)                                                          \
+    do {                                                                                     \
+        const int _rc = ::gnnlm::lds_opt_in(reinterpret_cast<const void*>(fn), (int)(bytes)); \
+        if (_rc != ::gnnlm::OK) return _rc;                                                  \
+    } while (0)
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

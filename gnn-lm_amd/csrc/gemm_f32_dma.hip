@@ -313,12 +313,7 @@ bool gemm_dma_eligible(const GemmParams& p) {
 template <int EPI, int BK, int BT>
 int launch_dma(const GemmParams& p, dim3 grid, hipStream_t stream) {
     constexpr size_t lds_bytes = 2 * (size_t)(2 * BT * BK) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {      // > 64 KiB of dynamic LDS has to be allowed once per kernel
-        GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_dma_kernel<EPI, BK, BT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
-    }
+    GNNLM_LDS_OPT_IN((&gemm_nt_f32_dma_kernel<EPI, BK, BT>), lds_bytes);      // > 64 KiB of dynamic LDS: once per kernel and device
     hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<EPI, BK, BT>), grid, dim3(BT == 256 ? 512 : 256), lds_bytes, stream, p);
     return OK;
 }
@@ -328,12 +323,7 @@ int gemm_nt_dma(const GemmParams& p_in, hipStream_t stream) {
     constexpr int BK = GNNLM_DMA_BK;
     if (p.K == 64 && p.lse_part) {      // short-K log-sum-exp: A stays in registers, workgroups walk the n-tiles
         constexpr size_t lds_bytes = (128 * 64 + 128) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lse_astationary_kernel<64>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            attr_set = true;
-        }
+        GNNLM_LDS_OPT_IN(&gemm_lse_astationary_kernel<64>, lds_bytes);
         const double work = 2.0 * p.M * (double)p.N * p.K;
         ProfScope prof(K_GEMM, stream, work, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N),
                        p.m_dev, (double)p.M, true);

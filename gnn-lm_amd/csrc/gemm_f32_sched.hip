@@ -240,12 +240,7 @@ bool gemm_sched_eligible(const GemmParams& p) {
 template <int EPI>
 static int launch_sched(const GemmParams& p, dim3 grid, hipStream_t stream) {
     constexpr size_t lds_bytes = 2 * 256 * 32 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_sched_kernel<EPI>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
-    }
+    GNNLM_LDS_OPT_IN(&gemm_nt_f32_sched_kernel<EPI>, lds_bytes);
     hipLaunchKernelGGL((gemm_nt_f32_sched_kernel<EPI>), grid, dim3(256), lds_bytes, stream, p);
     return OK;
 }

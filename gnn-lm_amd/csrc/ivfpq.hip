@@ -556,33 +556,21 @@ int ivfpq_scan(const gnnlm_ivfpq_scan_t& d, hipStream_t stream) {
     if (d.tau) GNNLM_REQUIRE(d.cand_val && d.cand_id && d.cand_cnt && d.cap > 0, "ivfpq_scan: filtered mode needs the candidate buffers");
     else GNNLM_REQUIRE(d.out_val && d.seg > 0 && d.ld_out >= d.seg, "ivfpq_scan: dense mode needs the output rows");
     const size_t lds = (size_t)d.M * 256 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivfpq_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
+    GNNLM_LDS_OPT_IN(&ivfpq_scan_kernel, 128 * 1024);
     ProfScope prof(K_IVF, stream, 0.0, 0.0);
     if (d.packed) {
         GNNLM_REQUIRE(d.M == 32 || d.M == 64, "ivfpq_scan: the packed image exists for M = 32 and 64");
         const int64_t n_pairs = cdiv(d.n_tasks, (int64_t)2);
         const int per_xcd = (int)cdiv(n_pairs, (int64_t)8);
-        static bool attr3_set = false;
-        if (!attr3_set) {
-            GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivfpq_scan_rot_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + STAGE_BYTES));
-            GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivfpq_scan_rot_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + STAGE_BYTES));
-            attr3_set = true;
-        }
+        GNNLM_LDS_OPT_IN(&ivfpq_scan_rot_kernel<64>, 128 * 1024 + STAGE_BYTES);
+        GNNLM_LDS_OPT_IN(&ivfpq_scan_rot_kernel<32>, 64 * 1024 + STAGE_BYTES);
         if (d.M == 64) hipLaunchKernelGGL(ivfpq_scan_rot_kernel<64>, dim3((unsigned)(8 * per_xcd)), dim3(1024), 2 * lds + STAGE_BYTES, stream, d, n_pairs, per_xcd);
         else hipLaunchKernelGGL(ivfpq_scan_rot_kernel<32>, dim3((unsigned)(8 * per_xcd)), dim3(1024), 2 * lds + STAGE_BYTES, stream, d, n_pairs, per_xcd);
         GNNLM_LAUNCH_CHECK();
         return OK;
     }
     if (d.M <= 64 && !getenv("GNNLM_IVF_SINGLE")) {
-        static bool attr2_set = false;
-        if (!attr2_set) {
-            GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivfpq_scan2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr2_set = true;
-        }
+        GNNLM_LDS_OPT_IN(&ivfpq_scan2_kernel, 128 * 1024);
         hipLaunchKernelGGL(ivfpq_scan2_kernel, dim3((unsigned)cdiv(d.n_tasks, 2)), dim3(1024), 2 * lds, stream, d);
         GNNLM_LAUNCH_CHECK();
         return OK;

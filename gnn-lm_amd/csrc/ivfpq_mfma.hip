@@ -32,6 +32,7 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr int QG = 8;                                   // queries per workgroup
 constexpr int TAB_BYTES = 2 * 256 * 32 * QG;            // [half][code][slot][query]: 128 KiB
 constexpr int STAGE_CAP = 640;                          // survivors staged per query and task
@@ -121,10 +122,16 @@ __global__ __launch_bounds__(256) void quantize_lut_kernel(const float* __restri
 }
 
 #define GNNLM_PERM(hi_, lo_, sel_) __builtin_amdgcn_perm((hi_), (lo_), (sel_))
+#ifndef GNNLM_IVF8_ORDER
+#define GNNLM_IVF8_ORDER 1      // 1: the next tile's look-ups interleaved with this tile's MFMAs (8.8 ms); 0: look-ups first (11.0 ms)
+#endif
 #ifndef GNNLM_IVF8_EXP
-#define GNNLM_IVF8_EXP 0        // ablation builds: 1 no code loads, 2 no table fill, 4 no look-ups (MFMAs on constants), 8 no MFMAs
+#define GNNLM_IVF8_EXP 0        // ablation builds (no survivors): 1 no code loads, 2 no table fill, 4 no look-ups, 8 no MFMAs, 16 nothing else
 #endif
 
+// SUMS = false: the filter (survivors of the integer threshold).  SUMS = true: the threshold pass -- every key's integer sum
+// (+ 128 * 64, i.e. sum_u) is written as uint16 to the (query, dense slot) segment grp_out names; nothing is compared.
+template <bool SUMS>
 __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // tables at LDS address 0 (look-up addresses are absolute)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,7 +181,12 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     const int j = lane & 15, g = lane >> 4;
     int T = 0x7fffffff;
     const int qj = j < QG ? gq[j] : -1;                                   // (a register array may not be indexed by the lane)
-    if (qj >= 0) {
+    uint16_t* osum = nullptr;                                                // SUMS: this lane's (query, slot) segment
+    if (SUMS) {
+        const int64_t ob = j < QG ? p.grp_out[(int64_t)grp * QG + j] : -1;
+        if (qj >= 0 && ob >= 0) osum = p.out_sum + ob;
+    }
+    if (!SUMS && qj >= 0) {
         const int64_t q = qj;
         const float delta = p.qmeta[q * 4], sum_lo = p.qmeta[q * 4 + 1], amax = p.qmeta[q * 4 + 2];
         const float bias = p.coarse[q * p.ld_coarse + list], tau = p.tau[q];
@@ -184,6 +196,9 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
         // the table bytes are u - 128 (signed): the MFMA's sums are sum_u - 128 * 64
         T = !(thr == thr) || thr <= -1.0e9f ? -(1 << 30) : (thr >= 1.0e9f ? 0x7fffffff : (int)floorf(thr) - 128 * 64);
     }
+#if GNNLM_IVF8_EXP
+    T = 0x7fffffff;                                  // ablation builds time the main loop: nothing survives
+#endif
     if (tid < 16) scnt[tid] = 0;
     __syncthreads();
 
@@ -197,63 +212,132 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     const uint32_t b0 = j < 4 ? 1u << (8 * j) : 0u, b1 = (j >= 4 && j < 8) ? 1u << (8 * (j - 4)) : 0u;
     const v4i Bc = {(int)b0, (int)b1, (int)b0, (int)b1};                    // B[(look-up, query)][j] = [query == j]
 
-    const int64_t t_hi = (hi - 1) >> 4;
-    const uint4* img = reinterpret_cast<const uint4*>(p.tiles);
-    int64_t t = (lo >> 4) + wave;
-    uint4 cw = uint4{0u, 0u, 0u, 0u}, n1 = cw;          // this tile's code bytes, the next one's; the one after is requested in the loop
-#if !(GNNLM_IVF8_EXP & 1)
-    if (t <= t_hi) cw = img[t * 64 + lane];
-    if (t + 16 <= t_hi) n1 = img[(t + 16) * 64 + lane];
-#endif
-    for (; t <= t_hi; t += 16) {
-        uint4 n2 = n1;
-#if !(GNNLM_IVF8_EXP & 1)
-        if (t + 32 <= t_hi) n2 = img[(t + 32) * 64 + lane];                 // two tiles ahead: an HBM round trip under two tiles of look-ups
+    // ---- the list's tiles: wave w takes tiles w, w + 16, ... two per step.  Everything that steers the loop is scalar (the wave
+    // index through readfirstlane), the code bytes come by buffer loads off one resource over the list's tile range (lane
+    // offset in a VGPR, tile offset in an SGPR, out-of-range tiles read as zeros): no vector instruction is spent on addresses
+    const int64_t t_lo = lo >> 4;
+    const int nt = (int)(((hi - 1) >> 4) - t_lo) + 1;                        // tiles that hold rows of the list
+    const int len = (int)(hi - lo), row_shift = (int)(lo & 15);               // local row of (tile u, key i) = 16 u + i - row_shift
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.tiles) + t_lo * 1024, 0, nt * 1024, 0x00020000);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int voff = lane * 16;
+    auto load_tile = [&](int u) -> v4u {
+#if GNNLM_IVF8_EXP & 1
+        return v4u{(uint32_t)u * 2654435761u + lane, (uint32_t)u * 40503u ^ lane, (uint32_t)u + 77u * lane, (uint32_t)u * 3u + lane};
 #else
-        cw.x += 0x01030507u; cw.y += 0x02040608u; cw.z += 0x0b0d0f11u; cw.w += 0x13171d1fu;
-        n1 = cw;
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane(u * 1024), 0);   // (u is wave-uniform: tell the compiler)
 #endif
+    };
+    // 16 look-ups of one tile: address = {0, half, code byte, slot offset} by one v_perm_b32 each
+    auto lookups = [&](const v4u& cw, v4i (&A)[8]) {
         const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
-        // all 16 look-ups of the tile in flight, then the 8 MFMAs (the other waves of the SIMD fill the matrix pipe meanwhile)
-        u32x2 x[16];
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) {
-            // address = {0, half, code byte, slot offset}: byte 0 <- tc byte (pp & 1), byte 1 <- w byte (pp & 3), byte 2 <- tc byte 2
-            const uint32_t a = GNNLM_PERM(w[pp >> 2], tc[pp >> 1], 0x0c020000u | (uint32_t)(4 + (pp & 3)) << 8 | (uint32_t)(pp & 1));
+        for (int s = 0; s < 8; ++s) {
+            const int p0 = 2 * s, p1 = 2 * s + 1;
+            const uint32_t a0 = GNNLM_PERM(w[p0 >> 2], tc[s], 0x0c020000u | (uint32_t)(4 + (p0 & 3)) << 8 | 0u);
+            const uint32_t a1 = GNNLM_PERM(w[p1 >> 2], tc[s], 0x0c020000u | (uint32_t)(4 + (p1 & 3)) << 8 | 1u);
 #if GNNLM_IVF8_EXP & 4
-            x[pp] = u32x2{a, a ^ 0x5a5a5a5au};
+            const u32x2 x0 = u32x2{a0, a1}, x1 = u32x2{a1, a0};
 #else
-            x[pp] = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(a);
+            const u32x2 x0 = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(a0);
+            const u32x2 x1 = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(a1);
 #endif
+            A[s] = v4i{(int)x0.x, (int)x0.y, (int)x1.x, (int)x1.y};
         }
+    };
+    // survivors of one tile (entered when some lane of the wave has one): ONE LDS atomic per lane
+    auto survivors = [&](const v4i& acc, int u) {
+        const int r0 = 16 * u + 4 * g - row_shift;
+        bool sv[4];
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sv[r] = acc[r] >= T && (unsigned)(r0 + r) < (unsigned)len;       // rows of the neighbouring lists in the edge tiles drop out here
+            cnt += sv[r];
+        }
+        if (cnt) {
+            int pos = atomicAdd(&scnt[j], cnt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (!sv[r]) continue;
+                if (pos < STAGE_CAP) sbuf[j * STAGE_CAP + pos] = (uint32_t)(r0 + r);
+                else {                                                       // staging full: straight to the query's list
+                    const int gp = atomicAdd(&p.surv_cnt[qj], 1);
+                    if (gp < p.cap) surv[(int64_t)qj * p.cap + gp] = uint2{(uint32_t)(lo + r0 + r), (uint32_t)list};
+                }
+                ++pos;
+            }
+        }
+    };
+    // Software pipeline, one tile per step: the 8 MFMAs of tile i are issued interleaved with the 16 look-ups of tile i + 1
+    // (address + read pairs between the matrix instructions), the code bytes of tile i + 3 are requested at the top of the
+    // step.  Look-up results alternate between two register sets, code bytes rotate through three: the loop is unrolled six
+    // times so that every name is static.
+    auto step = [&](v4i (&Xc)[8], v4i (&Xn)[8], const v4u& cn, v4u& cl, int u) {
+        cl = load_tile(u + 48);
+        lookups(cn, Xn);
         v4i acc = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const v4i A = {(int)x[2 * s].x, (int)x[2 * s].y, (int)x[2 * s + 1].x, (int)x[2 * s + 1].y};
 #if GNNLM_IVF8_EXP & 8
-            acc += A;
+            acc += Xc[s];
 #else
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, Bc, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Xc[s], Bc, acc, 0, 0, 0);
 #endif
         }
-        const int mx = max(max(acc[0], acc[1]), max(acc[2], acc[3]));
-        if (__builtin_amdgcn_ballot_w64(mx >= T) != 0ull) {                  // rare: a fraction of a percent of the keys survive
+#if !(GNNLM_IVF8_EXP & 12)
+#if GNNLM_IVF8_ORDER == 0
+        // the next tile's 16 look-ups first (address + read pairs), then this tile's 8 matrix instructions: every read has the
+        // whole MFMA chain and the test behind it to come back before the next step needs it
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = t * 16 + 4 * g + r;
-                if (acc[r] >= T && row >= lo && row < hi) {
-                    const int pos = atomicAdd(&scnt[j], 1);
-                    if (pos < STAGE_CAP) sbuf[j * STAGE_CAP + pos] = (uint32_t)(row - lo);
-                    else {                                                   // staging full: straight to the query's list
-                        const int gp = atomicAdd(&p.surv_cnt[qj], 1);
-                        if (gp < p.cap) surv[(int64_t)qj * p.cap + gp] = uint2{(uint32_t)row, (uint32_t)list};
-                    }
-                }
-            }
+        for (int e = 0; e < 16; ++e) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        cw = n1;
-        n1 = n2;
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#else
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one matrix instruction of this tile,
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);               // two look-up addresses and
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);               // their two reads of the next tile
+        }
+#endif
+#endif
+        if (SUMS) {
+            // the lane's four keys (rows 4 g .. 4 g + 3 of the tile) of query j as one aligned 8-byte store; the segment is indexed
+            // by the position in the TILE range of the list (first row of the list at row_shift): rows of the neighbouring lists
+            // in the two edge tiles are written too and skipped by the reader (ivfpq_tau_kernel)
+            if (osum) {
+                const v4i b = acc + 128 * 64;
+                *reinterpret_cast<u32x2*>(osum + 16 * u + 4 * g) = u32x2{(uint32_t)b[0] | (uint32_t)b[1] << 16, (uint32_t)b[2] | (uint32_t)b[3] << 16};
+            }
+        } else {
+            const int mx = max(max(acc[0], acc[1]), max(acc[2], acc[3]));
+            if (__builtin_amdgcn_ballot_w64(mx >= T) != 0ull) survivors(acc, u);
+        }
+    };
+    {
+        int u = wv;
+        v4i XA[8], XB[8];
+        v4u C0 = load_tile(u), C1 = load_tile(u + 16), C2 = load_tile(u + 32);   // (loads beyond the list's tiles return zeros)
+        lookups(C0, XA);
+        while (true) {
+            if (u >= nt) break;
+            step(XA, XB, C1, C0, u); u += 16;
+            if (u >= nt) break;
+            step(XB, XA, C2, C1, u); u += 16;
+            if (u >= nt) break;
+            step(XA, XB, C0, C2, u); u += 16;
+            if (u >= nt) break;
+            step(XB, XA, C1, C0, u); u += 16;
+            if (u >= nt) break;
+            step(XA, XB, C2, C1, u); u += 16;
+            if (u >= nt) break;
+            step(XB, XA, C0, C2, u); u += 16;
+        }
     }
+    if (SUMS) return;
     __syncthreads();
     if (tid < QG) {
         const int n = min(scnt[tid], STAGE_CAP), qt = gq[tid];
@@ -268,46 +352,147 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     }
 }
 
+// Threshold from the integer sums of a query's D dense lists (written by the SUMS pass): a LOWER bound of its k-th best exact
+// score.  score(x) >= bias_l + sum_lo + sum_u(x) delta' (delta' a hair below delta), so with v(x) = sum_u(x) + floor((bias_l -
+// bias_min) / delta) the k-th largest v gives tau = bias_min + sum_lo + v_k delta' - eps: at least k keys score >= tau.  The k-th
+// largest comes from a histogram of v >> 2 in LDS (the lower bin edge is taken: a bound, not a selection).
+constexpr int TAU_BINS = 16384;
+__global__ __launch_bounds__(1024) void ivfpq_tau_kernel(gnnlm_ivfpq_tau_t p) {
+    __shared__ int hist[TAU_BINS];
+    __shared__ int part[1024];
+    __shared__ int bstar_s;
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    for (int e = tid; e < TAU_BINS; e += 1024) hist[e] = 0;
+    const float delta = p.qmeta[q * 4], sum_lo = p.qmeta[q * 4 + 1], amax = p.qmeta[q * 4 + 2];
+    float bmin = INFINITY, bmax = -INFINITY;
+    for (int d = 0; d < p.D; ++d) {
+        if (p.probe_list[q * p.ld_probe + d] < 0) continue;
+        const float b = p.probe_bias[q * p.ld_probe + d];
+        bmin = fminf(bmin, b);
+        bmax = fmaxf(bmax, b);
+    }
+    __syncthreads();
+    for (int d = 0; d < p.D; ++d) {
+        const int64_t l = p.probe_list[q * p.ld_probe + d];
+        if (l < 0) continue;
+        const int64_t lo = p.list_off[l];
+        const int first = (int)(lo & 15), last = first + (int)min(p.list_off[l + 1] - lo, (int64_t)(p.seg - 16));   // positions [first, last)
+        // floor of the bias difference in units of delta, a little low on purpose (a smaller offset only lowers the bound)
+        const float offf = (p.probe_bias[q * p.ld_probe + d] - bmin) / delta * 0.9999f - 1.f;
+        const int off = (int)fminf(fmaxf(offf, 0.f), 40000.f);
+        const uint4* src = reinterpret_cast<const uint4*>(p.sums + (q * p.D + d) * p.seg);      // 8 sums per load
+        for (int e8 = tid; e8 * 8 < last; e8 += 1024) {
+            const uint4 v = src[e8];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int pos = e8 * 8 + x;
+                const int val = (int)((w[x >> 1] >> (16 * (x & 1))) & 0xffffu);
+                if (pos >= first && pos < last) atomicAdd(&hist[min(TAU_BINS - 1, (val + off) >> 2)], 1);
+            }
+        }
+    }
+    __syncthreads();
+    // b*: the highest bin whose suffix count reaches k.  Thread t owns bins [16 t, 16 t + 16); suffix sums over the threads by
+    // a doubling scan in LDS, then the one thread whose range holds the crossing walks its 16 bins
+    int mine = 0;
+    constexpr int PER = TAU_BINS / 1024;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) mine += hist[tid * PER + e];
+    part[tid] = mine;
+    if (tid == 0) bstar_s = -1;
+    __syncthreads();
+    int suf = mine;                                                          // sum of part[t .. 1023]
+    for (int step = 1; step < 1024; step <<= 1) {
+        const int other = tid + step < 1024 ? part[tid + step] : 0;
+        __syncthreads();
+        suf += other;
+        part[tid] = suf;
+        __syncthreads();
+    }
+    if (suf >= p.k && suf - mine < p.k) {                                    // exactly one thread (suffix sums decrease with t)
+        int acc = suf - mine, b = tid * PER + PER - 1;
+        for (; b >= tid * PER; --b) { acc += hist[b]; if (acc >= p.k) break; }
+        bstar_s = b;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float tau = -INFINITY;
+        if (bstar_s >= 0) {
+            const float eps = 66.f * 2.3841858e-7f * (64.f * amax + fmaxf(fabsf(bmin), fabsf(bmax)));
+            tau = (bmin + sum_lo) + (float)(4 * bstar_s) * delta * (1.f - 6.1035156e-5f) - eps;       // delta (1 - 2^-14) < 1 / inv
+            tau -= fabsf(tau) * 2.3841858e-7f + 1e-30f;                       // strictly below the k keys' scores: candidates are score > tau
+        }
+        p.tau[q] = tau;
+    }
+}
+
 // Exact float32 scores of the survivors, in the summation order of the f32 scan (ivfpq.hip scan_rot: look-up s of half h
 // goes to sub-quantizer 32 h + (row + s) % 32, even look-ups into one chain, odd ones into the other, halves in order,
 // score = bias + (chain0 + chain1)).  One workgroup per query, its table in LDS.
 template <int M>
-__global__ __launch_bounds__(256) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore_t p) {
-    extern __shared__ __attribute__((aligned(16))) float rtab[];            // [M][256] f32, then 256 x (M + 16) code bytes
+__global__ __launch_bounds__(1024) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore_t p) {
+    extern __shared__ __attribute__((aligned(16))) float rtab[];            // [M][256] f32, then the threads' code rows [M / 4 dwords][NT]
     __shared__ int ccnt;
-    constexpr int RS = M + 16;                                              // row stride of the per-thread code bytes
-    uint8_t* cbuf = reinterpret_cast<uint8_t*>(rtab + M * 256);
+    constexpr int NT = 1024;                                                // 16 waves: the survivors' code rows are random 64-B reads
+    uint32_t* cdw = reinterpret_cast<uint32_t*>(rtab + M * 256);            // dword k of thread t at [k][t]: bank = t mod 32 for stores and byte reads alike
     const int tid = threadIdx.x;
     const int64_t q = blockIdx.x;
     const int n = min(p.surv_cnt[q], p.cap);
     if (tid == 0) ccnt = 0;
+    const uint2* surv = reinterpret_cast<const uint2*>(p.surv) + q * p.cap;
+    // the first survivor's code row is requested before the table arrives
+    uint32_t row32 = 0u, list = 0u;
+    v4u cr[M / 16];
+#pragma unroll
+    for (int c16 = 0; c16 < M / 16; ++c16) cr[c16] = v4u{0u, 0u, 0u, 0u};
+    if (tid < n) {
+        const uint2 sv = surv[tid];
+        row32 = sv.x;
+        list = sv.y;
+        const v4u* crow = reinterpret_cast<const v4u*>(p.codes + (int64_t)row32 * M);
+#pragma unroll
+        for (int c16 = 0; c16 < M / 16; ++c16) cr[c16] = crow[c16];
+    }
     if (n > 0) {
         const float4* src = reinterpret_cast<const float4*>(p.lut + q * p.ld_lut);
         float4* dst = reinterpret_cast<float4*>(rtab);
-        for (int e = tid; e < M * 64; e += 256) dst[e] = src[e];
+        for (int e = tid; e < M * 64; e += NT) dst[e] = src[e];
     }
     __syncthreads();
     const float tau = p.tau[q];
-    for (int e = tid; e < n; e += 256) {
-        const uint2 sv = reinterpret_cast<const uint2*>(p.surv)[q * p.cap + e];
-        const int64_t row = sv.x;
-        const uint4* crow = reinterpret_cast<const uint4*>(p.codes + row * M);
-        uint4* mine = reinterpret_cast<uint4*>(cbuf + tid * RS);
+    const uint8_t* cb = reinterpret_cast<const uint8_t*>(cdw + tid);        // byte m of the row: cb[(m >> 2) * 4 * NT + (m & 3)]
+    for (int e = tid; e < n; e += NT) {
+        const int64_t row = row32;
+        const uint32_t lst = list;
 #pragma unroll
-        for (int c16 = 0; c16 < M / 16; ++c16) mine[c16] = crow[c16];
-        const uint8_t* cb = cbuf + tid * RS;
+        for (int c16 = 0; c16 < M / 16; ++c16) {
+            cdw[(4 * c16 + 0) * NT + tid] = cr[c16].x;
+            cdw[(4 * c16 + 1) * NT + tid] = cr[c16].y;
+            cdw[(4 * c16 + 2) * NT + tid] = cr[c16].z;
+            cdw[(4 * c16 + 3) * NT + tid] = cr[c16].w;
+        }
+        if (e + NT < n) {                                                   // the next survivor's row travels under this one's look-ups
+            const uint2 sv = surv[e + NT];
+            row32 = sv.x;
+            list = sv.y;
+            const v4u* crow = reinterpret_cast<const v4u*>(p.codes + (int64_t)row32 * M);
+#pragma unroll
+            for (int c16 = 0; c16 < M / 16; ++c16) cr[c16] = crow[c16];
+        }
         const int rot = (int)(row & 31);
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int h = 0; h < M / 32; ++h) {
-#pragma unroll 4
+#pragma unroll 8
             for (int s = 0; s < 32; s += 2) {
                 const int m0 = 32 * h + ((rot + s) & 31), m1 = 32 * h + ((rot + s + 1) & 31);
-                a0 = a0 + rtab[m0 * 256 + cb[m0]];
-                a1 = a1 + rtab[m1 * 256 + cb[m1]];
+                a0 = a0 + rtab[m0 * 256 + cb[(m0 >> 2) * (4 * NT) + (m0 & 3)]];
+                a1 = a1 + rtab[m1 * 256 + cb[(m1 >> 2) * (4 * NT) + (m1 & 3)]];
             }
         }
-        const float score = p.coarse[q * p.ld_coarse + sv.y] + (a0 + a1);
+        const float score = p.coarse[q * p.ld_coarse + lst] + (a0 + a1);
         if (score > tau) {
             const int pos = atomicAdd(&ccnt, 1);
             if (pos < p.cand_cap) {
@@ -343,30 +528,31 @@ int ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int M, uint8
     return OK;
 }
 
-// one hipFuncSetAttribute per (kernel, device): a process may drive several devices
-template <typename K>
-static int opt_in_lds(K kernel, int bytes, bool (&done)[16]) {
-    int dev = 0;
-    GNNLM_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 16 && done[dev]) return OK;
-    GNNLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    if (dev >= 0 && dev < 16) done[dev] = true;
-    return OK;
-}
-
 int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream) {
     GNNLM_REQUIRE(d.max_groups >= 0, "ivfpq_scan8: bad group count");
     if (d.max_groups == 0) return OK;
-    GNNLM_REQUIRE(d.tiles && d.list_off && d.qlut && d.qmeta && d.coarse && d.tau && d.grp_list && d.grp_q && d.n_groups && d.surv &&
-                      d.surv_cnt && d.cap > 0,
+    GNNLM_REQUIRE(d.tiles && d.list_off && d.qlut && d.qmeta && d.coarse && d.grp_list && d.grp_q && d.n_groups &&
+                      (d.out_sum || (d.tau && d.surv && d.surv_cnt && d.cap > 0)),
                   "ivfpq_scan8: null operand");
     GNNLM_REQUIRE(d.M == 64 && (uintptr_t)d.tiles % 16 == 0 && (uintptr_t)d.qlut % 4 == 0, "ivfpq_scan8: need M = 64, aligned images");
-    static bool done[16] = {};
-    const int rc = opt_in_lds(&ivfpq_scan8_kernel, SCAN_LDS, done);
-    if (rc != OK) return rc;
-    ProfScope prof(K_IVF, stream, 0.0, 0.0);             // work figures are device-side (list lengths): bench.py computes them
+    GNNLM_REQUIRE(!d.out_sum || d.grp_out, "ivfpq_scan8: out_sum needs grp_out");
+    GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<false>, SCAN_LDS);
+    GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<true>, SCAN_LDS);
+    ProfScope prof(K_IVF8, stream, 0.0, 0.0);            // work figures are device-side (list lengths): bench.py computes them
     const int64_t grid = 8 * cdiv((int64_t)d.max_groups, (int64_t)8);
-    hipLaunchKernelGGL(ivfpq_scan8_kernel, dim3((unsigned)grid), dim3(1024), SCAN_LDS, stream, d);
+    if (d.out_sum) hipLaunchKernelGGL(ivfpq_scan8_kernel<true>, dim3((unsigned)grid), dim3(1024), SCAN_LDS, stream, d);
+    else hipLaunchKernelGGL(ivfpq_scan8_kernel<false>, dim3((unsigned)grid), dim3(1024), SCAN_LDS, stream, d);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int ivfpq_tau(const gnnlm_ivfpq_tau_t& d, hipStream_t stream) {
+    GNNLM_REQUIRE(d.n >= 0 && d.n < (1ll << 31) && d.D >= 1 && d.seg > 0 && d.k > 0, "ivfpq_tau: bad shape");
+    if (d.n == 0) return OK;
+    GNNLM_REQUIRE(d.sums && d.probe_list && d.probe_bias && d.list_off && d.qmeta && d.tau && d.ld_probe >= d.D, "ivfpq_tau: null operand");
+    GNNLM_REQUIRE(d.seg % 8 == 0 && d.seg > 32 && (uintptr_t)d.sums % 16 == 0, "ivfpq_tau: segments of a multiple of 8 entries (longest list + 32, rounded up), 16-byte aligned");
+    ProfScope prof(K_TOPK, stream, 0.0, 2.0 * (double)d.n * d.D * d.seg);
+    hipLaunchKernelGGL(ivfpq_tau_kernel, dim3((unsigned)d.n), dim3(1024), 0, stream, d);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }
@@ -380,15 +566,14 @@ int ivfpq_rescore(const gnnlm_ivfpq_rescore_t& d, hipStream_t stream) {
     GNNLM_REQUIRE((d.M == 64 || d.M == 32) && d.ld_lut >= (int64_t)d.M * 256 && d.ld_lut % 4 == 0 && (uintptr_t)d.lut % 16 == 0 &&
                       (uintptr_t)d.codes % 16 == 0,
                   "ivfpq_rescore: need M = 32 or 64, 16-byte aligned tables");
-    ProfScope prof(K_IVF, stream, 0.0, 0.0);
-    const size_t lds = (size_t)d.M * 256 * 4 + 256 * (size_t)(d.M + 16);
+    ProfScope prof(K_RESCORE, stream, 0.0, 0.0);
+    const size_t lds = (size_t)d.M * 256 * 4 + 1024 * (size_t)d.M;
     if (d.M == 64) {
-        static bool done[16] = {};
-        const int rc = opt_in_lds(&ivfpq_rescore_kernel<64>, (int)lds, done);
-        if (rc != OK) return rc;
-        hipLaunchKernelGGL(ivfpq_rescore_kernel<64>, dim3((unsigned)d.n), dim3(256), lds, stream, d);
+        GNNLM_LDS_OPT_IN(&ivfpq_rescore_kernel<64>, lds);
+        hipLaunchKernelGGL(ivfpq_rescore_kernel<64>, dim3((unsigned)d.n), dim3(1024), lds, stream, d);
     } else {
-        hipLaunchKernelGGL(ivfpq_rescore_kernel<32>, dim3((unsigned)d.n), dim3(256), lds, stream, d);
+        GNNLM_LDS_OPT_IN(&ivfpq_rescore_kernel<32>, lds);
+        hipLaunchKernelGGL(ivfpq_rescore_kernel<32>, dim3((unsigned)d.n), dim3(1024), lds, stream, d);
     }
     GNNLM_LAUNCH_CHECK();
     return OK;

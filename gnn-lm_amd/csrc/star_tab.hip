@@ -548,13 +548,10 @@ bool star_attn_tab_eligible(const StarAttnParams& p) {
 int star_attn_tab(const StarAttnParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(star_attn_tab_eligible(p), "star_attn_tab: shape not supported by the table-resident kernel");
     const int lds_bytes = carve(p.M).total;
-    static bool attr_set = false;
     const auto k8m = &star_attn_tab_kernel<8, 128>, k8 = &star_attn_tab_kernel<8, 0>, k4 = &star_attn_tab_kernel<4, 0>;
-    if (!attr_set) {
-        for (const void* f : {reinterpret_cast<const void*>(k8m), reinterpret_cast<const void*>(k8), reinterpret_cast<const void*>(k4)})
-            GNNLM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    GNNLM_LDS_OPT_IN(k8m, 160 * 1024);
+    GNNLM_LDS_OPT_IN(k8, 160 * 1024);
+    GNNLM_LDS_OPT_IN(k4, 160 * 1024);
     const dim3 grid((unsigned)cdiv(p.T, TPW)), block(NTHREADS);
     for (int h0 = 0; h0 < p.H; h0 += HB) {
         if (p.dsub == 8 && p.M == 128) hipLaunchKernelGGL(k8m, grid, block, lds_bytes, stream, p, h0);

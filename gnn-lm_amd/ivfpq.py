@@ -66,7 +66,7 @@ class IVFPQIndex:
 
     LABEL_BITS = 24                                                          # payload = id << 24 | label (ids < 2^39, labels < 2^24)
 
-    def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=2, cand_cap=16384,
+    def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=None, cand_cap=16384,
                  score_bytes=6 << 30, scan=None):
         self.R, self.coarse, self.pq = R, coarse, pq                         # [d, d], [nlist, d], [M, 256, dsub]  f32
         self.list_off, self.list_ids, self.list_codes = list_off, list_ids, list_codes   # i64 [nlist+1], i64 [N], u8 [N, M]
@@ -89,6 +89,10 @@ class IVFPQIndex:
         scan = scan or os.environ.get("GNNLM_IVF_SCAN", "mfma")              # "f32": the one-pass float32 scan everywhere (A/B, tests)
         if self.M == 64 and self.ntotal and self.ntotal < (1 << 32) and scan != "f32":
             self.tiles = ops.ivfpq_pack_tiles(self.list_codes)
+        # lists per query behind the threshold: the float32 dense round scores 2 in full; the int8 threshold pass is cheap and its
+        # bound a little loose, 6 lists give the tighter threshold (fewer survivors to re-score) for less time
+        if self.dense_probes is None:
+            self.dense_probes = 6 if self.tiles is not None else 2
         self.stats = {}                                                      # device-side work counters of the last search (bench.py)
 
     def attach_vals(self, vals):
@@ -173,7 +177,7 @@ class IVFPQIndex:
         return cls(t(R), t(z["coarse"]), t(z["pq"]), t(z["list_off"]), t(z["list_ids"]), t(z["list_codes"]), cosine=cosine, **kw)
 
     # ------------------------------------------------------------------------------------------ search
-    def _scan(self, lut, probe_val, probe_id, p_lo, p_hi, out=None, tau=None, cand=None):
+    def _scan(self, lut, probe_val, probe_id, p_lo, p_hi, out=None, tau=None, cand=None, cap=None):
         n = lut.shape[0]
         dev = self.device
         pl = probe_id[:, p_lo:p_hi]
@@ -191,31 +195,36 @@ class IVFPQIndex:
         if tau is None:
             s.out_val, s.ld_out, s.p0, s.seg = out.data_ptr(), out.stride(0), p_lo, self.max_list       # scores only (out_id NULL)
         else:
-            s.tau, s.cand_val, s.cand_id, s.cand_cnt, s.cap = tau.data_ptr(), cand[0].data_ptr(), cand[1].data_ptr(), cand[2].data_ptr(), self.cand_cap
+            s.tau, s.cand_val, s.cand_id, s.cand_cnt, s.cap = tau.data_ptr(), cand[0].data_ptr(), cand[1].data_ptr(), cand[2].data_ptr(), cap
         _lib.call_desc("gnnlm_ivfpq_scan", s)
 
-    def _groups(self, pl):
+    def _groups(self, pl, seg=None):
         """(query, probe) pairs of ``pl`` [nq, P] (list ids, -1 = none) -> groups of up to 8 queries that probe the same list,
         sorted by list: grp_list [G], grp_q [G, 8] (-1 padded), the number of groups in use as a DEVICE scalar.  Torch ops
-        on the device, no host round trip; G is the upper bound pairs / 8 + nlist + 1."""
+        on the device, no host round trip; G is the upper bound pairs / 8 + nlist + 1.  With ``seg``: also grp_out [G, 8], the
+        offset (query * P + probe slot) * seg of the pair's segment in a [nq, P, seg] array (-1: none)."""
         nq, P = pl.shape
         dev = self.device
         n = nq * P
         key = torch.where(pl < 0, torch.full_like(pl, self.nlist), pl).reshape(-1)
         skey, order = torch.sort(key, stable=True)
-        idx = torch.arange(n, device=dev)
-        start = torch.ones(n, dtype=torch.bool, device=dev)
-        start[1:] = skey[1:] != skey[:-1]
-        run0 = torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0).values
-        pos = idx - run0                                                      # position inside the run of one list
-        gid = torch.cumsum((pos % 8 == 0).to(torch.int64), 0) - 1
+        cnt = torch.bincount(key, minlength=self.nlist + 1)                   # pairs per list (last bucket: no list)
+        start = torch.cumsum(cnt, 0) - cnt
+        gcnt = (cnt + 7) // 8
+        goff = torch.cumsum(gcnt, 0) - gcnt                                   # first group of every list
+        pos = torch.arange(n, device=dev) - start[skey]                       # position inside the run of one list
+        gid = goff[skey] + pos // 8
         G = n // 8 + self.nlist + 1
         grp_list = torch.full((G,), -1, dtype=torch.int32, device=dev)
         grp_list[gid] = torch.where(skey >= self.nlist, torch.full_like(skey, -1), skey).to(torch.int32)
         grp_q = torch.full((G, 8), -1, dtype=torch.int32, device=dev)
         grp_q[gid, pos % 8] = torch.div(order, P, rounding_mode="floor").to(torch.int32)
-        n_groups = (gid[-1:] + 1).to(torch.int32)
-        return grp_list, grp_q, n_groups, G
+        n_groups = gcnt.sum().reshape(1).to(torch.int32)
+        if seg is None:
+            return grp_list, grp_q, n_groups, G
+        grp_out = torch.full((G, 8), -1, dtype=torch.int64, device=dev)
+        grp_out[gid, pos % 8] = torch.where(skey >= self.nlist, torch.full_like(order, -1), order * seg)   # order = query * P + slot
+        return grp_list, grp_q, n_groups, G, grp_out
 
     def search_device(self, q, k, query_block=None, return_vals=False):
         """The search, on device tensors: (scores [n, k] descending, ids [n, k], -1 padded[, vals [n, k] int32 with
@@ -225,7 +234,7 @@ class IVFPQIndex:
         doubled for good and the call repeated."""
         q = q.to(self.device, torch.float32).contiguous()
         while True:
-            val, idx, over = self._search_once(q, k, query_block, self.dense_probes)
+            val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
             if over is None:
                 break
             bad = (over > self.cand_cap).nonzero().reshape(-1)                # host sync
@@ -234,7 +243,12 @@ class IVFPQIndex:
             if bad.numel() * 8 > q.shape[0] and self.cand_cap < (1 << 18):
                 self.cand_cap *= 2
                 continue
-            v2, i2, _ = self._search_once(q[bad].contiguous(), k, query_block, self.nprobe)
+            sub, cap2 = q[bad].contiguous(), self.cand_cap
+            while True:                                                       # every probed list in the threshold / dense round
+                v2, i2, o2 = self._search_once(sub, k, query_block, self.nprobe, cap2)
+                if o2 is None or cap2 >= (1 << 22) or int(o2.max().item()) <= cap2:
+                    break
+                cap2 *= 2
             val[bad], idx[bad] = v2, i2
             break
         self._overflow = None
@@ -246,7 +260,7 @@ class IVFPQIndex:
         vals = torch.where(idx < 0, torch.full_like(idx, self.val_last), idx & ((1 << self.LABEL_BITS) - 1)).to(torch.int32)
         return val, ids, vals
 
-    def _search_once(self, q, k, query_block, dense_probes):
+    def _search_once(self, q, k, query_block, dense_probes, cap):
         n, dev = q.shape[0], self.device
         nprobe = min(self.nprobe, self.nlist)
         dense = max(1, min(dense_probes, nprobe))
@@ -255,17 +269,17 @@ class IVFPQIndex:
         if query_block is None:                                               # groups of 8 queries per list want many queries per block
             query_block = 8192 if self.tiles is not None else 1024
         # the dense round's score rows: query_block * dense * max_list floats, bounded (a skewed index has long lists)
-        qb = max(1, min(query_block, self.score_bytes // max(1, 4 * dense * max(self.max_list, 1))))
+        qb = max(1, min(query_block, self.score_bytes // max(1, (2 if self.tiles is not None else 4) * dense * max(self.max_list, 1))))
         over = None
         self.stats = {"pairs": torch.zeros((), device=dev, dtype=torch.float64), "survivors": torch.zeros((), device=dev, dtype=torch.float64),
                       "candidates": torch.zeros((), device=dev, dtype=torch.float64), "queries": n, "M": self.M}
         for q0 in range(0, n, qb):
-            o = self._search_block(q[q0:q0 + qb], k, val[q0:q0 + qb], idx[q0:q0 + qb], nprobe, dense)
+            o = self._search_block(q[q0:q0 + qb], k, val[q0:q0 + qb], idx[q0:q0 + qb], nprobe, dense, cap)
             if o is not None:
                 over = o if over is None else torch.cat([over, o])
         return val, idx, over
 
-    def _search_block(self, qs, k, bv, bi, nprobe, dense):
+    def _search_block(self, qs, k, bv, bi, nprobe, dense, cap):
         dev = self.device
         nq = qs.shape[0]
         qr = ops.gemm_nt(qs, self.R)                                            # q' = R q
@@ -281,6 +295,11 @@ class IVFPQIndex:
         g.M, g.N, g.K, g.batch1 = nq, 256, self.dsub, self.M
         g.sA1, g.sW1, g.sC1 = self.dsub, 256 * self.dsub, 256
         _lib.call_desc("gnnlm_gemm_nt", g)
+        cv = torch.empty(nq, cap, device=dev, dtype=torch.float32)
+        ci = torch.empty(nq, cap, device=dev, dtype=torch.int64)
+        cc = torch.zeros(nq, device=dev, dtype=torch.int32)
+        if self.tiles is not None:
+            return self._search_block_mfma(k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc)
         lut_s = lut
         if self.packed_codes is not None:
             lut_s = torch.empty_like(lut)
@@ -296,39 +315,57 @@ class IVFPQIndex:
         if nprobe <= dense:
             return None
         # round 2: the other lists only emit scores above the query's k-th best so far
-        cap = self.cand_cap
         tau = torch.where(bi[:, k - 1] >= 0, bv[:, k - 1], torch.full_like(bv[:, k - 1], float("-inf"))).contiguous()
-        cv = torch.empty(nq, cap, device=dev, dtype=torch.float32)
-        ci = torch.empty(nq, cap, device=dev, dtype=torch.int64)
-        cc = torch.zeros(nq, device=dev, dtype=torch.int32)
-        if self.tiles is None:
-            self._scan(lut_s, pv, pi, dense, nprobe, tau=tau, cand=(cv, ci, cc))
-            over = cc
-        else:
-            # filter on the int8 matrix cores (a superset of {score > tau}), then the exact float32 scores of what passed
-            qlut, qmeta = ops.ivfpq_quantize_lut(lut, self.M)
-            grp_list, grp_q, n_groups, G = self._groups(pi[:, dense:nprobe])
-            surv = torch.empty(nq, cap, 2, device=dev, dtype=torch.int32)
-            sc = torch.zeros(nq, device=dev, dtype=torch.int32)
-            d = _lib.gnnlm_ivfpq_scan8_t()
-            d.tiles, d.list_off, d.M = self.tiles.data_ptr(), self.list_off.data_ptr(), self.M
-            d.qlut, d.qmeta, d.coarse, d.ld_coarse, d.tau = qlut.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0), tau.data_ptr()
-            d.grp_list, d.grp_q, d.n_groups, d.max_groups = grp_list.data_ptr(), grp_q.data_ptr(), n_groups.data_ptr(), G
-            d.surv, d.surv_cnt, d.cap = surv.data_ptr(), sc.data_ptr(), cap
-            _lib.call_desc("gnnlm_ivfpq_scan8", d)
-            r = _lib.gnnlm_ivfpq_rescore_t()
-            r.codes, r.payload, r.M = self.list_codes.data_ptr(), self.payload.data_ptr(), self.M
-            r.lut, r.ld_lut, r.coarse, r.ld_coarse, r.tau = lut.data_ptr(), lut.stride(0), cs.data_ptr(), cs.stride(0), tau.data_ptr()
-            r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), sc.data_ptr(), cap, nq
-            r.cand_val, r.cand_id, r.cand_cnt, r.cand_cap = cv.data_ptr(), ci.data_ptr(), cc.data_ptr(), cap
-            _lib.call_desc("gnnlm_ivfpq_rescore", r)
-            over = sc                                                          # every candidate is a survivor: sc >= cc
-            self.stats["survivors"] += sc.sum()
+        self._scan(lut_s, pv, pi, dense, nprobe, tau=tau, cand=(cv, ci, cc), cap=cap)
         self.stats["candidates"] += cc.sum()
         if getattr(self, "keep_candidates", False):                          # tests / debugging: the round-2 candidates of the last block
             self.last_candidates = (cv, ci, cc, tau)
         ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=False, row_ncols=cc.clamp(max=cap))
-        return over
+        return cc
+
+    def _scan8(self, qlut, qmeta, cs, groups, tau=None, surv=None, sums=None):
+        d = _lib.gnnlm_ivfpq_scan8_t()
+        d.tiles, d.list_off, d.M = self.tiles.data_ptr(), self.list_off.data_ptr(), self.M
+        d.qlut, d.qmeta, d.coarse, d.ld_coarse = qlut.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0)
+        d.grp_list, d.grp_q, d.n_groups, d.max_groups = groups[0].data_ptr(), groups[1].data_ptr(), groups[2].data_ptr(), groups[3]
+        if sums is not None:
+            d.out_sum, d.grp_out = sums.data_ptr(), groups[4].data_ptr()
+        else:
+            d.tau, d.surv, d.surv_cnt, d.cap = tau.data_ptr(), surv[0].data_ptr(), surv[1].data_ptr(), surv[0].shape[1]
+        _lib.call_desc("gnnlm_ivfpq_scan8", d)
+
+    def _search_block_mfma(self, k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc):
+        """M = 64: everything on the int8 matrix cores (csrc/ivfpq_mfma.hip).  (1) threshold pass: the integer sums of the first
+        `dense` lists -> a lower bound tau of the query's k-th best score (histogram, no selection); (2) filter: every probed
+        list, keys whose integer sum can reach tau; (3) exact float32 scores of the survivors, score > tau -> candidates;
+        (4) one k-selection over the candidates."""
+        dev = self.device
+        nq, cap = pv.shape[0], cv.shape[1]
+        qlut, qmeta = ops.ivfpq_quantize_lut(lut, self.M)
+        seg = (self.max_list + 32 + 7) // 8 * 8                                 # positions in a list's tile range (csrc/ivfpq_mfma.hip)
+        sums = torch.empty(nq, dense, seg, device=dev, dtype=torch.int16)       # (uint16 values)
+        self._scan8(qlut, qmeta, cs, self._groups(pi[:, :dense], seg=seg), sums=sums)
+        tau = torch.empty(nq, device=dev, dtype=torch.float32)
+        t = _lib.gnnlm_ivfpq_tau_t()
+        t.sums, t.D, t.seg = sums.data_ptr(), dense, seg
+        t.probe_list, t.probe_bias, t.ld_probe = pi.data_ptr(), pv.data_ptr(), pi.stride(0)
+        t.list_off, t.qmeta, t.n, t.k, t.tau = self.list_off.data_ptr(), qmeta.data_ptr(), nq, k, tau.data_ptr()
+        _lib.call_desc("gnnlm_ivfpq_tau", t)
+        surv = torch.empty(nq, cap, 2, device=dev, dtype=torch.int32)
+        sc = torch.zeros(nq, device=dev, dtype=torch.int32)
+        self._scan8(qlut, qmeta, cs, self._groups(pi), tau=tau, surv=(surv, sc))
+        r = _lib.gnnlm_ivfpq_rescore_t()
+        r.codes, r.payload, r.M = self.list_codes.data_ptr(), self.payload.data_ptr(), self.M
+        r.lut, r.ld_lut, r.coarse, r.ld_coarse, r.tau = lut.data_ptr(), lut.stride(0), cs.data_ptr(), cs.stride(0), tau.data_ptr()
+        r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), sc.data_ptr(), cap, nq
+        r.cand_val, r.cand_id, r.cand_cnt, r.cand_cap = cv.data_ptr(), ci.data_ptr(), cc.data_ptr(), cap
+        _lib.call_desc("gnnlm_ivfpq_rescore", r)
+        self.stats["survivors"] += sc.sum()
+        self.stats["candidates"] += cc.sum()
+        if getattr(self, "keep_candidates", False):
+            self.last_candidates = (cv, ci, cc, tau)
+        ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=True, row_ncols=cc.clamp(max=cap))
+        return sc                                                              # every candidate is a survivor: sc >= cc
 
     def check(self):
         """Kept for callers of earlier versions: ``search_device`` itself re-searches queries whose survivors did not fit."""
