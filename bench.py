@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-extras", dest="extras", action="store_false",
                     help="skip the recipe_L3 and driver_path sub-benchmarks (run after the timed region, N = 1 only)")
     ap.add_argument("--cpu-tokens", type=int, default=384)
+    ap.add_argument("--search-check", type=int, default=32,
+                    help="queries of the kNN-search sub-benchmark checked against the float64 oracle before it is timed (0: skip)")
     ap.add_argument("--small", action="store_true", help="tiny shapes (plumbing check only)")
     ap.add_argument("--graph", action="store_true",
                     help="capture each batch's step once in a HIP graph and replay it in the timed region (launch-bound "
@@ -381,25 +383,99 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def search_check(idx, q, k, n_check):
+    """Parity gate of the search bench: the first `n_check` queries through the device search against the float64 IVFADC
+    oracle (oracle/ivfpq.py) over the SAME index arrays -- restricted to the lists those queries can probe (their 40 best
+    lists each: the oracle selects its own 32 among them), which is what fits a host transfer at 103 M keys."""
+    from oracle import ivfpq as oivf
+    qs = q[:n_check].contiguous()
+    t0 = time.perf_counter()
+    v, i = idx.search_device(qs, k)
+    cs = (qs @ idx.R.t()) @ idx.coarse.t()
+    U = torch.unique(cs.topk(min(40, idx.nlist), dim=1).indices)
+    lens = (idx.list_off[U + 1] - idx.list_off[U])
+    off_sub = torch.zeros(U.numel() + 1, dtype=torch.int64, device=q.device)
+    off_sub[1:] = torch.cumsum(lens, 0)
+    rows = torch.repeat_interleave(idx.list_off[U] - off_sub[:-1], lens) + torch.arange(int(off_sub[-1]), device=q.device)
+    arrs = [idx.R.cpu().numpy(), idx.coarse[U].cpu().numpy(), idx.pq.cpu().numpy(), off_sub.cpu().numpy(),
+            idx.list_ids[rows].cpu().numpy(), idx.list_codes[rows].cpu().numpy()]
+    v_ref, i_ref = oivf.search(qs.cpu().numpy(), *arrs, k=k, nprobe=idx.nprobe)
+    v, i = v.cpu().numpy(), i.cpu().numpy()
+    same = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(i, i_ref)]))
+    dv = float(np.abs(v - v_ref).max())
+    ok = same >= 0.998 and dv <= 2e-5
+    out = {"queries": int(qs.shape[0]), "lists_on_host": int(U.numel()), "id_set_overlap": round(same, 5), "max_abs_dscore": dv,
+           "tolerance": {"id_set_overlap": 0.998, "score": 2e-5}, "oracle_seconds": round(time.perf_counter() - t0, 1), "ok": ok}
+    if not ok:
+        raise SystemExit(f"bench.py: the on-device kNN search disagrees with the oracle: {out}")
+    return out
+
+
 def knn_search(args, eng, batches, dev, step_ms):
-    """The kNN SEARCH the headline step leaves out (the reference runs it on the CPU with faiss, knn_model.py:100): the
-    step's queries (the HGT features of one batch) through the on-device IVF-PQ search over a synthetic index of the
-    reference's index shape (OPQ64_1024,IVF4096,PQ64, nprobe 32, k = --k) with as many keys as the store."""
+    """The kNN SEARCH the headline step leaves out (the reference runs it on the CPU with faiss inside its timer,
+    knn_model.py:100 under fairseq_cli/eval_lm.py:214-219): the step's queries (the HGT features of one batch) through the
+    on-device IVF-PQ search over a synthetic index of the reference's index shape (OPQ64_1024,IVF4096,PQ64, nprobe 32,
+    k = --k) with as many keys as the store, the labels travelling with the results (no label gather in the step).
+    Checked against the oracle first, then timed; per-kernel times by HIP events of one more call."""
+    from dataclasses import replace
+    from gnnlm_amd import _lib
     from gnnlm_amd.synthetic import synthetic_ivfpq_index
     idx = synthetic_ivfpq_index(args.n_store, eng.hgt.hidden_dim, 4096, 64, dev, nprobe=32)
+    idx.attach_vals(eng.store.vals)                                       # index key ids = store rows: payload = id << 24 | label
     q = eng.features(batches[0])
     q = q / q.norm(dim=1, keepdim=True)                                   # knn_model.py:181-184 (cosine index)
-    idx.search_device(q, args.k)                                          # same shapes as the timed call: no allocation inside it
+    check = search_check(idx, q, args.k, args.search_check) if args.search_check > 0 else None
+    idx.search_device(q, args.k, return_vals=True)                        # same shapes as the timed call: no allocation inside it
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    idx.search_device(q, args.k)
+    sims, ids, kvals = idx.search_device(q, args.k, return_vals=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    idx.check()
+    st = {k_: (float(v_.item()) if torch.is_tensor(v_) else v_) for k_, v_ in idx.stats.items()}
+    _lib.profile_begin()
+    idx.search_device(q, args.k, return_vals=True)
+    torch.cuda.synchronize()
+    prof = _lib.profile_end()
     n = q.shape[0]
+    # the step fed by the search: similarities, ids and LABELS come from the index (knn_vals given: no gather of vals[ids])
+    b2 = replace(batches[0], knn_sims=sims.contiguous(), knn_ids=ids.contiguous(), knn_vals=kvals.contiguous())
+    for _ in range(2):
+        eng.score(b2, args.lmbda, args.temperature)
+    torch.cuda.synchronize()
+    _lib.profile_begin(1 << 7)                                            # K_KNN
+    t1 = time.perf_counter()
+    for _ in range(10):
+        eng.score(b2, args.lmbda, args.temperature)
+    torch.cuda.synchronize()
+    step2 = (time.perf_counter() - t1) / 10
+    knn_prof = _lib.profile_end().get("knn_interp_kernel", {"launches": 1, "total_ms": 0.0})
+    # roofline of the search's dominant kernel, the int8-MFMA filter: one table byte per (query, key, sub-quantizer) goes
+    # through LDS (ds_read_b64 of 8 queries' bytes) and through the matrix core (a byte of the MFMA's A operand = 32 int8 ops)
+    filt = prof.get("ivfpq_scan8_kernel", {"total_ms": 0.0, "launches": 0})
+    thr = prof.get("ivfpq_sums_kernel", {"total_ms": 0.0, "launches": 0})
+    pairs_filter = st["pairs"]                                            # (query, key) pairs of all probed lists
+    lookups = pairs_filter * 64.0
+    sec = filt["total_ms"] / 1e3
+    roof = None
+    if sec > 0:
+        roof = {"kernel": "ivfpq_scan8_kernel (int8-MFMA filter over all probed lists)", "bound": "mfma",
+                "achieved": round(lookups * 32 / sec / 1e12, 1), "peak": 5000.0, "unit": "TOP/s (int8)", "frac": round(lookups * 32 / sec / 1e12 / 5000.0, 4),
+                "peak_note": "dense i8 MFMA = 2x bf16 (MI355X_MICROARCH.md); its measured 16x16x64 ceiling is 3944 TOP/s",
+                "frac_of_measured_ceiling": round(lookups * 32 / sec / 1e12 / 3944.0, 4),
+                "lds_lookup_bytes_per_s_TB": round(lookups / sec / 1e12, 2), "lds_frac_of_150TBps": round(lookups / sec / 1e12 / 150.0, 4),
+                "list_bytes_GBps": round(pairs_filter / 8 * 64 / sec / 1e9, 1),
+                "avg_us": round(filt["total_ms"] * 1e3 / max(1, filt["launches"]), 1), "launches": filt["launches"],
+                "table_byte_lookups": lookups, "traffic": None}
     return {"index": "synthetic OPQ64_1024,IVF4096,PQ64", "keys": args.n_store, "nprobe": 32, "k": args.k, "queries": n,
+            "scan": "int8-MFMA filter + exact float32 re-score" if idx.tiles is not None else "float32",
+            "threshold_lists": idx.dense_probes, "cand_cap": idx.cand_cap,
             "ms_per_batch": round(dt * 1e3, 2), "queries_per_s": round(n / dt, 1),
-            "tokens_per_s_step_plus_search": round(n / (dt + step_ms / 1e3), 1)}
+            "pairs_per_query": round(st["pairs"] / n), "survivors_per_query": round(st["survivors"] / n), "candidates_per_query": round(st["candidates"] / n),
+            "kernels_ms": {k_: round(v_["total_ms"], 3) for k_, v_ in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
+            "roofline": roof, "parity": check,
+            "step_with_search_labels_ms": round(step2 * 1e3, 4),
+            "knn_interp_with_labels_us": round(knn_prof["total_ms"] * 1e3 / max(1, knn_prof["launches"]), 1),
+            "tokens_per_s_step_plus_search": round(n / (dt + step2), 1)}
 
 
 def pmc_traffic(kernel):
@@ -696,10 +772,12 @@ def main():
             "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
+            "value_with_search": (search["tokens_per_s_step_plus_search"] if search is not None else None),
             "dtype": "f32" if args.precision == "f32" else f"f32 via {args.precision} split-bf16 MFMA", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: WikiText-103 full PQ datastore in HBM, k_g={args.gcn_k}, "
                                    f"context 2+2, HGT {args.layers} layer{'s' if args.layers > 1 else ''}, kNN k={args.k} "
-                                   f"(search results given), {args.tokens_per_sample}-token blocks",
+                                   f"(`value`: search results given, SURVEY.md 8d; `value_with_search`: step + on-device IVF-PQ search of the same queries "
+                                   f"= what the reference's own timer spans, fairseq_cli/eval_lm.py:214-219), {args.tokens_per_sample}-token blocks",
                        "n_store": args.n_store, "blocks_per_step_per_gpu": args.blocks, "streams": args.streams, "hip_graph": bool(args.graph), "tokens_per_block": args.tokens_per_sample,
                        "gcn_k": args.gcn_k, "knn_k": args.k, "hgt_layers": args.layers, "d": d, "vocab": vocab,
                        "lmbda": args.lmbda, "temperature": args.temperature,

@@ -164,9 +164,9 @@ def profile_begin(mask=0xFFFFFFFF):
 def profile_end():
     """-> {kernel name: dict(launches, total_ms, flops, bytes)} for the kernels that were launched."""
     L = lib()
-    arr = (STRUCTS["gnnlm_profile_entry_t"] * 16)()
+    arr = (STRUCTS["gnnlm_profile_entry_t"] * 32)()
     n = ctypes.c_int32(0)
-    check(L.gnnlm_profile_end(arr, 16, ctypes.byref(n)), "gnnlm_profile_end")
+    check(L.gnnlm_profile_end(arr, 32, ctypes.byref(n)), "gnnlm_profile_end")
     out = {}
     for i in range(n.value):
         e = arr[i]

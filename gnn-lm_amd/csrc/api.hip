@@ -639,7 +639,7 @@ int gnnlm_hgt_forward(const gnnlm_hgt_t* m, const gnnlm_hgt_io_t* io, void* work
 static const char* kKernelNames[K_COUNT] = {"gemm_nt_f32_kernel", "gather_decode_kernel", "star_attn_kernel",
                                             "chain_attn_kernel", "causal_attn_kernel", "layernorm_kernel",
                                             "row_lse_pick_kernel", "knn_interp_kernel", "misc", "split_planes_kernel",
-                                            "topk_merge_kernel", "ivfpq_scan_kernel", "ivfpq_scan8_kernel", "ivfpq_rescore_kernel"};
+                                            "topk_merge_kernel", "ivfpq_scan_kernel", "ivfpq_scan8_kernel", "ivfpq_rescore_kernel", "ivfpq_sums_kernel", "ivfpq_tau_kernel"};
 const char* gnnlm_kernel_name(int32_t kernel_id) {
     return kernel_id >= 0 && kernel_id < K_COUNT ? kKernelNames[kernel_id] : nullptr;
 }

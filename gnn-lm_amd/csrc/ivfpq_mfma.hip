@@ -538,7 +538,7 @@ int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream) {
     GNNLM_REQUIRE(!d.out_sum || d.grp_out, "ivfpq_scan8: out_sum needs grp_out");
     GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<false>, SCAN_LDS);
     GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<true>, SCAN_LDS);
-    ProfScope prof(K_IVF8, stream, 0.0, 0.0);            // work figures are device-side (list lengths): bench.py computes them
+    ProfScope prof(d.out_sum ? K_IVF8S : K_IVF8, stream, 0.0, 0.0);   // work figures are device-side (list lengths): bench.py computes them
     const int64_t grid = 8 * cdiv((int64_t)d.max_groups, (int64_t)8);
     if (d.out_sum) hipLaunchKernelGGL(ivfpq_scan8_kernel<true>, dim3((unsigned)grid), dim3(1024), SCAN_LDS, stream, d);
     else hipLaunchKernelGGL(ivfpq_scan8_kernel<false>, dim3((unsigned)grid), dim3(1024), SCAN_LDS, stream, d);
@@ -551,7 +551,7 @@ int ivfpq_tau(const gnnlm_ivfpq_tau_t& d, hipStream_t stream) {
     if (d.n == 0) return OK;
     GNNLM_REQUIRE(d.sums && d.probe_list && d.probe_bias && d.list_off && d.qmeta && d.tau && d.ld_probe >= d.D, "ivfpq_tau: null operand");
     GNNLM_REQUIRE(d.seg % 8 == 0 && d.seg > 32 && (uintptr_t)d.sums % 16 == 0, "ivfpq_tau: segments of a multiple of 8 entries (longest list + 32, rounded up), 16-byte aligned");
-    ProfScope prof(K_TOPK, stream, 0.0, 2.0 * (double)d.n * d.D * d.seg);
+    ProfScope prof(K_TAU, stream, 0.0, 2.0 * (double)d.n * d.D * d.seg);
     hipLaunchKernelGGL(ivfpq_tau_kernel, dim3((unsigned)d.n), dim3(1024), 0, stream, d);
     GNNLM_LAUNCH_CHECK();
     return OK;

@@ -80,15 +80,14 @@ class IVFPQIndex:
         self.max_list = int((list_off[1:] - list_off[:-1]).max().item()) if self.nlist else 0
         # M = 32 / 64: the scan runs on its own image of the code rows (blocks of 64 rows, bytes in rotated order) and on
         # tables in [half][code][sub-quantizer] order -- look-ups without LDS bank conflicts (csrc/ivfpq.hip)
-        self.packed_codes = None
-        if self.M in (32, 64) and self.ntotal:
-            self.packed_codes = torch.empty(-(-self.ntotal // 64) * 64 * self.M, dtype=torch.uint8, device=self.device)
-            _lib.call("gnnlm_ivfpq_pack_codes", _lib.ptr(self.list_codes), self.ntotal, self.M, _lib.ptr(self.packed_codes), _lib.stream())
-        # M = 64: the int8-MFMA filter's image of the code rows (tiles of 16 rows, rotated byte order; csrc/ivfpq_mfma.hip)
-        self.tiles = None
-        scan = scan or os.environ.get("GNNLM_IVF_SCAN", "mfma")              # "f32": the one-pass float32 scan everywhere (A/B, tests)
+        # M = 64: the int8-MFMA search's image of the code rows (tiles of 16 rows, rotated byte order; csrc/ivfpq_mfma.hip)
+        self.packed_codes = self.tiles = None
+        scan = scan or os.environ.get("GNNLM_IVF_SCAN", "mfma")              # "f32": the float32 scan everywhere (A/B, tests)
         if self.M == 64 and self.ntotal and self.ntotal < (1 << 32) and scan != "f32":
             self.tiles = ops.ivfpq_pack_tiles(self.list_codes)
+        elif self.M in (32, 64) and self.ntotal:
+            self.packed_codes = torch.empty(-(-self.ntotal // 64) * 64 * self.M, dtype=torch.uint8, device=self.device)
+            _lib.call("gnnlm_ivfpq_pack_codes", _lib.ptr(self.list_codes), self.ntotal, self.M, _lib.ptr(self.packed_codes), _lib.stream())
         # lists per query behind the threshold: the float32 dense round scores 2 in full; the int8 threshold pass is cheap and its
         # bound a little loose, 6 lists give the tighter threshold (fewer survivors to re-score) for less time
         if self.dense_probes is None:
@@ -111,7 +110,7 @@ class IVFPQIndex:
 
     # ------------------------------------------------------------------------------------------ offline producer
     @classmethod
-    def build(cls, keys, nlist, M, device="cuda", cosine=True, nprobe=32, iters=10, train_size=262144, seed=0, chunk=1 << 18):
+    def build(cls, keys, nlist, M, device="cuda", cosine=True, nprobe=32, iters=10, train_size=262144, seed=0, chunk=1 << 18, **kw):
         device = torch.device(device)
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
@@ -147,7 +146,7 @@ class IVFPQIndex:
         off = torch.zeros(nlist + 1, dtype=torch.int64, device=device)
         off[1:] = torch.cumsum(torch.bincount(assign, minlength=nlist), 0)
         return cls(R.contiguous(), coarse.contiguous(), pq.contiguous(), off, order.contiguous(), codes[order].contiguous(),
-                   nprobe=nprobe, cosine=cosine)
+                   nprobe=nprobe, cosine=cosine, **kw)
 
     def save(self, path):
         np.savez(path, **{k: getattr(self, k).cpu().numpy() for k in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")},

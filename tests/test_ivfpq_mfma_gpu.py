@@ -112,7 +112,7 @@ def small_index(dev):
     N, d, nlist = 150_001, 256, 24
     centres, keys = clustered(rs, N, d, 60, 0.6)
     index = IVFPQIndex.build(keys, nlist, 64, device=dev, cosine=True, nprobe=9, iters=5, seed=3)
-    assert index.tiles is not None and index.packed_codes is not None
+    assert index.tiles is not None and index.packed_codes is None
     q = (centres[rs.randint(0, 60, 45)] + 0.6 * rs.randn(45, d)).astype(np.float32)
     q /= np.sqrt((q ** 2).sum(1, keepdims=True))
     return index, q
@@ -263,7 +263,7 @@ def test_mfma_search_identical_to_f32_scan(dev, small_index):
     index, q = small_index
     args = (index.R, index.coarse, index.pq, index.list_off, index.list_ids, index.list_codes)
     f32 = IVFPQIndex(*args, nprobe=9, scan="f32")
-    assert f32.tiles is None
+    assert f32.tiles is None and f32.packed_codes is not None
     for k in (1024, 64):
         v, i = _same_search(index, f32, q, k)
         arrs = [getattr(index, a).cpu().numpy() for a in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")]

@@ -176,7 +176,7 @@ def test_ivfpq_packed_scan_matches_oracle(dev, M):
     N, d, nlist = 150_001, 256, 24
     centres = rs.randn(60, d).astype(np.float32)
     keys = (centres[rs.randint(0, 60, N)] + 0.6 * rs.randn(N, d).astype(np.float32)).astype(np.float16)
-    index = IVFPQIndex.build(keys, nlist, M, device=dev, cosine=True, nprobe=9, iters=5, seed=3)
+    index = IVFPQIndex.build(keys, nlist, M, device=dev, cosine=True, nprobe=9, iters=5, seed=3, scan="f32")     # (M = 64 defaults to the int8-MFMA search: tests/test_ivfpq_mfma_gpu.py)
     assert index.packed_codes is not None and index.packed_codes.numel() == -(-N // 64) * 64 * M
     # the packed image, restated: block of 64 rows, piece-major, byte s of half h = sub-quantizer 32 h + (row + s) mod 32
     codes = index.list_codes.cpu().numpy()
@@ -198,7 +198,7 @@ def test_ivfpq_packed_scan_matches_oracle(dev, M):
         assert (np.diff(v, axis=1) <= 0).all() and (i >= 0).all()
     # too few candidate slots for the thresholded round: the search notices (survivor counts) and repeats itself with room
     tight = IVFPQIndex(index.R, index.coarse, index.pq, index.list_off, index.list_ids, index.list_codes, nprobe=9,
-                       dense_probes=1, cand_cap=2)
+                       dense_probes=1, cand_cap=2, scan="f32")
     qr = rs.randn(9, d).astype(np.float32)                                   # unclustered queries: neighbours in every probed list
     qr /= np.sqrt((qr ** 2).sum(1, keepdims=True))
     vf, jf = index.search(qr, 1024)
@@ -207,7 +207,7 @@ def test_ivfpq_packed_scan_matches_oracle(dev, M):
     np.testing.assert_allclose(v3, vf, rtol=1e-5, atol=1e-5)
     assert np.mean([len(set(a) & set(b)) / 1024 for a, b in zip(jf, i3)]) > 0.998
     # the same index searched by the row-major kernels gives the same neighbours
-    plain = IVFPQIndex(index.R, index.coarse, index.pq, index.list_off, index.list_ids, index.list_codes, nprobe=9)
+    plain = IVFPQIndex(index.R, index.coarse, index.pq, index.list_off, index.list_ids, index.list_codes, nprobe=9, scan="f32")
     plain.packed_codes = None
     v2, i2 = plain.search(qn, 64)
     np.testing.assert_allclose(v2, v, rtol=1e-5, atol=1e-5)
@@ -223,7 +223,7 @@ def test_ivfpq_small_lists_and_padding(dev, d, M):
     rs = np.random.RandomState(2)
     keys = rs.randn(300, d).astype(np.float32)
     index = IVFPQIndex.build(keys, 8, M, device=dev, cosine=False, nprobe=3, iters=4, seed=0)
-    assert (index.packed_codes is not None) == (M in (32, 64))
+    assert (index.packed_codes is not None) == (M == 32) and (index.tiles is not None) == (M == 64)
     q = rs.randn(5, d).astype(np.float32)
     v, i = index.search(q, 200)                                           # more than 3 lists hold: -1 padding
     arrs = [getattr(index, a).cpu().numpy() for a in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")]
@@ -287,7 +287,7 @@ def test_knn_model_reads_faiss_index_file(dev, tmp_path):
     f = str(dd / "faiss_store.cosine")
     faiss_io.write_ivfpq_index(f, arrs["R"], arrs["coarse"], arrs["pq"], arrs["list_off"], arrs["list_ids"], arrs["list_codes"], nprobe=1)
     m = KNNModel(f, str(dd), k=64, probe=6, no_load_keys=True, metric_type="do_not_recomp_ip", device=dev)
-    assert isinstance(m.index, IVFPQIndex) and m.index.nprobe == 6 and m.index.packed_codes is not None
+    assert isinstance(m.index, IVFPQIndex) and m.index.nprobe == 6 and m.index.packed_codes is not None and m.index.has_vals
     q = (centres[rs.randint(0, 30, 17)] + 0.5 * rs.randn(17, d)).astype(np.float32)
     qn = q / np.sqrt((q ** 2).sum(1, keepdims=True))
     v0, i0 = built.search(qn, 64)
