@@ -85,6 +85,8 @@ def get_parser():
     p.add_argument("--output-word-probs", action="store_true")
     p.add_argument("--output-word-stats", action="store_true")
     p.add_argument("--output-knn-recall", action="store_true")
+    p.add_argument("--remove-bpe", nargs="?", const="@@ ", default=None)
+    p.add_argument("--add-bos-token", action="store_true", default=False)
     p.add_argument("--log-format", default=None)
     p.add_argument("--device", default="cuda:0")
     return p
@@ -98,6 +100,88 @@ class _Dict:
 
     def eos(self):
         return 2
+
+
+class WordStat(object):
+    """Per-word accumulator of --output-word-stats (fairseq_cli/eval_lm.py:32-58)."""
+
+    def __init__(self, word, is_bpe):
+        self.word, self.is_bpe = word, is_bpe
+        self.log_prob, self.next_word_prob, self.count, self.missing_next_words = 0, 0, 0, 0
+
+    def add(self, log_prob, next_word_prob):
+        if next_word_prob is not None:
+            self.next_word_prob += next_word_prob
+        else:
+            self.missing_next_words += 1
+        self.log_prob += log_prob
+        self.count += 1
+
+    def __str__(self):
+        return '{}\t{}\t{}\t{}\t{}\t{}'.format(self.word, self.count, self.log_prob, self.is_bpe,
+                                               self.next_word_prob, self.count - self.missing_next_words)
+
+
+def load_symbols(data):
+    """Token id -> string of the data directory's fairseq dictionary (``dict.txt``: one ``<symbol> <count>`` line per entry
+    after the four specials, fairseq/data/dictionary.py); None if the file is absent (words are then printed as ids)."""
+    f = os.path.join(data, "dict.txt")
+    if not os.path.exists(f):
+        return None
+    syms = ["<s>", "<pad>", "</s>", "<unk>"]
+    with open(f, encoding="utf-8") as fh:
+        for line in fh:
+            line = line.rstrip("\n")
+            if line:
+                syms.append(line.rsplit(" ", 1)[0])
+    return syms
+
+
+def word_outputs(args, hypos, sample_ids, symbols, bpe_toks, bpe_len, word_stats):
+    """--output-word-probs / --output-word-stats / --output-knn-recall (fairseq_cli/eval_lm.py:246-313), hypothesis by
+    hypothesis on the host (an opt-in reporting path: it synchronises).  Returns the number of BPE continuation tokens
+    whose scores were folded into the next token (they do not count as words, :258-263,274)."""
+    skipped_total = 0
+    for i, hyp in enumerate(hypos):
+        h = hyp[0]
+        tokens = h["tokens"].cpu()
+        pos_scores = h["positional_scores"].float().cpu().clone()
+        knn_recall = h["knn_recall"].cpu() if h["knn_recall"] is not None else None
+        if args.add_bos_token:
+            tokens, pos_scores = tokens[1:], pos_scores[1:]
+        tgt_len = tokens.numel()
+        if bpe_toks is not None:
+            for t in range(tgt_len - 1):
+                if tokens[t].item() in bpe_toks:
+                    skipped_total += 1
+                    pos_scores[t + 1] += pos_scores[t]
+                    pos_scores[t] = 0
+        w, word_prob, is_bpe = "", [], False
+        for t in range(len(tokens)):
+            w_ind = tokens[t].item()
+            w += symbols[w_ind] if symbols is not None and w_ind < len(symbols) else str(w_ind)
+            if bpe_toks is not None and w_ind in bpe_toks:
+                w = w[:-bpe_len]
+                is_bpe = True
+            else:
+                if args.output_knn_recall:
+                    word_prob.append((w, pos_scores[t].item(), knn_recall[t] if knn_recall is not None else None))
+                else:
+                    word_prob.append((w, pos_scores[t].item()))
+                next_prob, ind = None, t + 1
+                while ind < len(tokens):
+                    if pos_scores[ind].item() != 0:
+                        next_prob = pos_scores[ind]
+                        break
+                    ind += 1
+                word_stats.setdefault(w, WordStat(w, is_bpe)).add(pos_scores[t].item(), next_prob)
+                is_bpe, w = False, ""
+        if args.output_word_probs:
+            if args.output_knn_recall:
+                logger.info(str(int(sample_ids[i])) + " " + ('\t'.join('{} [{:2f}] [{}]'.format(x[0], x[1], x[2]) for x in word_prob)))
+            else:
+                logger.info(str(int(sample_ids[i])) + " " + ('\t'.join('{} [{:2f}]'.format(x[0], x[1]) for x in word_prob)))
+    return skipped_total
 
 
 def block_ranges(n_tokens, block, context_window=0):
@@ -159,7 +243,7 @@ def main(args, tables=None, model=None):
     left, right = (nc, nc) if isinstance(nc, int) else nc
     store = model.make_store(tabs["codes"], tabs["n_store"], device)
     T = args.tokens_per_sample - args.context_window
-    blocks = block_ranges(tabs["n_tok"], T, args.gcn_context_window)
+    blocks = [r + (bid,) for bid, r in enumerate(block_ranges(tabs["n_tok"], T, args.gcn_context_window))]   # (context start, start, end, sample id)
     if args.first > 0:
         blocks = blocks[:args.first]
     blocks = blocks[args.shard_id::args.num_shards]                                        # eval_lm.py:131-132
@@ -206,6 +290,21 @@ def main(args, tables=None, model=None):
                                   shape=(dstore_size, dim)),
                 "vals": np.memmap(os.path.join(save_dir, "vals.npy"), dtype=np.int16 if fp16 and vocab < 2 ** 15 else np.int32,
                                   mode="w+", shape=(dstore_size, 1))}
+    # --output-word-probs / --output-word-stats / --output-knn-recall / --remove-bpe (fairseq_cli/eval_lm.py:146-160,246-313,333-336)
+    want_words = args.output_word_probs or args.output_word_stats
+    symbols, bpe_toks, bpe_len, word_stats = None, None, 0, dict()
+    if want_words or args.remove_bpe is not None:
+        symbols = load_symbols(args.data)
+    if args.remove_bpe is not None:
+        if args.remove_bpe == "sentencepiece":
+            raise NotImplementedError                                        # as the reference (:148-149)
+        if symbols is None:
+            raise ValueError("--remove-bpe needs the data directory's dict.txt (the continuation marker lives in the symbols)")
+        bpe_cont = args.remove_bpe.rstrip()
+        bpe_toks = {i for i in range(len(symbols)) if symbols[i].endswith(bpe_cont)}
+        bpe_len = len(bpe_cont)
+    if args.output_knn_recall and not args.knnlm:
+        raise ValueError("--output-knn-recall needs --knnlm (the scorer returns no recall otherwise)")
     acc = torch.zeros(1, device=device, dtype=torch.float64)
     count, ntok = 0, 0
     timers = []             # gen_timer (eval_lm.py:214-219) as HIP event pairs on the stream: no per-batch host sync
@@ -222,7 +321,7 @@ def main(args, tables=None, model=None):
         if all(group[j + 1][0] == group[j][2] for j in range(len(group) - 1)):
             idx = slice(group[0][0], group[-1][2])           # back-to-back blocks (no --gcn-context-window): plain views, no gather
         else:
-            idx = torch.cat([torch.arange(c, e, device=device) for c, _, e in group])
+            idx = torch.cat([torch.arange(g_[0], g_[2], device=device) for g_ in group])
         target = tabs["targets"][idx].view(len(group), L)
         nb_ids = tabs["nbrs"][idx].contiguous()
         if invalid_ctx > 0:
@@ -230,9 +329,9 @@ def main(args, tables=None, model=None):
             nb_ids = ops.filter_neighbors(nb_ids, tok_pos.contiguous(), invalid_ctx)
         graph = NeighborGraph(ids=nb_ids, n_blocks=len(group), T=L, left=left, right=right,
                               store=store, tgt_h=tabs["feats"][idx].contiguous(), max_intra_context=args.intra_context)
-        sample = {"id": torch.arange(len(group)), "nsentences": len(group), "ntokens": len(group) * L,
+        sample = {"id": torch.tensor([g_[3] for g_ in group]), "nsentences": len(group), "ntokens": len(group) * L,
                   "net_input": {"src_tokens": target, "src_lengths": torch.full((len(group),), L), "graph": graph},
-                  "target": target, "start_indices": [s - c for c, s, _ in group]}
+                  "target": target, "start_indices": [g_[1] - g_[0] for g_ in group]}
         if tabs.get("no_pad") is not None:
             sample["no_pad_in_target"] = tabs["no_pad"]
         if args.batch_blocks > 0:
@@ -260,6 +359,8 @@ def main(args, tables=None, model=None):
         pos = torch.cat([h[0]["positional_scores"].float().reshape(-1) for h in hypos])     # one launch per batch
         ops.masked_sum_f64(pos, None, acc)                                                  # score_sum (:273), in f64
         count += pos.numel()                                                                # :274
+        if want_words or bpe_toks is not None:
+            count -= word_outputs(args, hypos, sample["id"], symbols, bpe_toks, bpe_len, word_stats)     # skipped_toks (:274)
     score_sum = acc.item()                                                                  # the only host sync
     if save is not None:
         save["keys"].flush()
@@ -278,8 +379,11 @@ def main(args, tables=None, model=None):
     logger.info(line2)
     print(line1)
     print(line2)
+    if args.output_word_stats:                                                              # :333-336
+        for ws in sorted(word_stats.values(), key=lambda x: x.count, reverse=True):
+            logger.info(ws)
     return {"score_sum": score_sum, "count": count, "ppl": 2 ** avg_nll_loss, "tokens": ntok, "seconds": gen_time,
-            "wall_seconds": wall}
+            "wall_seconds": wall, "word_stats": word_stats if args.output_word_stats else None}
 
 
 def cli_main(argv=None):

@@ -20,6 +20,11 @@ after ``add_with_ids`` (knn/index_builder.py:79-150), the file ``KNNModel`` is p
 
   index      |= fourcc "IwPQ" ivf_header  bool by_residual  uint64 code_size  pq  invlists                (IndexIVFPQ)
               | fourcc ("IxFI" | "IxF2" | "IxFl") header  vector<float> xb                                 (IndexFlat, the coarse quantizer)
+              | fourcc "IHNf" header  hnsw  index (an IndexFlat: the storage)                             (IndexHNSWFlat: the coarse quantizer of
+                                                                                                             `IVF{n}_HNSW32`, what index_builder.py:60-64 picks
+                                                                                                             by itself for >= 10^6 keys)
+  hnsw       := vector<double> assign_probas  vector<int32> cum_nneighbor_per_level  vector<int32> levels  vector<uint64> offsets
+                vector<int32> neighbors  int32 entry_point  int32 max_level  int32 efConstruction  int32 efSearch  int32 upper_beam
   ivf_header := header  uint64 nlist  uint64 nprobe  index (quantizer)  int8 direct_map_type  vector<int64> direct_map
                 [vector<(int64, int64)> if direct_map_type == 2]
   invlists   := fourcc "ilar"  uint64 nlist  uint64 code_size  fourcc ("full" | "sprs")  vector<uint64> sizes
@@ -153,8 +158,18 @@ def read_ivfpq_index(path):
     d, ntotal, trained, metric = _header(r)
     nlist, nprobe = r.take("Q"), r.take("Q")
     qcc = r.fourcc()
+    coarse_kind = "flat"
+    if qcc == "IHNf":
+        # IVF{n}_HNSW32: the centroids are the flat storage behind the HNSW graph.  The graph is skipped -- the device search
+        # ranks ALL centroids exactly (a GEMM), where faiss walks the graph with efSearch candidates: the probed lists can differ
+        # from faiss's approximate choice (they are the exact top-nprobe, never worse)
+        _header(r)
+        r.vector(np.float64); r.vector(np.int32); r.vector(np.int32); r.vector(np.uint64); r.vector(np.int32)
+        r.take("i"); r.take("i"); r.take("i"); r.take("i"); r.take("i")
+        qcc = r.fourcc()
+        coarse_kind = "hnsw"
     if qcc not in ("IxFI", "IxF2", "IxFl"):
-        raise ValueError(f"{path}: coarse quantizer '{qcc}' (the recipes' IVF4096 uses an IndexFlat)")
+        raise ValueError(f"{path}: coarse quantizer '{qcc}' (expected an IndexFlat, or an IndexHNSWFlat over one)")
     qd, qn, _, qmetric = _header(r)
     xb = r.vector(np.float32)
     if qd != d or qn != nlist or xb.size != nlist * d:
@@ -197,11 +212,13 @@ def read_ivfpq_index(path):
             r.o += 8 * n
     return {"R": R, "coarse": xb.reshape(nlist, d), "pq": cen.reshape(M, 256, d // M), "list_off": off, "list_ids": ids,
             "list_codes": codes, "nprobe": int(nprobe), "metric": "ip" if metric == 0 else "l2",
-            "coarse_metric": "ip" if qmetric == 0 else "l2", "by_residual": bool(by_residual)}
+            "coarse_metric": "ip" if qmetric == 0 else "l2", "by_residual": bool(by_residual), "coarse_kind": coarse_kind}
 
 
-def write_ivfpq_index(path, R, coarse, pq, list_off, list_ids, list_codes, nprobe=1, metric="ip"):
-    """The inverse, same layout (what ``faiss.write_index`` emits for ``OPQ..,IVF..,PQ..`` with array inverted lists)."""
+def write_ivfpq_index(path, R, coarse, pq, list_off, list_ids, list_codes, nprobe=1, metric="ip", coarse_kind="flat"):
+    """The inverse, same layout (what ``faiss.write_index`` emits for ``OPQ..,IVF..,PQ..`` with array inverted lists).
+    ``coarse_kind="hnsw"``: the coarse quantizer wrapped as an IndexHNSWFlat with an EMPTY graph (the layout of
+    ``IVF{n}_HNSW32``; enough for the reader, which skips the graph -- not a file faiss could search)."""
     coarse = np.ascontiguousarray(coarse, dtype=np.float32)
     cen = np.ascontiguousarray(pq, dtype=np.float32)
     nlist, d = coarse.shape
@@ -220,6 +237,9 @@ def write_ivfpq_index(path, R, coarse, pq, list_off, list_ids, list_codes, nprob
             f.write(b"LTra" + struct.pack("<?", False) + vec(R, np.float32) + vec(np.zeros(0, np.float32), np.float32)
                     + struct.pack("<ii?", d_in, d_out, True))
         f.write(b"IwPQ" + hdr(d, N) + struct.pack("<QQ", nlist, nprobe))
+        if coarse_kind == "hnsw":
+            f.write(b"IHNf" + hdr(d, nlist) + vec(np.zeros(0), np.float64) + vec(np.zeros(0, np.int32), np.int32) * 2
+                    + vec(np.zeros(0, np.uint64), np.uint64) + vec(np.zeros(0, np.int32), np.int32) + struct.pack("<iiiii", -1, -1, 40, 16, 1))
         f.write((b"IxFI" if mt == 0 else b"IxF2") + hdr(d, nlist) + vec(coarse, np.float32))
         f.write(struct.pack("<b", 0) + vec(np.zeros(0, np.int64), np.int64))
         f.write(struct.pack("<?Q", True, M) + struct.pack("<QQQ", d, M, 8) + vec(cen, np.float32))

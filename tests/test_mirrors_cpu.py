@@ -141,6 +141,13 @@ def test_faiss_ivfpq_index_file_round_trip(tmp_path):
             assert np.array_equal(z["coarse"], coarse) and np.array_equal(z["pq"], pq)
             assert np.array_equal(z["list_off"], off) and np.array_equal(z["list_ids"], ids) and np.array_equal(z["list_codes"], codes)
             assert z["nprobe"] == 3 and z["metric"] == "ip" and z["coarse_metric"] == "ip" and z["by_residual"]
+    # `IVF{n}_HNSW32` (what index_builder.py:60-64 picks by itself for >= 10^6 keys): the coarse quantizer is an IndexHNSWFlat;
+    # the reader takes the flat storage behind the graph
+    write_ivfpq_index(f, R, coarse, pq, off, ids, codes, nprobe=5, coarse_kind="hnsw")
+    z = read_ivfpq_index(f)
+    assert z["coarse_kind"] == "hnsw" and np.array_equal(z["coarse"], coarse) and np.array_equal(z["list_codes"], codes) and z["nprobe"] == 5
+    assert b"IHNf" in open(f, "rb").read()
+    write_ivfpq_index(f, None, coarse, pq, off, ids, codes, nprobe=3)
     raw = open(f, "rb").read()
     # IwPQ | header (int32 d, int64 ntotal, 2 x int64, bool, int32 metric) | uint64 nlist | uint64 nprobe | IxFI ...
     assert raw[:4] == b"IwPQ" and struct.unpack_from("<iq", raw, 4) == (d, 9)

@@ -379,3 +379,64 @@ def test_eval_lm_train_split_invalid_neighbor_context(dev, tmp_path):
     ref, ref_nofilter = np.concatenate(ref), np.concatenate(ref_nofilter)
     assert np.abs(keys - ref).max() < 1e-4
     assert np.abs(ref - ref_nofilter).max() > 1e-2                            # the filter changes the features: the test bites
+
+
+def test_eval_lm_word_outputs(dev, tmp_path, caplog):
+    """--output-word-probs / --output-word-stats / --output-knn-recall / --remove-bpe (fairseq_cli/eval_lm.py:146-160,246-313,
+    333-336): one line per hypothesis `<sample id> <word> [<score>] [<recall>]\\t...`, per-word statistics whose totals are the
+    run's score sum and token count, BPE continuation tokens folded into the following token (count = tokens - skipped)."""
+    import logging
+    from gnnlm_amd import eval_lm
+    c = make_data_dir(tmp_path)
+    data, T, n_test, blk = c["data"], c["T"], c["n_test"], c["blk"]
+    V = 600
+    syms = [f"w{i}" + ("@@" if i % 5 == 0 else "") for i in range(4, V)]
+    with open(data / "dict.txt", "w") as f:
+        for s_ in syms:
+            f.write(f"{s_} 1\n")
+    knn = ["--knnlm", "--k", "8", "--lmbda", "0.25", "--dstore-dir", str(data / "train_dstore"), "--index-file",
+           str(data / "train_dstore" / "faiss_store.cosine"), "--temperature", "1.0", "--knn-sim-func", "ip"]
+    base1 = list(c["base"])
+    base1[base1.index("--max-tokens") + 1] = str(T)
+    plain = eval_lm.cli_main(base1 + knn)
+    with caplog.at_level(logging.INFO, logger="gnnlm_amd.eval_lm"):
+        res = eval_lm.cli_main(base1 + knn + ["--output-word-probs", "--output-word-stats", "--output-knn-recall"])
+    assert res["count"] == n_test and abs(res["score_sum"] - plain["score_sum"]) < 1e-6 * n_test
+    lines = [r.getMessage() for r in caplog.records if "\t" in r.getMessage() and "[" in r.getMessage()]
+    n_blocks = -(-n_test // T)
+    assert len(lines) == n_blocks
+    first = lines[0].split(" ", 1)
+    assert first[0] == "0"                                                    # sample id = block index in the split
+    words = first[1].split("\t")
+    assert len(words) == T
+    tok0 = int(blk["targets"][0])
+    assert words[0].startswith(("w%d" % tok0) + ("@@" if tok0 % 5 == 0 else "") + " [")
+    assert words[0].count("[") == 2                                           # score and recall
+    assert lines[-1].split(" ", 1)[0] == str(n_blocks - 1)
+    ws = res["word_stats"]
+    assert sum(w.count for w in ws.values()) == n_test
+    assert abs(sum(w.log_prob for w in ws.values()) - res["score_sum"]) < 1e-3
+    some = next(iter(ws.values()))
+    assert str(some).count("\t") == 5
+    # --remove-bpe: tokens whose symbol ends with the continuation marker are folded into the next one
+    caplog.clear()
+    with caplog.at_level(logging.INFO, logger="gnnlm_amd.eval_lm"):
+        bpe = eval_lm.cli_main(base1 + ["--output-word-stats", "--remove-bpe"])
+    tg = blk["targets"][:n_test]
+    skipped = 0
+    for s in range(0, n_test, T):
+        seg = tg[s:s + T]
+        skipped += int(((seg[:-1] % 5) == 0).sum())                           # (the last token of a hypothesis is never folded, :258)
+    assert bpe["count"] == n_test - skipped
+    assert not any(k_.endswith("@@") for k_ in bpe["word_stats"])            # continuation markers are stripped from the words
+    # without dict.txt words are printed as token ids
+    (data / "dict.txt").unlink()
+    caplog.clear()
+    with caplog.at_level(logging.INFO, logger="gnnlm_amd.eval_lm"):
+        eval_lm.cli_main(base1 + ["--output-word-probs"])
+    l0 = [r.getMessage() for r in caplog.records if "\t" in r.getMessage() and "[" in r.getMessage()][0]
+    assert l0.split(" ", 1)[1].split("\t")[0].startswith(f"{tok0} [")
+    with pytest.raises(ValueError):
+        eval_lm.cli_main(base1 + ["--remove-bpe"])
+    with pytest.raises(ValueError):
+        eval_lm.cli_main(base1 + ["--output-knn-recall", "--output-word-probs"])
