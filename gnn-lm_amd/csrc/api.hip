@@ -142,7 +142,7 @@ void carve_hgt(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, Carver& c, HgtBuf
     b.aout = c.take<float>(Tt * d);
     b.has_nb = c.take<float>(Tt);
     if (needs_ntgt(m, io)) {
-        const int64_t S = Tt * io.kg * (1 + m.left + m.right);
+        const int64_t S = (io.group_ids ? io.n_unique : Tt * io.kg) * (1 + m.left + m.right);
         b.hn[0] = c.take<float>(S * dmax);
         b.hn[1] = c.take<float>(S * dmax);
         b.nq = c.take<float>(S * dmax);
@@ -212,7 +212,12 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
     const int d = m.d, H = m.n_heads, dk = d / H, T = io.T, kg = io.kg, nb = io.n_blocks;
     const int n_g = 1 + m.left + m.right;
     const int dpq = dense0 ? d : m.M * m.dsub;
-    const int64_t G = Tt * kg, S = G * n_g;
+    // ABI 6: the ntgt pipeline over the DISTINCT centre rows of the batch (io.group_ids); the star edges reach a group through
+    // io.group_index
+    const bool dedup = io.group_ids != nullptr;
+    GNNLM_REQUIRE(!dedup || (ntgt && !dense0 && !io.fetched_codes && io.group_index && io.n_unique >= 0 && !io.out_ntgt && !io.out_valid),
+                  "hgt: group_ids needs group_index, a multi-layer model on a resident store and no ntgt outputs");
+    const int64_t G = dedup ? io.n_unique : Tt * kg, S = G * n_g;
     GNNLM_REQUIRE(dk % 4 == 0 && d % 4 == 0 && dpq % 4 == 0, "hgt: d_k and the PQ dimension must be multiples of 4");
     GNNLM_REQUIRE(dense0 || m.opq_at || dpq == d, "hgt: without OPQ the PQ dimension must equal d");
 
@@ -231,6 +236,9 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         ld_hn = io.ld_ntgt;
         valid = io.ntgt_valid;
         if (io.out_valid) GNNLM_HIP(hipMemcpyAsync(io.out_valid, valid, (size_t)S, hipMemcpyDeviceToDevice, s));
+    } else if (ntgt && S == 0) {                         // a de-duplicated batch without a single valid neighbour
+        hn_cur = b.hn[0];
+        valid = b.valid;
     } else if (ntgt) {
         // layer-0 ntgt states: PQ lookup of every slot, then the OPQ rotation (pq_wrapper.py:189-202)
         GatherParams g{};
@@ -242,7 +250,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         g.vals = nullptr; g.vals_itemsize = 4;
         g.n_store = m.n_store; g.row0 = m.row0; g.n_local = m.n_local;
         g.M = m.M; g.dsub = m.dsub; g.centroids = m.centroids;
-        g.ids = io.ids; g.n_groups = G; g.left = m.left; g.right = m.right;
+        g.ids = dedup ? io.group_ids : io.ids; g.n_groups = G; g.left = m.left; g.right = m.right;
         g.out_valid = b.valid;
         const gnnlm_hgt_layer_t& w0 = m.layers[0];
         fold0 = m.opq_at && w0.wq_n0 && w0.bq_n0 && w0.wk_n0 && w0.bk_n0 && w0.wv_n0 && w0.bv_n0;
@@ -337,6 +345,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             a.Z = b.Z; a.has_nb = b.has_nb;
             a.n_store = m.n_store;
             if (ntgt || dense0) { a.nb_valid = valid; a.nb_valid_stride = n_g; }        // centre slot of each group
+            if (dedup) a.x_index = io.group_index;
             else if (io.fetched_valid) { a.nb_valid = io.fetched_valid; a.nb_valid_stride = io.fetched_centres_only ? 1 : n_g; }
             if (l == 0 && !dense0) {
                 a.codes = io.fetched_codes ? io.fetched_codes : m.codes;
@@ -368,7 +377,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         TRY(layernorm(b.aout, d, w.ln_g_t, w.ln_b_t, ht_out, d, Tt, d, m.ln_eps, nullptr, s, ht_in, d));    // + h (hgt.py:403)
 
         // ---- ntgt update (only when a later layer -- or the caller -- consumes it)
-        if (ntgt && (!last || io.out_ntgt)) {
+        if (ntgt && (!last || io.out_ntgt) && S > 0) {
             GNNLM_REQUIRE(w.wq_n && w.wk_n && w.wv_n && w.wa_n && w.ln_g_n && w.ln_b_n, "hgt: layer has null ntgt weights");
             // Only what a later layer reads is computed (outputs identical to the full update): the last layer's star edges
             // read the CENTRE slot of each group, and a slot's update depends on its path neighbours at distance 1

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void star_attn_kernel(StarAttnParams p, bool s
                     }
                     x[t] = *reinterpret_cast<const float4*>(p.centroids + ((int64_t)(m * 256 + code)) * p.dsub + within);
                 } else {
-                    x[t] = *reinterpret_cast<const float4*>(p.X + ((int64_t)i * kg + j) * p.x_group_stride * p.ldx + 4 * q);
+                    x[t] = *reinterpret_cast<const float4*>(p.X + star_group(p, i, j) * p.x_group_stride * p.ldx + 4 * q);
                 }
             }
         }

@@ -66,11 +66,19 @@ __device__ __forceinline__ const uint8_t* shard_row_ptr(const gnnlm_shards_t* sh
     const int64_t local = row - sh->row0[g];
     return local >= 0 && local < sh->rows[g] ? sh->base[g] + local * M : nullptr;
 }
+// group of neighbour (i, j): its own (i * kg + j), or the distinct-centre group of a de-duplicated batch (-1: none)
+__device__ __forceinline__ int64_t star_group(const StarAttnParams& p, int i, int j) {
+    const int64_t e = (int64_t)i * p.kg + j;
+    return p.x_index ? (int64_t)p.x_index[e] : e;
+}
 __device__ __forceinline__ bool star_nb_ok(const StarAttnParams& p, int i, int j, int64_t id) {
     bool ok = id >= 0 && (p.n_store <= 0 || id < p.n_store);
     if (p.shards) ok = ok && shard_row_ptr(p.shards, id, p.M) != nullptr;
     else if (p.codes && !p.codes_direct) ok = ok && id - p.row0 >= 0 && id - p.row0 < p.n_local;
-    if (ok && p.nb_valid) ok = p.nb_valid[((int64_t)i * p.kg + j) * p.nb_valid_stride] != 0;
+    if (ok && (p.nb_valid || p.x_index)) {
+        const int64_t gi = star_group(p, i, j);
+        ok = gi >= 0 && (!p.nb_valid || p.nb_valid[gi * p.nb_valid_stride] != 0);
+    }
     return ok;
 }
 // row of the code table that holds neighbour (i, j) (store rows, or the slots of an exchange)

@@ -15,6 +15,7 @@ Before the first forward the weights are *prepared* once (float64 on the host, r
 all exact algebra -- only the floating-point association changes.
 """
 import ctypes
+import os
 import math
 from dataclasses import dataclass
 from typing import Dict, Optional
@@ -213,6 +214,8 @@ class HGT(nn.Module):
             self.out = nn.Linear(hidden_dim, out_dim)
         self._prepared = None
         self.gemm_precision = 0     # 0 exact f32 MFMA | 1 bf16x3 | 2 bf16x6 (opt-in split-bf16 emulation)
+        self.dedup_groups = os.environ.get("GNNLM_DEDUP", "1") != "0"      # merge equal context groups of a batch (multi-layer models)
+        self.last_groups = None                                              # (groups of the last batch, distinct ones)
 
     def _load_from_state_dict(self, *a, **k):
         self._prepared = None
@@ -316,6 +319,20 @@ class HGT(nn.Module):
                 io.fetched_index = G.fetched_index.data_ptr()
         if adapted:
             io.ntgt_feats, io.ld_ntgt, io.ntgt_valid = ntgt0.data_ptr(), ntgt0.stride(0), ntgt_valid.data_ptr()
+        # exact de-duplication of context groups (the reference's "todo: merge same nodes", token_block_dataset.py:355): the ntgt
+        # states of a group depend on its centre row only, and the neighbour lists of nearby tokens overlap heavily -- the
+        # multi-layer ntgt pipeline runs once per DISTINCT centre row of the batch.  One host sync (the number of groups).
+        st = G.store
+        if (self.n_layers > 1 and self.dedup_groups and not adapted and not return_ntgt and G.fetched_codes is None
+                and not torch.cuda.is_current_stream_capturing()              # (a captured step stays sync-free: no merging)
+                and getattr(st, "shards", None) is None and st.row0 == 0 and st.codes.shape[0] == st.n_store):
+            flat = ids.reshape(-1)
+            key = torch.where((flat >= 0) & (flat < st.n_store), flat, torch.full_like(flat, -1))
+            u, inv = torch.unique(torch.cat([key.new_full((1,), -1), key]), return_inverse=True)     # u[0] == -1 always
+            group_ids = u[1:].contiguous()
+            group_index = (inv[1:] - 1).to(torch.int32).contiguous()                                  # -1: not a neighbour
+            io.group_ids, io.n_unique, io.group_index = group_ids.data_ptr(), group_ids.numel(), group_index.data_ptr()
+            self.last_groups = (flat.numel(), group_ids.numel())
         out_tgt = torch.empty_like(tgt)
         io.out_tgt = out_tgt.data_ptr()
         S = ids.shape[0] * G.kg * n_g

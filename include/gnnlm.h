@@ -157,6 +157,10 @@ typedef struct gnnlm_star_attn {
     int64_t n_store;
     const uint8_t* nb_valid;  int64_t nb_valid_stride;
     const gnnlm_shards_t* shards;  /* ABI 4 (DEVICE pointer): replaces codes / row0 / n_local (PQ source, not with codes_direct) */
+    /* ABI 6: optional [T, kg] group of neighbour (i, j) (-1: not a neighbour) when the dense rows / validity bytes are stored
+     * once per DISTINCT centre row of the batch: row of (i,j) = X + x_index[i*kg+j]*x_group_stride*ldx, validity byte
+     * nb_valid[x_index[i*kg+j]*nb_valid_stride] */
+    const int32_t* x_index;
 } gnnlm_star_attn_t;
 int gnnlm_star_attn(const gnnlm_star_attn_t* desc, void* stream);
 
@@ -415,6 +419,12 @@ typedef struct gnnlm_hgt_io {
      * not read; layer 0's `din` must be d. */
     const float* ntgt_feats;  int64_t ld_ntgt;
     const uint8_t* ntgt_valid;
+    /* ABI 6, optional: exact de-duplication of context groups (the reference's own "todo: merge same nodes",
+     * fairseq/data/token_block_dataset.py:355).  A group's ntgt states depend on its centre row only (ntgt nodes never
+     * receive from tgt nodes), so the ntgt pipeline of every layer runs once per DISTINCT centre row of the batch:
+     * group_ids [n_unique] the distinct valid rows, group_index [n_blocks*T*kg] the group of neighbour (i, j) (-1: not a
+     * neighbour).  Results are those of the un-merged graph.  Not with fetched_codes / ntgt_feats / out_ntgt / out_valid. */
+    const int64_t* group_ids;  int64_t n_unique;  const int32_t* group_index;
 } gnnlm_hgt_io_t;
 
 /* x = gelu(x) in place, the exact (erf) form of torch.nn.functional.gelu (input adapters of HGT, hgt.py:507) */

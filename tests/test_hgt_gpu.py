@@ -173,3 +173,50 @@ def test_step_is_graph_capturable(dev, precision):
     torch.cuda.synchronize()
     ref = eng.score(batch, 0.25, 1.0)
     assert torch.equal(out["logp"], ref["logp"]) and not torch.equal(out["logp"], eager["logp"])
+
+
+@pytest.mark.parametrize("L", [2, 3])
+def test_hgt_dedup_context_groups(dev, L):
+    """Equal context groups of a batch are computed once (the reference's 'todo: merge same nodes',
+    token_block_dataset.py:355; a group's states depend on its centre row only): heavy duplicates across tokens and blocks,
+    -1 / out-of-store ids, contexts clipped at both ends of the store -- bit-identical to the un-merged run of the same
+    kernels, and equal to the un-merged float64 oracle."""
+    from gnnlm_amd.hgt import HGT, NeighborGraph
+    d, H, M, dsub, T, kg, l, r, nblk = 128, 8, 16, 8, 12, 10, 2, 2, 3
+    rs = np.random.RandomState(50 + L)
+    n_store = 400
+    codes = rs.randint(0, 256, size=(n_store, M)).astype(np.uint8)
+    cen = (rs.randn(M, 256, dsub) * 0.5).astype(np.float32)
+    A = (rs.randn(M * dsub, d) / np.sqrt(M * dsub)).astype(np.float32)
+    b = (rs.randn(M * dsub) * 0.1).astype(np.float32)
+    pool = np.concatenate([[0, 1, n_store - 1, n_store - 2], rs.randint(0, n_store, 20)])     # ~24 distinct rows for 360 groups
+    nb = pool[rs.randint(0, len(pool), size=(nblk * T, kg))].astype(np.int64)
+    nb[rs.rand(*nb.shape) < 0.05] = -1
+    nb[2] = -1
+    nb[5, 3] = n_store + 4                                                    # not a row of the store
+    nb[7] = nb[6]                                                             # identical lists
+    tgt = rs.randn(nblk * T, d).astype(np.float16).astype(np.float32)
+    sd = {k: v.numpy() for k, v in ohgt.init_hgt_weights(L, d, H, seed=5).items()}
+    store = make_store(dev, codes, cen, A, b)
+    model = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=L, n_heads=H)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    G = NeighborGraph(ids=torch.from_numpy(nb).to(dev), n_blocks=nblk, T=T, left=l, right=r, store=store)
+    x = torch.from_numpy(tgt).to(dev)
+    assert model.dedup_groups
+    merged = model(G, features={"tgt": x})["tgt"].cpu().numpy()
+    n_all, n_distinct = model.last_groups
+    assert n_all == nblk * T * kg and n_distinct <= len(np.unique(pool)) and n_distinct >= 10
+    model.dedup_groups = False
+    plain = model(G, features={"tgt": x})["tgt"].cpu().numpy()
+    assert np.array_equal(merged, plain)                                      # same kernels, same row arithmetic: same bits
+    nbo = np.where(nb >= n_store, -1, nb)                                     # (the reference raises IndexError for such a row; here it is no neighbour)
+    ref = np.concatenate([oracle_hgt(sd, L, H, tgt[i * T:(i + 1) * T], nbo[i * T:(i + 1) * T], codes, cen, A, b, n_store, l, r)["tgt"].numpy()
+                          for i in range(nblk)])
+    assert np.abs(merged - ref).max() < 1e-4
+    # a batch without a single valid neighbour
+    model.dedup_groups = True
+    none = NeighborGraph(ids=torch.full((T, kg), -1, dtype=torch.int64, device=dev), n_blocks=1, T=T, left=l, right=r, store=store)
+    o1 = model(none, features={"tgt": x[:T]})["tgt"].cpu().numpy()
+    assert model.last_groups == (T * kg, 0)
+    model.dedup_groups = False
+    assert np.array_equal(o1, model(none, features={"tgt": x[:T]})["tgt"].cpu().numpy())
