@@ -35,8 +35,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr int QG = 8;                                   // queries per workgroup
 constexpr int TAB_BYTES = 2 * 256 * 32 * QG;            // [half][code][slot][query]: 128 KiB
-constexpr int STAGE_CAP = 640;                          // survivors staged per query and task
-constexpr int SCAN_LDS = TAB_BYTES + 64 + QG * STAGE_CAP * 4;
+constexpr int WAVE_CAP = 320;                           // survivors a wave stages per task (all 8 queries of its group)
+constexpr int SCAN_LDS = TAB_BYTES + 512 + 16 * WAVE_CAP * 4;
+constexpr int SURV_CNT_STRIDE = 16;                     // survivor counters one per 64-byte line: they are hammered by atomics
 constexpr int QLUT_BYTES = 64 * 256;                    // one query's quantised table
 
 // codes [N, 64] row-major -> tiles of 16 rows, [tile][g 0..3][i 0..15][p 0..15] = code[16 tile + i][16 g + (i + p) % 16];
@@ -146,8 +147,7 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     const int64_t lo = p.list_off[list], hi = p.list_off[list + 1];
     if (hi <= lo) return;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
-    int* scnt = reinterpret_cast<int*>(smem + TAB_BYTES);                     // [8] survivor counts, [8] output bases
-    uint32_t* sbuf = reinterpret_cast<uint32_t*>(smem + TAB_BYTES + 64);      // [8][STAGE_CAP] row - lo
+    uint32_t* wbuf = reinterpret_cast<uint32_t*>(smem + TAB_BYTES + 512) + wave * WAVE_CAP;   // this wave's survivors: (row - lo) << 3 | query slot
     const int* gq = p.grp_q + (int64_t)grp * QG;
     uint2* surv = reinterpret_cast<uint2*>(p.surv);                           // {row, list} per survivor
     int qs[QG];
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     const int j = lane & 15, g = lane >> 4;
     int T = 0x7fffffff;
     const int qj = j < QG ? gq[j] : -1;                                   // (a register array may not be indexed by the lane)
+    const int qs_lane = lane < QG ? gq[lane] : -1;                           // lanes 0..7: the query of slot `lane` (flush of the survivors)
     uint16_t* osum = nullptr;                                                // SUMS: this lane's (query, slot) segment
     if (SUMS) {
         const int64_t ob = j < QG ? p.grp_out[(int64_t)grp * QG + j] : -1;
@@ -196,11 +197,12 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
         // the table bytes are u - 128 (signed): the MFMA's sums are sum_u - 128 * 64
         T = !(thr == thr) || thr <= -1.0e9f ? -(1 << 30) : (thr >= 1.0e9f ? 0x7fffffff : (int)floorf(thr) - 128 * 64);
     }
-#if GNNLM_IVF8_EXP
+#if GNNLM_IVF8_EXP & 32
+    if (p.cap > 0) T = 0x7fffffff;                   // nothing survives, but the compiler cannot know: every instruction stays
+#elif GNNLM_IVF8_EXP
     T = 0x7fffffff;                                  // ablation builds time the main loop: nothing survives
 #endif
-    if (tid < 16) scnt[tid] = 0;
-    __syncthreads();
+    __syncthreads();                                                       // the tables are in place
 
     // ---- look-up constants of the lane: slot byte offsets of look-ups 2 s / 2 s + 1 and the table half in byte 2
     uint32_t tc[8];
@@ -245,30 +247,73 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
             A[s] = v4i{(int)x0.x, (int)x0.y, (int)x1.x, (int)x1.y};
         }
     };
-    // survivors of one tile (entered when some lane of the wave has one): ONE LDS atomic per lane
-    auto survivors = [&](const v4i& acc, int u) {
-        const int r0 = 16 * u + 4 * g - row_shift;
-        bool sv[4];
-        int cnt = 0;
+    // Survivors of one tile.  A wave stages its survivors in its OWN LDS region, {row - lo, query slot} packed in a dword, at
+    // positions it computes itself: a scalar count of what it has staged so far + scalar popcounts of the compare masks + the
+    // lane's rank inside its mask (v_mbcnt).  No LDS atomic, nothing to wait for: the look-ups of the next tile that are in
+    // flight stay in flight.  A full region (and the region at the end of the task) is flushed by the wave alone: one global
+    // atomic per query for the base, positions by ballot ranks again.
+    int wcnt = 0;                                                            // (scalar) entries staged by this wave
+    uint32_t ent[WAVE_CAP / 64];                                             // the staged entries while they are written out
+    // entries of the region per query slot: lane s (0..7) gets the total of slot s
+    auto slot_totals = [&]() __attribute__((always_inline)) -> int {
+        const int n = wcnt;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sv[r] = acc[r] >= T && (unsigned)(r0 + r) < (unsigned)len;       // rows of the neighbouring lists in the edge tiles drop out here
-            cnt += sv[r];
+        for (int x = 0; x < WAVE_CAP / 64; ++x) ent[x] = (lane + 64 * x < n) ? wbuf[lane + 64 * x] : 0xffffffffu;
+        int mytot = 0;
+#pragma unroll
+        for (int sl = 0; sl < QG; ++sl) {
+            int t = 0;
+#pragma unroll
+            for (int x = 0; x < WAVE_CAP / 64; ++x)
+                if (64 * x < n) t += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ent[x] != 0xffffffffu && (int)(ent[x] & 7u) == sl));
+            if (lane == sl) mytot = t;
         }
-        if (cnt) {
-            int pos = atomicAdd(&scnt[j], cnt);
+        return mytot;
+    };
+    // the region's entries -> the queries' lists; basev: lane s holds the first position of slot s
+    auto write_entries = [&](int basev) __attribute__((always_inline)) {
+        const int n = wcnt;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (!sv[r]) continue;
-                if (pos < STAGE_CAP) sbuf[j * STAGE_CAP + pos] = (uint32_t)(r0 + r);
-                else {                                                       // staging full: straight to the query's list
-                    const int gp = atomicAdd(&p.surv_cnt[qj], 1);
-                    if (gp < p.cap) surv[(int64_t)qj * p.cap + gp] = uint2{(uint32_t)(lo + r0 + r), (uint32_t)list};
+        for (int sl = 0; sl < QG; ++sl) {
+            const int base = __builtin_amdgcn_readlane(basev, sl), qsl = __builtin_amdgcn_readlane(qs_lane, sl);
+            if (qsl < 0) continue;
+            int run = 0;
+#pragma unroll
+            for (int x = 0; x < WAVE_CAP / 64; ++x) {
+                if (64 * x >= n) continue;
+                const bool mine = ent[x] != 0xffffffffu && (int)(ent[x] & 7u) == sl;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+                if (m == 0ull) continue;
+                if (mine) {
+                    const int64_t at = (int64_t)base + run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (at < p.cap) surv[(int64_t)qsl * p.cap + at] = uint2{(uint32_t)(lo + (ent[x] >> 3)), (uint32_t)list};
                 }
-                ++pos;
+                run += __builtin_popcountll(m);
             }
         }
+        wcnt = 0;
     };
+    // a full region in the middle of a task (the best lists of a query hold thousands of its survivors): the wave flushes alone,
+    // one global atomic per query slot
+    auto flush_wave = [&]() __attribute__((always_inline)) {
+        if (wcnt == 0) return;
+        const int mytot = slot_totals();
+        int basev = 0;
+        if (lane < QG && mytot > 0 && qs_lane >= 0) basev = atomicAdd(&p.surv_cnt[(int64_t)qs_lane * SURV_CNT_STRIDE], mytot);
+        write_entries(basev);
+    };
+    auto append = [&](uint64_t m, bool mine, int local_row) {                // m: the wave's mask, mine: this lane's bit
+        if (m == 0ull) return;
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#if !(GNNLM_IVF8_EXP & 64)
+        if (mine) wbuf[wcnt + rank] = (uint32_t)local_row << 3 | (uint32_t)(j & 7);
+#endif
+        wcnt += __builtin_popcountll(m);
+#if GNNLM_IVF8_EXP & 128
+        wcnt = 0;
+#endif
+    };
+    const int g4 = 4 * g;
     // Software pipeline, one tile per step: the 8 MFMAs of tile i are issued interleaved with the 16 look-ups of tile i + 1
     // (address + read pairs between the matrix instructions), the code bytes of tile i + 3 are requested at the top of the
     // step.  Look-up results alternate between two register sets, code bytes rotate through three: the loop is unrolled six
@@ -313,8 +358,26 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
                 *reinterpret_cast<u32x2*>(osum + 16 * u + 4 * g) = u32x2{(uint32_t)b[0] | (uint32_t)b[1] << 16, (uint32_t)b[2] | (uint32_t)b[3] << 16};
             }
         } else {
-            const int mx = max(max(acc[0], acc[1]), max(acc[2], acc[3]));
-            if (__builtin_amdgcn_ballot_w64(mx >= T) != 0ull) survivors(acc, u);
+            // four compares straight into scalar masks; a tile with survivors (about every second one) appends them mask by mask.
+            // The two edge tiles of the list share rows with the neighbouring lists: they take the same steps with the range test
+            const int rb = 16 * u - row_shift + g4;                          // local row of the lane's first key
+            if (wcnt + 128 > WAVE_CAP) flush_wave();                         // a tile adds at most 4 x 32 entries (8 query columns x 4 lane groups)
+            if (u == 0 || u == nt - 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool sr = acc[r] >= T && (unsigned)(rb + r) < (unsigned)len;
+                    append(__builtin_amdgcn_ballot_w64(sr), sr, rb + r);
+                }
+            } else {
+                const uint64_t m0 = __builtin_amdgcn_ballot_w64(acc[0] >= T), m1 = __builtin_amdgcn_ballot_w64(acc[1] >= T),
+                               m2 = __builtin_amdgcn_ballot_w64(acc[2] >= T), m3 = __builtin_amdgcn_ballot_w64(acc[3] >= T);
+                if ((m0 | m1 | m2 | m3) != 0ull) {
+                    append(m0, acc[0] >= T, rb + 0);
+                    append(m1, acc[1] >= T, rb + 1);
+                    append(m2, acc[2] >= T, rb + 2);
+                    append(m3, acc[3] >= T, rb + 3);
+                }
+            }
         }
     };
     {
@@ -338,18 +401,20 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
         }
     }
     if (SUMS) return;
+    // ---- end of the task: the 16 waves' regions -> the queries' lists with ONE global atomic per query slot for the whole
+    // workgroup (the counters are contended: 30 lists x their groups add to every query's): per-wave slot totals meet in LDS
+    int* wtot = reinterpret_cast<int*>(smem + TAB_BYTES);                     // [16 waves][8 slots] totals, then first positions
+    const int mytot = slot_totals();
+    if (lane < QG) wtot[wave * QG + lane] = mytot;
     __syncthreads();
     if (tid < QG) {
-        const int n = min(scnt[tid], STAGE_CAP), qt = gq[tid];
-        scnt[8 + tid] = (n > 0 && qt >= 0) ? atomicAdd(&p.surv_cnt[qt], n) : 0;
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += wtot[w * QG + tid];
+        int at = (tot > 0 && qs_lane >= 0) ? atomicAdd(&p.surv_cnt[(int64_t)qs_lane * SURV_CNT_STRIDE], tot) : 0;
+        for (int w = 0; w < 16; ++w) { const int t = wtot[w * QG + tid]; wtot[w * QG + tid] = at; at += t; }
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < QG; ++u) {
-        const int n = min(scnt[u], STAGE_CAP), base = scnt[8 + u];
-        for (int e = tid; e < n; e += 1024)
-            if (base + e < p.cap) surv[(int64_t)qs[u] * p.cap + base + e] = uint2{(uint32_t)(lo + sbuf[u * STAGE_CAP + e]), (uint32_t)list};
-    }
+    write_entries(lane < QG ? wtot[wave * QG + lane] : 0);
 }
 
 // Threshold from the integer sums of a query's D dense lists (written by the SUMS pass): a LOWER bound of its k-th best exact
@@ -439,7 +504,7 @@ __global__ __launch_bounds__(1024) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore
     uint32_t* cdw = reinterpret_cast<uint32_t*>(rtab + M * 256);            // dword k of thread t at [k][t]: bank = t mod 32 for stores and byte reads alike
     const int tid = threadIdx.x;
     const int64_t q = blockIdx.x;
-    const int n = min(p.surv_cnt[q], p.cap);
+    const int n = min(p.surv_cnt[q * SURV_CNT_STRIDE], p.cap);
     if (tid == 0) ccnt = 0;
     const uint2* surv = reinterpret_cast<const uint2*>(p.surv) + q * p.cap;
     // the first survivor's code row is requested before the table arrives

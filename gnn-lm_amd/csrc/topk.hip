@@ -12,6 +12,9 @@
 
 #include "kernels.h"
 
+#ifndef GNNLM_TOPK_PRESEL
+#define GNNLM_TOPK_PRESEL 2      // counting pre-pass from this many times KP columns on (first chunk)
+#endif
 namespace gnnlm {
 namespace {
 
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(TopkParams p) {
     __shared__ int hist[NB];
     __shared__ int rng[2];                           // order-preserving integer images of the sample's min / max
     __shared__ int bstar_s;
-    const bool presel = p.init && ncols >= 8 * KP;
+    const bool presel = p.init && ncols >= GNNLM_TOPK_PRESEL * KP;
     float b_lo = 0.f, b_scale = 0.f;
     int bstar = 0;
     auto value_of = [&](int c, float& v, int64_t& cid) {

@@ -351,12 +351,13 @@ class IVFPQIndex:
         t.list_off, t.qmeta, t.n, t.k, t.tau = self.list_off.data_ptr(), qmeta.data_ptr(), nq, k, tau.data_ptr()
         _lib.call_desc("gnnlm_ivfpq_tau", t)
         surv = torch.empty(nq, cap, 2, device=dev, dtype=torch.int32)
-        sc = torch.zeros(nq, device=dev, dtype=torch.int32)
-        self._scan8(qlut, qmeta, cs, self._groups(pi), tau=tau, surv=(surv, sc))
+        sc16 = torch.zeros(nq, 16, device=dev, dtype=torch.int32)              # one 64-byte line per counter (column 0)
+        self._scan8(qlut, qmeta, cs, self._groups(pi), tau=tau, surv=(surv, sc16))
+        sc = sc16[:, 0]
         r = _lib.gnnlm_ivfpq_rescore_t()
         r.codes, r.payload, r.M = self.list_codes.data_ptr(), self.payload.data_ptr(), self.M
         r.lut, r.ld_lut, r.coarse, r.ld_coarse, r.tau = lut.data_ptr(), lut.stride(0), cs.data_ptr(), cs.stride(0), tau.data_ptr()
-        r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), sc.data_ptr(), cap, nq
+        r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), sc16.data_ptr(), cap, nq
         r.cand_val, r.cand_id, r.cand_cnt, r.cand_cap = cv.data_ptr(), ci.data_ptr(), cc.data_ptr(), cap
         _lib.call_desc("gnnlm_ivfpq_rescore", r)
         self.stats["survivors"] += sc.sum()

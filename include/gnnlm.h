@@ -330,7 +330,8 @@ typedef struct gnnlm_ivfpq_scan8 {
     const float* tau;                                 /* [n] */
     const int32_t* grp_list;  const int32_t* grp_q;   /* [max_groups] list (-1: none), [max_groups, 8] queries (-1: none), sorted by list */
     const int32_t* n_groups;  int32_t max_groups;     /* DEVICE count of groups in use (no host round trip), capacity of the arrays */
-    uint32_t* surv;  int32_t* surv_cnt;  int32_t cap; /* [n, cap, 2] {row, list}; surv_cnt[q] counts ALL survivors (overflow check) */
+    uint32_t* surv;  int32_t* surv_cnt;  int32_t cap; /* [n, cap, 2] {row, list}; surv_cnt [n, 16] int32 (one 64-byte line per query: the
+                                                       * counters are hammered by atomics), column 0 counts ALL survivors (overflow check) */
     /* threshold pass (out_sum != NULL; tau / surv unused): every key's integer sum sum_m u (0 .. 255 * 64) is written as uint16 to
      * out_sum[grp_out[group * 8 + j] + (list_off[list] & 15) + position in the list] for query j of the group (grp_out < 0:
      * skipped): a segment is indexed by the position in the list's 16-row TILE range (aligned 8-byte stores); it must hold the

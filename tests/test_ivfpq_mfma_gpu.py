@@ -94,7 +94,7 @@ def _run_filter(index, q, tau, p_lo, dev, cap):
     qlut, qmeta = ops.ivfpq_quantize_lut(lut, 64)
     grp_list, grp_q, n_groups, G = index._groups(pi[:, p_lo:])
     surv = torch.zeros(nq, cap, 2, device=dev, dtype=torch.int32)
-    sc = torch.zeros(nq, device=dev, dtype=torch.int32)
+    sc = torch.zeros(nq, 16, device=dev, dtype=torch.int32)                  # one 64-byte line per counter
     d = _lib.gnnlm_ivfpq_scan8_t()
     d.tiles, d.list_off, d.M = index.tiles.data_ptr(), index.list_off.data_ptr(), 64
     d.qlut, d.qmeta, d.coarse, d.ld_coarse, d.tau = qlut.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0), tau.data_ptr()
@@ -102,7 +102,7 @@ def _run_filter(index, q, tau, p_lo, dev, cap):
     d.surv, d.surv_cnt, d.cap = surv.data_ptr(), sc.data_ptr(), cap
     _lib.call_desc("gnnlm_ivfpq_scan8", d)
     torch.cuda.synchronize()
-    return cs, pi, lut, qmeta, surv.cpu().numpy(), sc.cpu().numpy(), (grp_list.cpu().numpy(), grp_q.cpu().numpy(), int(n_groups.item()))
+    return cs, pi, lut, qmeta, surv.cpu().numpy(), sc[:, 0].cpu().numpy(), (grp_list.cpu().numpy(), grp_q.cpu().numpy(), int(n_groups.item()))
 
 
 @pytest.fixture(scope="module")

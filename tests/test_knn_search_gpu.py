@@ -299,3 +299,33 @@ def test_knn_model_reads_faiss_index_file(dev, tmp_path):
         IVFPQIndex.from_faiss_file(f, device=dev)
     with pytest.raises(ValueError):
         KNNModel(f, str(dd), k=64, probe=6, no_load_keys=True, metric_type="do_not_recomp_ip", device=dev)
+
+
+@pytest.mark.parametrize("k", [64, 1024, 2000])
+@pytest.mark.parametrize("largest", [True, False])
+def test_topk_select_from_ragged_candidate_lists(dev, k, largest):
+    """init + per-row ids + row_ncols (what the exact re-score of an IVF-PQ search hands over: one ragged candidate list per
+    query, a few times k long -- the counting pre-pass applies from 2 KP columns on): exact ids with ties by ascending id,
+    empty and short rows, negative (skipped) ids."""
+    from gnnlm_amd import ops
+    rs = np.random.RandomState(3 * k + largest)
+    n, W = 11, 20000
+    scores = rs.randn(n, W).astype(np.float32)
+    scores[:, ::30] = scores[:, 1::30]                                    # exact ties
+    scores[1] = np.round(scores[1] * 3) / 3                               # thousands of ties
+    ids = np.stack([rs.permutation(10_000_000_000 + np.arange(W)) for _ in range(n)]).astype(np.int64)
+    ids[2, ::9] = -1                                                      # skipped entries
+    ncols = np.array([W, W, W, 0, 1, k - 1, k, k + 1, 4096, 8192, 8193], dtype=np.int32)
+    args = dict(largest=largest, init=True, row_ncols=torch.from_numpy(ncols).to(dev), ids=torch.from_numpy(ids).to(dev))
+    s_dev = torch.from_numpy(scores).to(dev)
+    bv = torch.empty(n, k, device=dev)
+    bi = torch.empty(n, k, device=dev, dtype=torch.int64)
+    ops.topk_merge(s_dev, bv, bi, **args)
+    bv, bi = bv.cpu().numpy(), bi.cpu().numpy()
+    for r in range(n):
+        ok = (np.arange(W) < ncols[r]) & (ids[r] >= 0)
+        v, i = ref_topk(scores[r][ok], ids[r][ok], k, largest)
+        m = min(k, int(ok.sum()))
+        assert np.array_equal(bi[r, :m], i[:m]), r
+        np.testing.assert_array_equal(bv[r, :m], v[:m])
+        assert (bi[r, m:] == -1).all()
