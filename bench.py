@@ -190,7 +190,7 @@ def cpu_baseline(args, cpu_model):
         asm = cpu_model["asm"]
         all_cores = torch.get_num_threads()
 
-        def run(n_tok, cores, cold):
+        def run(n_tok, cores, cold, L=L, sd=sd):
             torch.set_num_threads(cores)
             ms = {}
             clock = lambda: time.perf_counter()
@@ -233,13 +233,16 @@ def cpu_baseline(args, cpu_model):
         full = run(Tc, all_cores, cold=True)
         warm = run(min(Tc, 64), all_cores, cold=False)
         one = run(min(Tc, 16), 1, cold=False)
+        # the shipped 3-layer recipe (hgt_lm_wiki103_reproduce.sh:56) on the same cores: the CPU pair of `recipe_L3`
+        sd3 = {k_: v.float() for k_, v in ohgt.init_hgt_weights(3, d, cpu_model["H"], seed=7).items()}
+        l3 = run(min(Tc, 64), all_cores, cold=False, L=3, sd=sd3) if L == 1 else None
         torch.set_num_threads(all_cores)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return {"value": round(full["tokens_per_s"], 2), "unit": "tokens/s", "cores": all_cores, "kind": "port",
             "sample": f"{Tc} tokens of one block, k_g={kg}, l=r=2, L={L}, kNN k={k}, d={d}, {n_host}-row tables as np.memmap "
                       f"files on local disk (cold page cache), reference-style expansion loop, torch-CPU fp32, {full['seconds']} s",
-            "all_cores": full, "all_cores_warm": warm, "one_core": one}
+            "all_cores": full, "all_cores_warm": warm, "one_core": one, "recipe_L3_all_cores": l3}
 
 
 def verify_block(eng, batch, args, cpu_model, n_tok):
@@ -420,13 +423,18 @@ def search_check(idx, q, k, n_check):
     rows = torch.repeat_interleave(idx.list_off[U] - off_sub[:-1], lens) + torch.arange(int(off_sub[-1]), device=q.device)
     arrs = [idx.R.cpu().numpy(), idx.coarse[U].cpu().numpy(), idx.pq.cpu().numpy(), off_sub.cpu().numpy(),
             idx.list_ids[rows].cpu().numpy(), idx.list_codes[rows].cpu().numpy()]
+    t1 = time.perf_counter()
     v_ref, i_ref = oivf.search(qs.cpu().numpy(), *arrs, k=k, nprobe=idx.nprobe)
+    t_oracle = time.perf_counter() - t1
     v, i = v.cpu().numpy(), i.cpu().numpy()
     same = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(i, i_ref)]))
     dv = float(np.abs(v - v_ref).max())
     ok = same >= 0.998 and dv <= 2e-5
     out = {"queries": int(qs.shape[0]), "lists_on_host": int(U.numel()), "id_set_overlap": round(same, 5), "max_abs_dscore": dv,
-           "tolerance": {"id_set_overlap": 0.998, "score": 2e-5}, "oracle_seconds": round(time.perf_counter() - t0, 1), "ok": ok}
+           "tolerance": {"id_set_overlap": 0.998, "score": 2e-5}, "oracle_seconds": round(time.perf_counter() - t0, 1),
+           "cpu_port_queries_per_s": round(qs.shape[0] / t_oracle, 2),
+           "cpu_port_note": "oracle/ivfpq.py: numpy float64 restatement of IVFADC on one core over the same lists (NOT faiss, which the reference calls and this image lacks)",
+           "ok": ok}
     if not ok:
         raise SystemExit(f"bench.py: the on-device kNN search disagrees with the oracle: {out}")
     return out

@@ -37,6 +37,8 @@ constexpr int QG = 8;                                   // queries per workgroup
 constexpr int TAB_BYTES = 2 * 256 * 32 * QG;            // [half][code][slot][query]: 128 KiB
 constexpr int WAVE_CAP = 320;                           // survivors a wave stages per task (all 8 queries of its group)
 constexpr int SCAN_LDS = TAB_BYTES + 512 + 16 * WAVE_CAP * 4;
+constexpr int HIST_BINS = 1024, HIST_SHIFT = 4;         // threshold pass: sum_u (0 .. 16320) >> 4
+constexpr int SUMS_LDS = TAB_BYTES + QG * HIST_BINS * 4;  // = 160 KiB: the whole LDS of a CU
 constexpr int SURV_CNT_STRIDE = 16;                     // survivor counters one per 64-byte line: they are hammered by atomics
 constexpr int QLUT_BYTES = 64 * 256;                    // one query's quantised table
 
@@ -130,8 +132,9 @@ __global__ __launch_bounds__(256) void quantize_lut_kernel(const float* __restri
 #define GNNLM_IVF8_EXP 0        // ablation builds (no survivors): 1 no code loads, 2 no table fill, 4 no look-ups, 8 no MFMAs, 16 nothing else
 #endif
 
-// SUMS = false: the filter (survivors of the integer threshold).  SUMS = true: the threshold pass -- every key's integer sum
-// (+ 128 * 64, i.e. sum_u) is written as uint16 to the (query, dense slot) segment grp_out names; nothing is compared.
+// SUMS = false: the filter (survivors of the integer threshold).  SUMS = true: the threshold pass -- the integer sums sum_u of a
+// list's keys are HISTOGRAMMED per query in LDS (bins of 16, atomics without return) and the (query, list) histogram is written
+// to the segment grp_out names; nothing is compared, no per-key output.
 template <bool SUMS>
 __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // tables at LDS address 0 (look-up addresses are absolute)
@@ -182,10 +185,11 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     int T = 0x7fffffff;
     const int qj = j < QG ? gq[j] : -1;                                   // (a register array may not be indexed by the lane)
     const int qs_lane = lane < QG ? gq[lane] : -1;                           // lanes 0..7: the query of slot `lane` (flush of the survivors)
-    uint16_t* osum = nullptr;                                                // SUMS: this lane's (query, slot) segment
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + TAB_BYTES);          // SUMS: [8 queries][HIST_BINS] counters
+    uint32_t* hist_j = nullptr;                                              // this lane's query (lanes j < 8 of a live query)
     if (SUMS) {
-        const int64_t ob = j < QG ? p.grp_out[(int64_t)grp * QG + j] : -1;
-        if (qj >= 0 && ob >= 0) osum = p.out_sum + ob;
+        for (int e = tid; e < QG * HIST_BINS; e += 1024) hist[e] = 0u;
+        if (qj >= 0 && p.grp_out[(int64_t)grp * QG + j] >= 0) hist_j = hist + j * HIST_BINS;
     }
     if (!SUMS && qj >= 0) {
         const int64_t q = qj;
@@ -350,12 +354,14 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
 #endif
 #endif
         if (SUMS) {
-            // the lane's four keys (rows 4 g .. 4 g + 3 of the tile) of query j as one aligned 8-byte store; the segment is indexed
-            // by the position in the TILE range of the list (first row of the list at row_shift): rows of the neighbouring lists
-            // in the two edge tiles are written too and skipped by the reader (ivfpq_tau_kernel)
-            if (osum) {
-                const v4i b = acc + 128 * 64;
-                *reinterpret_cast<u32x2*>(osum + 16 * u + 4 * g) = u32x2{(uint32_t)b[0] | (uint32_t)b[1] << 16, (uint32_t)b[2] | (uint32_t)b[3] << 16};
+            // the lane's four keys (rows 4 g .. 4 g + 3 of the tile) of query j -> four counters of the query's histogram (LDS
+            // atomics without return: nothing waits for them); the two edge tiles count the list's own rows only
+            if (hist_j) {
+                const int r0 = 16 * u + 4 * g - row_shift;
+                const bool edge = u == 0 || u == nt - 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (!edge || (unsigned)(r0 + r) < (unsigned)len) atomicAdd(&hist_j[(acc[r] + 128 * 64) >> HIST_SHIFT], 1u);
             }
         } else {
             // four compares straight into scalar masks; a tile with survivors (about every second one) appends them mask by mask.
@@ -400,7 +406,16 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
             step(XB, XA, C0, C2, u); u += 16;
         }
     }
-    if (SUMS) return;
+    if (SUMS) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < QG; ++u) {
+            const int64_t ob = p.grp_out[(int64_t)grp * QG + u];
+            if (qs[u] < 0 || ob < 0) continue;
+            for (int e = tid; e < HIST_BINS; e += 1024) p.out_hist[ob + e] = hist[u * HIST_BINS + e];
+        }
+        return;
+    }
     // ---- end of the task: the 16 waves' regions -> the queries' lists with ONE global atomic per query slot for the whole
     // workgroup (the counters are contended: 30 lists x their groups add to every query's): per-wave slot totals meet in LDS
     int* wtot = reinterpret_cast<int*>(smem + TAB_BYTES);                     // [16 waves][8 slots] totals, then first positions
@@ -417,18 +432,17 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     write_entries(lane < QG ? wtot[wave * QG + lane] : 0);
 }
 
-// Threshold from the integer sums of a query's D dense lists (written by the SUMS pass): a LOWER bound of its k-th best exact
-// score.  score(x) >= bias_l + sum_lo + sum_u(x) delta' (delta' a hair below delta), so with v(x) = sum_u(x) + floor((bias_l -
-// bias_min) / delta) the k-th largest v gives tau = bias_min + sum_lo + v_k delta' - eps: at least k keys score >= tau.  The k-th
-// largest comes from a histogram of v >> 2 in LDS (the lower bin edge is taken: a bound, not a selection).
-constexpr int TAU_BINS = 16384;
+// Threshold from the histograms of a query's D dense lists (written by the SUMS pass): a LOWER bound of its k-th best exact
+// score.  score(x) >= bias_l + sum_lo + sum_u(x) delta' (delta' a hair below delta), so with v(x) = sum_u(x) + off_l,
+// off_l <= (bias_l - bias_min) / delta, the k-th largest v gives tau = bias_min + sum_lo + v_k delta' - eps: at least k keys score
+// >= tau.  Bins of 16: a key of bin b of list l counts in the combined bin b + (off_l >> 4) -- its lower edge bounds v from below.
 __global__ __launch_bounds__(1024) void ivfpq_tau_kernel(gnnlm_ivfpq_tau_t p) {
-    __shared__ int hist[TAU_BINS];
+    constexpr int CB = 2 * HIST_BINS;                                        // combined bins (list offsets up to HIST_BINS bins)
+    __shared__ int comb[CB];
     __shared__ int part[1024];
     __shared__ int bstar_s;
     const int tid = threadIdx.x;
     const int64_t q = blockIdx.x;
-    for (int e = tid; e < TAU_BINS; e += 1024) hist[e] = 0;
     const float delta = p.qmeta[q * 4], sum_lo = p.qmeta[q * 4 + 1], amax = p.qmeta[q * 4 + 2];
     float bmin = INFINITY, bmax = -INFINITY;
     for (int d = 0; d < p.D; ++d) {
@@ -437,36 +451,25 @@ __global__ __launch_bounds__(1024) void ivfpq_tau_kernel(gnnlm_ivfpq_tau_t p) {
         bmin = fminf(bmin, b);
         bmax = fmaxf(bmax, b);
     }
-    __syncthreads();
+    int c0 = 0, c1 = 0;                                                      // combined bins tid and tid + 1024
     for (int d = 0; d < p.D; ++d) {
-        const int64_t l = p.probe_list[q * p.ld_probe + d];
-        if (l < 0) continue;
-        const int64_t lo = p.list_off[l];
-        const int first = (int)(lo & 15), last = first + (int)min(p.list_off[l + 1] - lo, (int64_t)(p.seg - 16));   // positions [first, last)
+        if (p.probe_list[q * p.ld_probe + d] < 0) continue;
         // floor of the bias difference in units of delta, a little low on purpose (a smaller offset only lowers the bound)
         const float offf = (p.probe_bias[q * p.ld_probe + d] - bmin) / delta * 0.9999f - 1.f;
-        const int off = (int)fminf(fmaxf(offf, 0.f), 40000.f);
-        const uint4* src = reinterpret_cast<const uint4*>(p.sums + (q * p.D + d) * p.seg);      // 8 sums per load
-        for (int e8 = tid; e8 * 8 < last; e8 += 1024) {
-            const uint4 v = src[e8];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const int pos = e8 * 8 + x;
-                const int val = (int)((w[x >> 1] >> (16 * (x & 1))) & 0xffffu);
-                if (pos >= first && pos < last) atomicAdd(&hist[min(TAU_BINS - 1, (val + off) >> 2)], 1);
-            }
-        }
+        const int sh = (int)fminf(fmaxf(offf, 0.f), (float)(HIST_BINS << HIST_SHIFT)) >> HIST_SHIFT;
+        const uint32_t* h = p.hist + (q * p.D + d) * HIST_BINS;
+        const int b0 = tid - sh, b1 = tid + 1024 - sh;
+        if (b0 >= 0 && b0 < HIST_BINS) c0 += (int)h[b0];
+        if (b1 >= 0 && b1 < HIST_BINS) c1 += (int)h[b1];
     }
-    __syncthreads();
-    // b*: the highest bin whose suffix count reaches k.  Thread t owns bins [16 t, 16 t + 16); suffix sums over the threads by
-    // a doubling scan in LDS, then the one thread whose range holds the crossing walks its 16 bins
-    int mine = 0;
-    constexpr int PER = TAU_BINS / 1024;
-#pragma unroll
-    for (int e = 0; e < PER; ++e) mine += hist[tid * PER + e];
-    part[tid] = mine;
+    comb[tid] = c0;
+    comb[tid + 1024] = c1;
     if (tid == 0) bstar_s = -1;
+    __syncthreads();
+    // b*: the highest combined bin whose suffix count reaches k.  Thread t owns bins [2 t, 2 t + 2); suffix sums over the threads
+    // by a doubling scan in LDS, then the one thread whose pair holds the crossing picks the bin
+    const int h0 = comb[2 * tid], h1 = comb[2 * tid + 1], mine = h0 + h1;
+    part[tid] = mine;
     __syncthreads();
     int suf = mine;                                                          // sum of part[t .. 1023]
     for (int step = 1; step < 1024; step <<= 1) {
@@ -476,17 +479,13 @@ __global__ __launch_bounds__(1024) void ivfpq_tau_kernel(gnnlm_ivfpq_tau_t p) {
         part[tid] = suf;
         __syncthreads();
     }
-    if (suf >= p.k && suf - mine < p.k) {                                    // exactly one thread (suffix sums decrease with t)
-        int acc = suf - mine, b = tid * PER + PER - 1;
-        for (; b >= tid * PER; --b) { acc += hist[b]; if (acc >= p.k) break; }
-        bstar_s = b;
-    }
+    if (suf >= p.k && suf - mine < p.k) bstar_s = (suf - mine + h1 >= p.k) ? 2 * tid + 1 : 2 * tid;   // exactly one thread
     __syncthreads();
     if (tid == 0) {
         float tau = -INFINITY;
         if (bstar_s >= 0) {
             const float eps = 66.f * 2.3841858e-7f * (64.f * amax + fmaxf(fabsf(bmin), fabsf(bmax)));
-            tau = (bmin + sum_lo) + (float)(4 * bstar_s) * delta * (1.f - 6.1035156e-5f) - eps;       // delta (1 - 2^-14) < 1 / inv
+            tau = (bmin + sum_lo) + (float)(bstar_s << HIST_SHIFT) * delta * (1.f - 6.1035156e-5f) - eps;   // delta (1 - 2^-14) < 1 / inv
             tau -= fabsf(tau) * 2.3841858e-7f + 1e-30f;                       // strictly below the k keys' scores: candidates are score > tau
         }
         p.tau[q] = tau;
@@ -597,26 +596,25 @@ int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream) {
     GNNLM_REQUIRE(d.max_groups >= 0, "ivfpq_scan8: bad group count");
     if (d.max_groups == 0) return OK;
     GNNLM_REQUIRE(d.tiles && d.list_off && d.qlut && d.qmeta && d.coarse && d.grp_list && d.grp_q && d.n_groups &&
-                      (d.out_sum || (d.tau && d.surv && d.surv_cnt && d.cap > 0)),
+                      (d.out_hist || (d.tau && d.surv && d.surv_cnt && d.cap > 0)),
                   "ivfpq_scan8: null operand");
     GNNLM_REQUIRE(d.M == 64 && (uintptr_t)d.tiles % 16 == 0 && (uintptr_t)d.qlut % 4 == 0, "ivfpq_scan8: need M = 64, aligned images");
-    GNNLM_REQUIRE(!d.out_sum || d.grp_out, "ivfpq_scan8: out_sum needs grp_out");
+    GNNLM_REQUIRE(!d.out_hist || d.grp_out, "ivfpq_scan8: out_hist needs grp_out");
     GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<false>, SCAN_LDS);
-    GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<true>, SCAN_LDS);
-    ProfScope prof(d.out_sum ? K_IVF8S : K_IVF8, stream, 0.0, 0.0);   // work figures are device-side (list lengths): bench.py computes them
+    GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<true>, SUMS_LDS);
+    ProfScope prof(d.out_hist ? K_IVF8S : K_IVF8, stream, 0.0, 0.0);   // work figures are device-side (list lengths): bench.py computes them
     const int64_t grid = 8 * cdiv((int64_t)d.max_groups, (int64_t)8);
-    if (d.out_sum) hipLaunchKernelGGL(ivfpq_scan8_kernel<true>, dim3((unsigned)grid), dim3(1024), SCAN_LDS, stream, d);
+    if (d.out_hist) hipLaunchKernelGGL(ivfpq_scan8_kernel<true>, dim3((unsigned)grid), dim3(1024), SUMS_LDS, stream, d);
     else hipLaunchKernelGGL(ivfpq_scan8_kernel<false>, dim3((unsigned)grid), dim3(1024), SCAN_LDS, stream, d);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }
 
 int ivfpq_tau(const gnnlm_ivfpq_tau_t& d, hipStream_t stream) {
-    GNNLM_REQUIRE(d.n >= 0 && d.n < (1ll << 31) && d.D >= 1 && d.seg > 0 && d.k > 0, "ivfpq_tau: bad shape");
+    GNNLM_REQUIRE(d.n >= 0 && d.n < (1ll << 31) && d.D >= 1 && d.k > 0, "ivfpq_tau: bad shape");
     if (d.n == 0) return OK;
-    GNNLM_REQUIRE(d.sums && d.probe_list && d.probe_bias && d.list_off && d.qmeta && d.tau && d.ld_probe >= d.D, "ivfpq_tau: null operand");
-    GNNLM_REQUIRE(d.seg % 8 == 0 && d.seg > 32 && (uintptr_t)d.sums % 16 == 0, "ivfpq_tau: segments of a multiple of 8 entries (longest list + 32, rounded up), 16-byte aligned");
-    ProfScope prof(K_TAU, stream, 0.0, 2.0 * (double)d.n * d.D * d.seg);
+    GNNLM_REQUIRE(d.hist && d.probe_list && d.probe_bias && d.qmeta && d.tau && d.ld_probe >= d.D, "ivfpq_tau: null operand");
+    ProfScope prof(K_TAU, stream, 0.0, 4.0 * (double)d.n * d.D * HIST_BINS);
     hipLaunchKernelGGL(ivfpq_tau_kernel, dim3((unsigned)d.n), dim3(1024), 0, stream, d);
     GNNLM_LAUNCH_CHECK();
     return OK;

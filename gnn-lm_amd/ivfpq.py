@@ -268,7 +268,7 @@ class IVFPQIndex:
         if query_block is None:                                               # groups of 8 queries per list want many queries per block
             query_block = 8192 if self.tiles is not None else 1024
         # the dense round's score rows: query_block * dense * max_list floats, bounded (a skewed index has long lists)
-        qb = max(1, min(query_block, self.score_bytes // max(1, (2 if self.tiles is not None else 4) * dense * max(self.max_list, 1))))
+        qb = query_block if self.tiles is not None else max(1, min(query_block, self.score_bytes // max(1, 4 * dense * max(self.max_list, 1))))
         over = None
         self.stats = {"pairs": torch.zeros((), device=dev, dtype=torch.float64), "survivors": torch.zeros((), device=dev, dtype=torch.float64),
                       "candidates": torch.zeros((), device=dev, dtype=torch.float64), "queries": n, "M": self.M}
@@ -322,33 +322,32 @@ class IVFPQIndex:
         ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=False, row_ncols=cc.clamp(max=cap))
         return cc
 
-    def _scan8(self, qlut, qmeta, cs, groups, tau=None, surv=None, sums=None):
+    def _scan8(self, qlut, qmeta, cs, groups, tau=None, surv=None, hist=None):
         d = _lib.gnnlm_ivfpq_scan8_t()
         d.tiles, d.list_off, d.M = self.tiles.data_ptr(), self.list_off.data_ptr(), self.M
         d.qlut, d.qmeta, d.coarse, d.ld_coarse = qlut.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0)
         d.grp_list, d.grp_q, d.n_groups, d.max_groups = groups[0].data_ptr(), groups[1].data_ptr(), groups[2].data_ptr(), groups[3]
-        if sums is not None:
-            d.out_sum, d.grp_out = sums.data_ptr(), groups[4].data_ptr()
+        if hist is not None:
+            d.out_hist, d.grp_out = hist.data_ptr(), groups[4].data_ptr()
         else:
             d.tau, d.surv, d.surv_cnt, d.cap = tau.data_ptr(), surv[0].data_ptr(), surv[1].data_ptr(), surv[0].shape[1]
         _lib.call_desc("gnnlm_ivfpq_scan8", d)
 
     def _search_block_mfma(self, k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc):
-        """M = 64: everything on the int8 matrix cores (csrc/ivfpq_mfma.hip).  (1) threshold pass: the integer sums of the first
-        `dense` lists -> a lower bound tau of the query's k-th best score (histogram, no selection); (2) filter: every probed
+        """M = 64: everything on the int8 matrix cores (csrc/ivfpq_mfma.hip).  (1) threshold pass: histograms of the integer sums of the
+        first `dense` lists -> a lower bound tau of the query's k-th best score (no per-key output, no selection); (2) filter: every probed
         list, keys whose integer sum can reach tau; (3) exact float32 scores of the survivors, score > tau -> candidates;
         (4) one k-selection over the candidates."""
         dev = self.device
         nq, cap = pv.shape[0], cv.shape[1]
         qlut, qmeta = ops.ivfpq_quantize_lut(lut, self.M)
-        seg = (self.max_list + 32 + 7) // 8 * 8                                 # positions in a list's tile range (csrc/ivfpq_mfma.hip)
-        sums = torch.empty(nq, dense, seg, device=dev, dtype=torch.int16)       # (uint16 values)
-        self._scan8(qlut, qmeta, cs, self._groups(pi[:, :dense], seg=seg), sums=sums)
+        hist = torch.empty(nq, dense, 1024, device=dev, dtype=torch.int32)      # per (query, list): sum_u >> 4 counted on the device
+        self._scan8(qlut, qmeta, cs, self._groups(pi[:, :dense], seg=1024), hist=hist)
         tau = torch.empty(nq, device=dev, dtype=torch.float32)
         t = _lib.gnnlm_ivfpq_tau_t()
-        t.sums, t.D, t.seg = sums.data_ptr(), dense, seg
+        t.hist, t.D = hist.data_ptr(), dense
         t.probe_list, t.probe_bias, t.ld_probe = pi.data_ptr(), pv.data_ptr(), pi.stride(0)
-        t.list_off, t.qmeta, t.n, t.k, t.tau = self.list_off.data_ptr(), qmeta.data_ptr(), nq, k, tau.data_ptr()
+        t.qmeta, t.n, t.k, t.tau = qmeta.data_ptr(), nq, k, tau.data_ptr()
         _lib.call_desc("gnnlm_ivfpq_tau", t)
         surv = torch.empty(nq, cap, 2, device=dev, dtype=torch.int32)
         sc16 = torch.zeros(nq, 16, device=dev, dtype=torch.int32)              # one 64-byte line per counter (column 0)

@@ -316,8 +316,8 @@ int gnnlm_ivfpq_pack_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M,
  *   gnnlm_ivfpq_scan8          one workgroup per GROUP = up to 8 queries probing one list; a key (row of the list-ordered
  *                              index) is appended to surv[q] = {row, list} iff the integer sum of its 64 table bytes
  *                              reaches the integer image of tau[q] -- a superset of {score > tau[q]}
- *   gnnlm_ivfpq_tau            the threshold itself: a lower bound of the k-th best score from the integer sums of the first
- *                              D lists (gnnlm_ivfpq_scan8 with out_sum), replacing the float32 dense round + its k-selection
+ *   gnnlm_ivfpq_tau            the threshold itself: a lower bound of the k-th best score from histograms of the integer sums of
+ *                              the first D lists (gnnlm_ivfpq_scan8 with out_hist), replacing the float32 dense round + its k-selection
  *   gnnlm_ivfpq_rescore        exact scores of the survivors (summation order of gnnlm_ivfpq_scan's packed kernel),
  *                              score > tau[q] -> (cand_val, cand_id = payload[row]); cand_cnt[q] counts all of them
  * ---------------------------------------------------------------------------------------------- */
@@ -332,20 +332,19 @@ typedef struct gnnlm_ivfpq_scan8 {
     const int32_t* n_groups;  int32_t max_groups;     /* DEVICE count of groups in use (no host round trip), capacity of the arrays */
     uint32_t* surv;  int32_t* surv_cnt;  int32_t cap; /* [n, cap, 2] {row, list}; surv_cnt [n, 16] int32 (one 64-byte line per query: the
                                                        * counters are hammered by atomics), column 0 counts ALL survivors (overflow check) */
-    /* threshold pass (out_sum != NULL; tau / surv unused): every key's integer sum sum_m u (0 .. 255 * 64) is written as uint16 to
-     * out_sum[grp_out[group * 8 + j] + (list_off[list] & 15) + position in the list] for query j of the group (grp_out < 0:
-     * skipped): a segment is indexed by the position in the list's 16-row TILE range (aligned 8-byte stores); it must hold the
-     * longest list + 32 entries, a multiple of 8, and the offsets must be multiples of 4 */
-    uint16_t* out_sum;  const int64_t* grp_out;
+    /* threshold pass (out_hist != NULL; tau / surv unused): the integer sums sum_m u (0 .. 255 * 64) of a list's keys are
+     * histogrammed per query (1024 bins of 16) and written to out_hist[grp_out[group * 8 + j] .. + 1024) for query j of the group
+     * (grp_out < 0: skipped; every (query, list) pair belongs to exactly one group: plain stores) */
+    uint32_t* out_hist;  const int64_t* grp_out;
 } gnnlm_ivfpq_scan8_t;
 int gnnlm_ivfpq_scan8(const gnnlm_ivfpq_scan8_t* desc, void* stream);
-/* tau[q] = a lower bound of query q's k-th best score over its first D probed lists, from the threshold pass's sums
- * ([n, D, seg] uint16 in the tile-range positions described above; list d of query q = probe_list[q, d] with bias
- * probe_bias[q, d]); -inf if they hold fewer than k keys */
+/* tau[q] = a lower bound of query q's k-th best score over its first D probed lists, from the threshold pass's histograms
+ * ([n, D, 1024] uint32; list d of query q = probe_list[q, d] with bias probe_bias[q, d]): at least k keys of those lists score
+ * above it; -inf if they hold fewer than k keys */
 typedef struct gnnlm_ivfpq_tau {
-    const uint16_t* sums;  int32_t D;  int64_t seg;
+    const uint32_t* hist;  int32_t D;
     const int64_t* probe_list;  const float* probe_bias;  int32_t ld_probe;
-    const int64_t* list_off;  const float* qmeta;
+    const float* qmeta;
     int64_t n;  int32_t k;
     float* tau;
 } gnnlm_ivfpq_tau_t;

@@ -201,39 +201,33 @@ def test_threshold_pass_is_a_lower_bound(dev, small_index):
     cs64 = qr @ arr["coarse"].astype(np.float64).T
     lut64 = np.einsum("nmd,mcd->nmc", qr.reshape(nq, 64, -1), arr["pq"].astype(np.float64))
     pi_h = pi.cpu().numpy()
+    u = (qlut.cpu().numpy().astype(np.int64) ^ 0x80)                           # [nq, 2, 256, 32]: the byte tables
     for D, k in ((3, 1024), (2, 64), (1, 9000)):
-        seg = (index.max_list + 32 + 7) // 8 * 8
-        sums = torch.zeros(nq, D, seg, device=dev, dtype=torch.int16)
-        index._scan8(qlut, qmeta, cs, index._groups(pi[:, :D], seg=seg), sums=sums)
+        hist = torch.zeros(nq, D, 1024, device=dev, dtype=torch.int32)
+        index._scan8(qlut, qmeta, cs, index._groups(pi[:, :D], seg=1024), hist=hist)
         tau = torch.empty(nq, device=dev)
         t = _lib.gnnlm_ivfpq_tau_t()
-        t.sums, t.D, t.seg = sums.data_ptr(), D, seg
+        t.hist, t.D = hist.data_ptr(), D
         t.probe_list, t.probe_bias, t.ld_probe = pi.data_ptr(), pv.data_ptr(), pi.stride(0)
-        t.list_off, t.qmeta, t.n, t.k, t.tau = index.list_off.data_ptr(), qmeta.data_ptr(), nq, k, tau.data_ptr()
+        t.qmeta, t.n, t.k, t.tau = qmeta.data_ptr(), nq, k, tau.data_ptr()
         _lib.call_desc("gnnlm_ivfpq_tau", t)
-        tau_h, sums_h, dl = tau.cpu().numpy(), sums.cpu().numpy().astype(np.int64) & 0xffff, qmeta[:, 0].cpu().numpy()
+        tau_h, hist_h, dl = tau.cpu().numpy(), hist.cpu().numpy(), qmeta[:, 0].cpu().numpy()
         for r in range(nq):
-            sc, su = [], []
+            sc = []
             for d_, l in enumerate(pi_h[r, :D]):
                 lo, hi = int(arr["list_off"][l]), int(arr["list_off"][l + 1])
                 c = arr["list_codes"][lo:hi].astype(np.int64)
                 sc.append(cs64[r, l] + lut64[r][np.arange(64)[None, :], c].sum(1))
-                su.append(sums_h[r, d_, (lo & 15):(lo & 15) + hi - lo])
+                if r % 7 == 0:                                               # the histogram: sum_m u of every key of the list, exactly
+                    su = sum(u[r, m // 32, c[:, m], m % 32] for m in range(64))
+                    assert np.array_equal(hist_h[r, d_], np.bincount(su >> 4, minlength=1024)), (D, r, d_)
             sc = np.concatenate(sc)
             if len(sc) < k:
                 assert np.isneginf(tau_h[r])
                 continue
             assert (sc > tau_h[r]).sum() >= k, (D, k, r)                      # a valid threshold
             kth = np.sort(sc)[-k]
-            assert tau_h[r] > kth - 72 * dl[r] - 1e-4, (D, k, r, tau_h[r], kth, dl[r])   # and not a loose one
-        # the sums themselves: sum_m u of the key, exactly (integer arithmetic on the matrix cores)
-        u = (qlut.cpu().numpy().astype(np.int64) ^ 0x80)                       # [nq, 2, 256, 32]
-        r = 3
-        l = pi_h[r, 0]
-        lo, hi = int(arr["list_off"][l]), int(arr["list_off"][l + 1])
-        c = arr["list_codes"][lo:hi].astype(np.int64)
-        want = sum(u[r, m // 32, c[:, m], m % 32] for m in range(64))
-        assert np.array_equal(sums_h[r, 0, (lo & 15):(lo & 15) + hi - lo], want)
+            assert tau_h[r] > kth - 112 * dl[r] - 1e-4, (D, k, r, tau_h[r], kth, dl[r])   # and not a loose one (64 + bins of 16 twice + slack)
 
 
 def _assert_same(va, ia, vb, ib, what=None):
