@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void quantize_lut_kernel(const float* __restri
 }
 
 #define GNNLM_PERM(hi_, lo_, sel_) __builtin_amdgcn_perm((hi_), (lo_), (sel_))
+#ifndef GNNLM_IVF8_NW
+#define GNNLM_IVF8_NW 16         // waves per workgroup of the scan (A/B: 8)
+#endif
+constexpr int NW = GNNLM_IVF8_NW, NTH = 64 * NW;
 #ifndef GNNLM_IVF8_ORDER
 #define GNNLM_IVF8_ORDER 1      // 1: the next tile's look-ups interleaved with this tile's MFMAs (8.8 ms); 0: look-ups first (11.0 ms)
 #endif
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void quantize_lut_kernel(const float* __restri
 // list's keys are HISTOGRAMMED per query in LDS (bins of 16, atomics without return) and the (query, list) histogram is written
 // to the segment grp_out names; nothing is compared, no per-key output.
 template <bool SUMS>
-__global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p) {
+__global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // tables at LDS address 0 (look-up addresses are absolute)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // consecutive workgroups go to consecutive XCDs: give each XCD a contiguous range of the list-sorted groups
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
 
     // ---- the 8 queries' byte tables -> [half][code][slot] x 8 B: a 4 x 8 byte transpose per thread and step
 #if !(GNNLM_IVF8_EXP & 2)
-    for (int e4 = tid; e4 < QLUT_BYTES / 4; e4 += 1024) {
+    for (int e4 = tid; e4 < QLUT_BYTES / 4; e4 += NTH) {
         uint32_t w[QG];
 #pragma unroll
         for (int j = 0; j < QG; ++j)
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem + TAB_BYTES);          // SUMS: [8 queries][HIST_BINS] counters
     uint32_t* hist_j = nullptr;                                              // this lane's query (lanes j < 8 of a live query)
     if (SUMS) {
-        for (int e = tid; e < QG * HIST_BINS; e += 1024) hist[e] = 0u;
+        for (int e = tid; e < QG * HIST_BINS; e += NTH) hist[e] = 0u;
         if (qj >= 0 && p.grp_out[(int64_t)grp * QG + j] >= 0) hist_j = hist + j * HIST_BINS;
     }
     if (!SUMS && qj >= 0) {
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     // step.  Look-up results alternate between two register sets, code bytes rotate through three: the loop is unrolled six
     // times so that every name is static.
     auto step = [&](v4i (&Xc)[8], v4i (&Xn)[8], const v4u& cn, v4u& cl, int u) {
-        cl = load_tile(u + 48);
+        cl = load_tile(u + 3 * NW);
         lookups(cn, Xn);
         v4i acc = {0, 0, 0, 0};
 #pragma unroll
@@ -389,21 +393,21 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     {
         int u = wv;
         v4i XA[8], XB[8];
-        v4u C0 = load_tile(u), C1 = load_tile(u + 16), C2 = load_tile(u + 32);   // (loads beyond the list's tiles return zeros)
+        v4u C0 = load_tile(u), C1 = load_tile(u + NW), C2 = load_tile(u + 2 * NW);   // (loads beyond the list's tiles return zeros)
         lookups(C0, XA);
         while (true) {
             if (u >= nt) break;
-            step(XA, XB, C1, C0, u); u += 16;
+            step(XA, XB, C1, C0, u); u += NW;
             if (u >= nt) break;
-            step(XB, XA, C2, C1, u); u += 16;
+            step(XB, XA, C2, C1, u); u += NW;
             if (u >= nt) break;
-            step(XA, XB, C0, C2, u); u += 16;
+            step(XA, XB, C0, C2, u); u += NW;
             if (u >= nt) break;
-            step(XB, XA, C1, C0, u); u += 16;
+            step(XB, XA, C1, C0, u); u += NW;
             if (u >= nt) break;
-            step(XA, XB, C2, C1, u); u += 16;
+            step(XA, XB, C2, C1, u); u += NW;
             if (u >= nt) break;
-            step(XB, XA, C0, C2, u); u += 16;
+            step(XB, XA, C0, C2, u); u += NW;
         }
     }
     if (SUMS) {
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
         for (int u = 0; u < QG; ++u) {
             const int64_t ob = p.grp_out[(int64_t)grp * QG + u];
             if (qs[u] < 0 || ob < 0) continue;
-            for (int e = tid; e < HIST_BINS; e += 1024) p.out_hist[ob + e] = hist[u * HIST_BINS + e];
+            for (int e = tid; e < HIST_BINS; e += NTH) p.out_hist[ob + e] = hist[u * HIST_BINS + e];
         }
         return;
     }
@@ -424,9 +428,9 @@ __global__ __launch_bounds__(1024) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p
     __syncthreads();
     if (tid < QG) {
         int tot = 0;
-        for (int w = 0; w < 16; ++w) tot += wtot[w * QG + tid];
+        for (int w = 0; w < NW; ++w) tot += wtot[w * QG + tid];
         int at = (tot > 0 && qs_lane >= 0) ? atomicAdd(&p.surv_cnt[(int64_t)qs_lane * SURV_CNT_STRIDE], tot) : 0;
-        for (int w = 0; w < 16; ++w) { const int t = wtot[w * QG + tid]; wtot[w * QG + tid] = at; at += t; }
+        for (int w = 0; w < NW; ++w) { const int t = wtot[w * QG + tid]; wtot[w * QG + tid] = at; at += t; }
     }
     __syncthreads();
     write_entries(lane < QG ? wtot[wave * QG + lane] : 0);
@@ -604,8 +608,8 @@ int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream) {
     GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<true>, SUMS_LDS);
     ProfScope prof(d.out_hist ? K_IVF8S : K_IVF8, stream, 0.0, 0.0);   // work figures are device-side (list lengths): bench.py computes them
     const int64_t grid = 8 * cdiv((int64_t)d.max_groups, (int64_t)8);
-    if (d.out_hist) hipLaunchKernelGGL(ivfpq_scan8_kernel<true>, dim3((unsigned)grid), dim3(1024), SUMS_LDS, stream, d);
-    else hipLaunchKernelGGL(ivfpq_scan8_kernel<false>, dim3((unsigned)grid), dim3(1024), SCAN_LDS, stream, d);
+    if (d.out_hist) hipLaunchKernelGGL(ivfpq_scan8_kernel<true>, dim3((unsigned)grid), dim3(NTH), SUMS_LDS, stream, d);
+    else hipLaunchKernelGGL(ivfpq_scan8_kernel<false>, dim3((unsigned)grid), dim3(NTH), SCAN_LDS, stream, d);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }
