@@ -481,6 +481,8 @@ def knn_search(args, eng, batches, dev, step_ms):
     torch.cuda.synchronize()
     step2 = (time.perf_counter() - t1) / 10
     knn_prof = _lib.profile_end().get("knn_interp_kernel", {"launches": 1, "total_ms": 0.0})
+    scan_name = "int8-MFMA filter + exact float32 re-score" if idx.tiles is not None else "float32"
+    thr_lists, cap_now = idx.dense_probes, idx.cand_cap
     # roofline of the search's dominant kernel, the int8-MFMA filter: one table byte per (query, key, sub-quantizer) goes
     # through LDS (ds_read_b64 of 8 queries' bytes) and through the matrix core (a byte of the MFMA's A operand = 32 int8 ops)
     filt = prof.get("ivfpq_scan8_kernel", {"total_ms": 0.0, "launches": 0})
@@ -498,11 +500,35 @@ def knn_search(args, eng, batches, dev, step_ms):
                 "list_bytes_GBps": round(pairs_filter / 8 * 64 / sec / 1e9, 1),
                 "avg_us": round(filt["total_ms"] * 1e3 / max(1, filt["launches"]), 1), "launches": filt["launches"],
                 "table_byte_lookups": lookups, "traffic": None}
+    # the same search over an index with SKEWED lists (log-normal lengths, sigma 0.7: ~30x between the shortest and the longest
+    # of 4096 lists), as k-means lists of real keys are: the groups of a long list are long tasks
+    skewed = None
+    if not args.small:
+        del idx, b2
+        torch.cuda.empty_cache()
+        idx2 = synthetic_ivfpq_index(args.n_store, eng.hgt.hidden_dim, 4096, 64, dev, nprobe=32, skew=0.7)
+        idx2.attach_vals(eng.store.vals)
+        idx2.search_device(q, args.k, return_vals=True)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            idx2.search_device(q, args.k, return_vals=True)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        st2 = {k_: (float(v_.item()) if torch.is_tensor(v_) else v_) for k_, v_ in idx2.stats.items()}
+        lens = (idx2.list_off[1:] - idx2.list_off[:-1])
+        skewed = {"list_lengths_min_median_max": [int(lens.min().item()), int(lens.median().item()), int(lens.max().item())],
+                  "ms_per_batch": round(sorted(ts)[1] * 1e3, 2), "ms_per_batch_runs": [round(t_ * 1e3, 2) for t_ in ts],
+                  "pairs_per_query": round(st2["pairs"] / n), "survivors_per_query": round(st2["survivors"] / n),
+                  "queries_searched_again": st2.get("requeried", 0), "queries_per_s": round(n / sorted(ts)[1], 1)}
+        del idx2
+        torch.cuda.empty_cache()
     return {"index": "synthetic OPQ64_1024,IVF4096,PQ64", "keys": args.n_store, "nprobe": 32, "k": args.k, "queries": n,
-            "scan": "int8-MFMA filter + exact float32 re-score" if idx.tiles is not None else "float32",
-            "threshold_lists": idx.dense_probes, "cand_cap": idx.cand_cap,
+            "skewed_lists": skewed,
+            "scan": scan_name, "threshold_lists": thr_lists, "cand_cap": cap_now,
             "ms_per_batch": round(dt * 1e3, 2), "ms_per_batch_runs": [round(t_ * 1e3, 2) for t_ in times], "queries_per_s": round(n / dt, 1),
-            "pairs_per_query": round(st["pairs"] / n), "survivors_per_query": round(st["survivors"] / n), "candidates_per_query": round(st["candidates"] / n),
+            "pairs_per_query": round(st["pairs"] / n), "survivors_per_query": round(st["survivors"] / n), "candidates_per_query": round(st["candidates"] / n), "queries_searched_again": st.get("requeried", 0),
             "kernels_ms": {k_: round(v_["total_ms"], 3) for k_, v_ in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
             "roofline": roof, "parity": check,
             "step_with_search_labels_ms": round(step2 * 1e3, 4),

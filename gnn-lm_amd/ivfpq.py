@@ -207,7 +207,7 @@ class IVFPQIndex:
         n = nq * P
         key = torch.where(pl < 0, torch.full_like(pl, self.nlist), pl).reshape(-1)
         skey, order = torch.sort(key, stable=True)
-        cnt = torch.bincount(key, minlength=self.nlist + 1)                   # pairs per list (last bucket: no list)
+        cnt = torch.zeros(self.nlist + 1, dtype=torch.int64, device=dev).scatter_add_(0, key, torch.ones_like(key))   # pairs per list (last bucket: no list); no host sync, unlike bincount
         start = torch.cumsum(cnt, 0) - cnt
         gcnt = (cnt + 7) // 8
         goff = torch.cumsum(gcnt, 0) - gcnt                                   # first group of every list
@@ -232,7 +232,11 @@ class IVFPQIndex:
         threshold) are searched again on their own with every probed list scored in full; if many overflow, the capacity is
         doubled for good and the call repeated."""
         q = q.to(self.device, torch.float32).contiguous()
+        zero = lambda: torch.zeros((), device=self.device, dtype=torch.float64)
         while True:
+            # work counters of this call (device side; bench.py reads them): (query, key) pairs of the probed lists, survivors
+            # of the filter, candidates after the exact re-score, queries searched a second time because their survivors overflowed
+            self.stats = {"pairs": zero(), "survivors": zero(), "candidates": zero(), "queries": q.shape[0], "M": self.M, "requeried": 0}
             val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
             if over is None:
                 break
@@ -243,12 +247,14 @@ class IVFPQIndex:
                 self.cand_cap *= 2
                 continue
             sub, cap2 = q[bad].contiguous(), self.cand_cap
+            main = {k_: (v_.clone() if torch.is_tensor(v_) else v_) for k_, v_ in self.stats.items()}
             while True:                                                       # every probed list in the threshold / dense round
                 v2, i2, o2 = self._search_once(sub, k, query_block, self.nprobe, cap2)
                 if o2 is None or cap2 >= (1 << 22) or int(o2.max().item()) <= cap2:
                     break
                 cap2 *= 2
             val[bad], idx[bad] = v2, i2
+            self.stats = dict(main, requeried=int(bad.numel()))               # (the counters describe the main pass)
             break
         self._overflow = None
         if not self.has_vals:
@@ -270,8 +276,6 @@ class IVFPQIndex:
         # the dense round's score rows: query_block * dense * max_list floats, bounded (a skewed index has long lists)
         qb = query_block if self.tiles is not None else max(1, min(query_block, self.score_bytes // max(1, 4 * dense * max(self.max_list, 1))))
         over = None
-        self.stats = {"pairs": torch.zeros((), device=dev, dtype=torch.float64), "survivors": torch.zeros((), device=dev, dtype=torch.float64),
-                      "candidates": torch.zeros((), device=dev, dtype=torch.float64), "queries": n, "M": self.M}
         for q0 in range(0, n, qb):
             o = self._search_block(q[q0:q0 + qb], k, val[q0:q0 + qb], idx[q0:q0 + qb], nprobe, dense, cap)
             if o is not None:

@@ -44,18 +44,27 @@ def device_codes(n_local, M, dev, seed):
     return codes
 
 
-def synthetic_ivfpq_index(N, d, nlist, M, dev, nprobe=32, seed=7, **kw):
+def synthetic_ivfpq_index(N, d, nlist, M, dev, nprobe=32, seed=7, skew=0.0, **kw):
     """Shape-true, content-free IVF-PQ index of the reference's kNN index family (OPQ64_1024,IVF4096,PQ64 over the
-    103 M WikiText-103 keys: 6.6 GB of codes): uniform lists, random codes and centroids, a random rotation.  For
-    search-throughput measurements only (bench.py, tools/ivfpq_bench.py); a real index comes from run_index_build."""
+    103 M WikiText-103 keys: 6.6 GB of codes): random codes and centroids, a random rotation; lists of equal length, or
+    (``skew`` > 0) log-normally distributed lengths with that sigma -- k-means lists of real keys are skewed (the 8.4 M-key
+    clustered test index: 1 .. 32,659 keys, median 1,349).  For search-throughput measurements only (bench.py,
+    tools/ivfpq_bench.py); a real index comes from run_index_build."""
     from .ivfpq import IVFPQIndex
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     R = torch.linalg.qr(torch.randn(d, d, generator=g, device=dev, dtype=torch.float32))[0].contiguous()
     coarse = (torch.randn(nlist, d, generator=g, device=dev) / d ** 0.5).contiguous()
     pq = (torch.randn(M, 256, d // M, generator=g, device=dev) * 0.05).contiguous()
-    per = -(-N // nlist)
-    off = torch.clamp(torch.arange(nlist + 1, device=dev, dtype=torch.int64) * per, max=N)
+    if skew > 0:
+        w = torch.exp(skew * torch.randn(nlist, generator=g, device=dev, dtype=torch.float64))
+        sizes = torch.floor(w / w.sum() * N).to(torch.int64)
+        sizes[0] += N - int(sizes.sum().item())                              # the rounding remainder
+        off = torch.zeros(nlist + 1, device=dev, dtype=torch.int64)
+        off[1:] = torch.cumsum(sizes, 0)
+    else:
+        per = -(-N // nlist)
+        off = torch.clamp(torch.arange(nlist + 1, device=dev, dtype=torch.int64) * per, max=N)
     return IVFPQIndex(R, coarse, pq, off, torch.arange(N, device=dev, dtype=torch.int64), device_codes(N, M, dev, seed),
                       nprobe=nprobe, cosine=True, **kw)
 
