@@ -61,6 +61,36 @@ def _kmeans(x, k, iters, gen, spherical=False):
     return cen
 
 
+def build_groups(pl, nlist, seg=None):
+    """(query, probe) pairs of ``pl`` [nq, P] (list ids, -1 = none) -> groups of up to 8 queries that probe the same list,
+    sorted by list: grp_list [G] int32, grp_q [G, 8] int32 (-1 padded), the number of groups in use as a one-element int32
+    tensor on the device.  Torch ops on the tensor's device, no host round trip; G is the upper bound pairs / 8 + nlist + 1.
+    With ``seg``: also grp_out [G, 8] int64, the offset (query * P + probe slot) * seg of the pair's segment in a [nq, P, seg]
+    array (-1: none).  What gnnlm_ivfpq_scan8 takes as its task table (include/gnnlm.h)."""
+    nq, P = pl.shape
+    dev = pl.device
+    n = nq * P
+    key = torch.where(pl < 0, torch.full_like(pl, nlist), pl).reshape(-1)
+    skey, order = torch.sort(key, stable=True)
+    cnt = torch.zeros(nlist + 1, dtype=torch.int64, device=dev).scatter_add_(0, key, torch.ones_like(key))   # pairs per list (last bucket: no list); no host sync, unlike bincount
+    start = torch.cumsum(cnt, 0) - cnt
+    gcnt = (cnt + 7) // 8
+    goff = torch.cumsum(gcnt, 0) - gcnt                                       # first group of every list
+    pos = torch.arange(n, device=dev) - start[skey]                           # position inside the run of one list
+    gid = goff[skey] + pos // 8
+    G = n // 8 + nlist + 1
+    grp_list = torch.full((G,), -1, dtype=torch.int32, device=dev)
+    grp_list[gid] = torch.where(skey >= nlist, torch.full_like(skey, -1), skey).to(torch.int32)
+    grp_q = torch.full((G, 8), -1, dtype=torch.int32, device=dev)
+    grp_q[gid, pos % 8] = torch.div(order, P, rounding_mode="floor").to(torch.int32)
+    n_groups = gcnt.sum().reshape(1).to(torch.int32)
+    if seg is None:
+        return grp_list, grp_q, n_groups, G
+    grp_out = torch.full((G, 8), -1, dtype=torch.int64, device=dev)
+    grp_out[gid, pos % 8] = torch.where(skey >= nlist, torch.full_like(order, -1), order * seg)   # order = query * P + slot
+    return grp_list, grp_q, n_groups, G, grp_out
+
+
 class IVFPQIndex:
     """faiss ``search`` contract: ``search(queries [n, d] f32, k) -> (scores [n, k] descending, ids [n, k], -1 padded)``."""
 
@@ -198,32 +228,7 @@ class IVFPQIndex:
         _lib.call_desc("gnnlm_ivfpq_scan", s)
 
     def _groups(self, pl, seg=None):
-        """(query, probe) pairs of ``pl`` [nq, P] (list ids, -1 = none) -> groups of up to 8 queries that probe the same list,
-        sorted by list: grp_list [G], grp_q [G, 8] (-1 padded), the number of groups in use as a DEVICE scalar.  Torch ops
-        on the device, no host round trip; G is the upper bound pairs / 8 + nlist + 1.  With ``seg``: also grp_out [G, 8], the
-        offset (query * P + probe slot) * seg of the pair's segment in a [nq, P, seg] array (-1: none)."""
-        nq, P = pl.shape
-        dev = self.device
-        n = nq * P
-        key = torch.where(pl < 0, torch.full_like(pl, self.nlist), pl).reshape(-1)
-        skey, order = torch.sort(key, stable=True)
-        cnt = torch.zeros(self.nlist + 1, dtype=torch.int64, device=dev).scatter_add_(0, key, torch.ones_like(key))   # pairs per list (last bucket: no list); no host sync, unlike bincount
-        start = torch.cumsum(cnt, 0) - cnt
-        gcnt = (cnt + 7) // 8
-        goff = torch.cumsum(gcnt, 0) - gcnt                                   # first group of every list
-        pos = torch.arange(n, device=dev) - start[skey]                       # position inside the run of one list
-        gid = goff[skey] + pos // 8
-        G = n // 8 + self.nlist + 1
-        grp_list = torch.full((G,), -1, dtype=torch.int32, device=dev)
-        grp_list[gid] = torch.where(skey >= self.nlist, torch.full_like(skey, -1), skey).to(torch.int32)
-        grp_q = torch.full((G, 8), -1, dtype=torch.int32, device=dev)
-        grp_q[gid, pos % 8] = torch.div(order, P, rounding_mode="floor").to(torch.int32)
-        n_groups = gcnt.sum().reshape(1).to(torch.int32)
-        if seg is None:
-            return grp_list, grp_q, n_groups, G
-        grp_out = torch.full((G, 8), -1, dtype=torch.int64, device=dev)
-        grp_out[gid, pos % 8] = torch.where(skey >= self.nlist, torch.full_like(order, -1), order * seg)   # order = query * P + slot
-        return grp_list, grp_q, n_groups, G, grp_out
+        return build_groups(pl, self.nlist, seg)
 
     def search_device(self, q, k, query_block=None, return_vals=False):
         """The search, on device tensors: (scores [n, k] descending, ids [n, k], -1 padded[, vals [n, k] int32 with

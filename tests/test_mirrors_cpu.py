@@ -156,3 +156,42 @@ def test_faiss_ivfpq_index_file_round_trip(tmp_path):
     open(f, "wb").write(b"IxHN" + raw[4:])
     with pytest.raises(ValueError):
         read_ivfpq_index(f)
+
+
+def test_ivfpq_group_table():
+    """The task table of the int8-MFMA IVF-PQ scan (gnnlm_ivfpq_scan8, include/gnnlm.h): (query, probe) pairs -> groups of at
+    most 8 queries that probe the same list, sorted by list; every pair exactly once, full groups except the last of a list,
+    -1 probes dropped, the output offsets of the threshold pass -- pure torch, device-agnostic (here on the CPU)."""
+    import torch
+    from gnnlm_amd.ivfpq import build_groups
+    rs = np.random.RandomState(5)
+    nlist, nq, P, seg = 24, 61, 7, 1024
+    pl = torch.from_numpy(np.stack([rs.permutation(nlist)[:P] for _ in range(nq)]))
+    pl[3, 2] = -1
+    pl[11, :] = -1
+    grp_list, grp_q, n_groups, G, grp_out = build_groups(pl, nlist, seg=seg)
+    ng = int(n_groups.item())
+    assert G == nq * P // 8 + nlist + 1 and ng <= G
+    grp_list, grp_q, grp_out = grp_list.numpy(), grp_q.numpy(), grp_out.numpy()
+    assert (grp_list[ng:] == -1).all() and (grp_q[ng:] == -1).all() and (grp_out[ng:] == -1).all()
+    live = grp_list[:ng]
+    assert (np.diff(live[live >= 0]) >= 0).all()                             # sorted by list (the no-list bucket comes last)
+    got = sorted((int(l), int(q)) for l, row in zip(grp_list[:ng], grp_q[:ng]) for q in row if q >= 0 and l >= 0)
+    want = sorted((int(l), r) for r, row in enumerate(pl.numpy()) for l in row if l >= 0)
+    assert got == want                                                       # every pair exactly once
+    for l in np.unique(live[live >= 0]):
+        rows = grp_q[:ng][live == l]
+        assert ((rows >= 0).sum(1)[:-1] == 8).all() and (rows >= 0).sum(1)[-1] >= 1
+    # the segment of pair (q, slot): (q * P + slot) * seg, for the pairs that name a list
+    pln = pl.numpy()
+    for g in range(ng):
+        for j in range(8):
+            q, o = grp_q[g, j], grp_out[g, j]
+            if q < 0 or grp_list[g] < 0:
+                assert o == -1 or grp_list[g] < 0
+                continue
+            slot = int(np.nonzero(pln[q] == grp_list[g])[0][0])
+            assert o == (q * P + slot) * seg
+    # without seg: the same table
+    a = build_groups(pl, nlist)
+    assert np.array_equal(a[0].numpy(), grp_list) and np.array_equal(a[1].numpy(), grp_q) and int(a[2].item()) == ng
