@@ -500,6 +500,42 @@ def knn_search(args, eng, batches, dev, step_ms):
                 "list_bytes_GBps": round(pairs_filter / 8 * 64 / sec / 1e9, 1),
                 "avg_us": round(filt["total_ms"] * 1e3 / max(1, filt["launches"]), 1), "launches": filt["launches"],
                 "table_byte_lookups": lookups, "traffic": None}
+    # THROUGH THE DROP-IN DRIVER: eval_lm.main -> SequenceScorer.generate -> KNNModel.interpolate with the search inside the
+    # reference's own timer (fairseq_cli/eval_lm.py:214-219), 32 one-block batches per launch as in `driver_path`
+    drv = None
+    if not args.small:
+        import contextlib
+        import io
+        from gnnlm_amd import eval_lm, ops
+        from gnnlm_amd.model import GnnLmModel
+        T, nblk = args.tokens_per_sample, min(args.blocks, 32)
+        nb = nblk * T
+        pool = torch.cat([b_.tgt_feats[:nb] for b_ in batches]), torch.cat([b_.targets[:nb] for b_ in batches]), torch.cat([b_.ids[:nb] for b_ in batches])
+        st_ = eng.store
+        model = GnnLmModel(eng.hgt, eng.asm, None)
+        model.make_store = lambda codes, n_store, device: st_
+
+        class SearchKnn:                          # KNNModel.interpolate over the device index (cosine: knn_model.py:181-184)
+            def interpolate(self, queries, targets, lm_logp, t, lmbda, k=0):
+                qn = queries.float()
+                qn = qn / (qn ** 2).sum(-1, keepdims=True).sqrt()
+                sims_, ids_, vals_ = idx.search_device(qn.contiguous(), args.k, return_vals=True)
+                return ops.knn_interp(lm_logp.contiguous(), sims_.contiguous(), ids_.contiguous(), targets.long().contiguous(), t, lmbda,
+                                      n_store=st_.n_store, knn_vals=vals_.contiguous())
+        n_tok = nb * len(batches)
+        tabs = {"n_tok": n_tok, "d": eng.hgt.hidden_dim, "vocab": None, "n_store": st_.n_store, "feats": pool[0], "targets": pool[1].clamp(min=4),
+                "nbrs": pool[2], "codes": st_.codes, "no_pad": True}
+        a = eval_lm.get_parser().parse_args(
+            ["-", "--path", "-", "--graph", "--use-precompute-feat", "--neighbor-context", "2", "--gcn-k", str(args.gcn_k),
+             "--tokens-per-sample", str(T), "--max-tokens", str(T), "--knnlm", "--k", str(args.k), "--lmbda", str(args.lmbda),
+             "--temperature", str(args.temperature), "--knn-keytype", "gcn_feat", "--softmax-batch", str(nb + 1), "--device", str(dev)])
+        a.knn_model = SearchKnn()
+        with contextlib.redirect_stdout(io.StringIO()):
+            eval_lm.main(a, tables=tabs, model=model)                          # warm-up
+            r_ = eval_lm.main(a, tables=tabs, model=model)
+        drv = {"tokens": r_["tokens"], "tokens_per_s_generate_timer": round(r_["tokens"] / r_["seconds"], 1),
+               "tokens_per_s_wall": round(r_["tokens"] / r_["wall_seconds"], 1), "blocks_per_batch": nblk,
+               "what": "eval_lm.main with the recipe's --max-tokens 256 (one-block batches, 32 per launch), kNN search on the device inside generate"}
     # the same search over an index with SKEWED lists (log-normal lengths, sigma 0.7: ~30x between the shortest and the longest
     # of 4096 lists), as k-means lists of real keys are: the groups of a long list are long tasks
     skewed = None
@@ -525,7 +561,7 @@ def knn_search(args, eng, batches, dev, step_ms):
         del idx2
         torch.cuda.empty_cache()
     return {"index": "synthetic OPQ64_1024,IVF4096,PQ64", "keys": args.n_store, "nprobe": 32, "k": args.k, "queries": n,
-            "skewed_lists": skewed,
+            "skewed_lists": skewed, "driver_with_search": drv,
             "scan": scan_name, "threshold_lists": thr_lists, "cand_cap": cap_now,
             "ms_per_batch": round(dt * 1e3, 2), "ms_per_batch_runs": [round(t_ * 1e3, 2) for t_ in times], "queries_per_s": round(n / dt, 1),
             "pairs_per_query": round(st["pairs"] / n), "survivors_per_query": round(st["survivors"] / n), "candidates_per_query": round(st["candidates"] / n), "queries_searched_again": st.get("requeried", 0),
