@@ -329,3 +329,34 @@ def test_topk_select_from_ragged_candidate_lists(dev, k, largest):
         assert np.array_equal(bi[r, :m], i[:m]), r
         np.testing.assert_array_equal(bv[r, :m], v[:m])
         assert (bi[r, m:] == -1).all()
+
+
+def test_ivfpq_one_billion_index_family(dev):
+    """The index family of the One Billion Word recipe (`OPQ16_64,IVF1048576,PQ16`, nprobe 32, k = 256:
+    gnnlm_scripts/one_billion/find_knn.sh:9,20): a RECTANGULAR OPQ matrix (the rotation also reduces 1024 -> 64 dimensions),
+    16 sub-quantizers of 4 dimensions, far more lists than a query probes and short lists (here 8192 lists over 400 k keys:
+    ~49 keys each, many empty) -- against the float64 IVFADC oracle over the same arrays."""
+    from gnnlm_amd.ivfpq import IVFPQIndex
+    from oracle import ivfpq as oivf
+    rs = np.random.RandomState(31)
+    N, d_in, d_out, nlist, M, nprobe, k = 400_000, 256, 64, 8192, 16, 32, 256
+    centres = rs.randn(300, d_in).astype(np.float32)
+    keys = (centres[rs.randint(0, 300, N)] + 0.5 * rs.randn(N, d_in).astype(np.float32)).astype(np.float32)
+    P = np.linalg.qr(rs.randn(d_in, d_out))[0].T.astype(np.float32)          # [d_out, d_in] with orthonormal rows: the OPQ projection
+    inner = IVFPQIndex.build(keys @ P.T, nlist, M, device=dev, cosine=False, nprobe=nprobe, iters=4, seed=2)
+    R = (inner.R.cpu().numpy() @ P).astype(np.float32)                       # rotation of the projected space after the projection
+    index = IVFPQIndex(torch.from_numpy(R).to(dev), inner.coarse, inner.pq, inner.list_off, inner.list_ids, inner.list_codes,
+                       nprobe=nprobe, cosine=False)
+    assert index.R.shape == (d_out, d_in) and index.M == 16 and index.dsub == 4 and index.tiles is None
+    lens = (index.list_off[1:] - index.list_off[:-1]).cpu().numpy()
+    assert (lens == 0).any() and lens.max() < 4000
+    q = (centres[rs.randint(0, 300, 50)] + 0.5 * rs.randn(50, d_in)).astype(np.float32)
+    v, i = index.search(q, k)
+    arrs = [R, inner.coarse.cpu().numpy(), inner.pq.cpu().numpy(), inner.list_off.cpu().numpy(), inner.list_ids.cpu().numpy(),
+            inner.list_codes.cpu().numpy()]
+    v_ref, i_ref = oivf.search(q, *arrs, k=k, nprobe=nprobe)
+    ok = i_ref >= 0
+    assert np.array_equal(i >= 0, ok)                                        # the same number of neighbours found (-1 padding beyond)
+    same = np.mean([len(set(a[a >= 0]) & set(b[b >= 0])) / max(1, (b >= 0).sum()) for a, b in zip(i, i_ref)])
+    assert same > 0.998, same
+    np.testing.assert_allclose(v[ok], v_ref[ok], rtol=2e-5, atol=2e-4)
