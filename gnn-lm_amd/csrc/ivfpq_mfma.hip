@@ -510,19 +510,24 @@ __global__ __launch_bounds__(1024) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore
     const int n = min(p.surv_cnt[q * SURV_CNT_STRIDE], p.cap);
     if (tid == 0) ccnt = 0;
     const uint2* surv = reinterpret_cast<const uint2*>(p.surv) + q * p.cap;
-    // the first survivor's code row is requested before the table arrives
-    uint32_t row32 = 0u, list = 0u;
-    v4u cr[M / 16];
+    // the first two survivors' code rows are requested before the table arrives; from then on a thread always has the rows of
+    // its next two survivors in flight (random 64-byte reads: an HBM round trip is longer than one survivor's 64 look-ups)
+    uint32_t rowA = 0u, listA = 0u, rowB = 0u, listB = 0u;
+    v4u crA[M / 16], crB[M / 16];
 #pragma unroll
-    for (int c16 = 0; c16 < M / 16; ++c16) cr[c16] = v4u{0u, 0u, 0u, 0u};
-    if (tid < n) {
-        const uint2 sv = surv[tid];
-        row32 = sv.x;
-        list = sv.y;
-        const v4u* crow = reinterpret_cast<const v4u*>(p.codes + (int64_t)row32 * M);
+    for (int c16 = 0; c16 < M / 16; ++c16) crA[c16] = crB[c16] = v4u{0u, 0u, 0u, 0u};
+    auto fetch = [&](int e, uint32_t& r32, uint32_t& l32, v4u (&cr)[M / 16]) {
+        if (e < n) {
+            const uint2 sv = surv[e];
+            r32 = sv.x;
+            l32 = sv.y;
+            const v4u* crow = reinterpret_cast<const v4u*>(p.codes + (int64_t)r32 * M);
 #pragma unroll
-        for (int c16 = 0; c16 < M / 16; ++c16) cr[c16] = crow[c16];
-    }
+            for (int c16 = 0; c16 < M / 16; ++c16) cr[c16] = crow[c16];
+        }
+    };
+    fetch(tid, rowA, listA, crA);
+    fetch(tid + NT, rowB, listB, crB);
     if (n > 0) {
         const float4* src = reinterpret_cast<const float4*>(p.lut + q * p.ld_lut);
         float4* dst = reinterpret_cast<float4*>(rtab);
@@ -532,23 +537,20 @@ __global__ __launch_bounds__(1024) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore
     const float tau = p.tau[q];
     const uint8_t* cb = reinterpret_cast<const uint8_t*>(cdw + tid);        // byte m of the row: cb[(m >> 2) * 4 * NT + (m & 3)]
     for (int e = tid; e < n; e += NT) {
-        const int64_t row = row32;
-        const uint32_t lst = list;
+        const int64_t row = rowA;
+        const uint32_t lst = listA;
 #pragma unroll
         for (int c16 = 0; c16 < M / 16; ++c16) {
-            cdw[(4 * c16 + 0) * NT + tid] = cr[c16].x;
-            cdw[(4 * c16 + 1) * NT + tid] = cr[c16].y;
-            cdw[(4 * c16 + 2) * NT + tid] = cr[c16].z;
-            cdw[(4 * c16 + 3) * NT + tid] = cr[c16].w;
+            cdw[(4 * c16 + 0) * NT + tid] = crA[c16].x;
+            cdw[(4 * c16 + 1) * NT + tid] = crA[c16].y;
+            cdw[(4 * c16 + 2) * NT + tid] = crA[c16].z;
+            cdw[(4 * c16 + 3) * NT + tid] = crA[c16].w;
         }
-        if (e + NT < n) {                                                   // the next survivor's row travels under this one's look-ups
-            const uint2 sv = surv[e + NT];
-            row32 = sv.x;
-            list = sv.y;
-            const v4u* crow = reinterpret_cast<const v4u*>(p.codes + (int64_t)row32 * M);
+        rowA = rowB;
+        listA = listB;
 #pragma unroll
-            for (int c16 = 0; c16 < M / 16; ++c16) cr[c16] = crow[c16];
-        }
+        for (int c16 = 0; c16 < M / 16; ++c16) crA[c16] = crB[c16];
+        fetch(e + 2 * NT, rowB, listB, crB);
         const int rot = (int)(row & 31);
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
