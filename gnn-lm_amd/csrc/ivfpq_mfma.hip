@@ -132,6 +132,9 @@ constexpr int NW = GNNLM_IVF8_NW, NTH = 64 * NW;
 #ifndef GNNLM_IVF8_ORDER
 #define GNNLM_IVF8_ORDER 1      // 1: the next tile's look-ups interleaved with this tile's MFMAs (8.8 ms); 0: look-ups first (11.0 ms)
 #endif
+#ifndef GNNLM_IVF8_PF
+#define GNNLM_IVF8_PF 3         // tiles of code bytes in flight per wave (A/B: 4)
+#endif
 #ifndef GNNLM_IVF8_EXP
 #define GNNLM_IVF8_EXP 0        // ablation builds (no survivors): 1 no code loads, 2 no table fill, 4 no look-ups, 8 no MFMAs, 16 nothing else
 #endif
@@ -144,16 +147,22 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // tables at LDS address 0 (look-up addresses are absolute)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // consecutive workgroups go to consecutive XCDs: give each XCD a contiguous range of the list-sorted groups
+    // The workgroups are PERSISTENT (one per CU: the tables take the CU's LDS): workgroup b of XCD b % 8 walks the groups b / 8,
+    // b / 8 + gridDim / 8, ... of its XCD's range -- the groups of one list are neighbours in that order, so they run side by
+    // side on one XCD and share the list's bytes in its L2; no workgroup launch (and LDS allocation) between two groups.
     const int n_groups = min(*p.n_groups, p.max_groups);
     const int per_xcd = (n_groups + 7) >> 3;
-    if ((int)(blockIdx.x >> 3) >= per_xcd) return;
-    const int grp = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (grp >= n_groups) return;
-    const int list = p.grp_list[grp];
-    if (list < 0) return;
-    const int64_t lo = p.list_off[list], hi = p.list_off[list + 1];
-    if (hi <= lo) return;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
+    bool first = true;
+    for (int gi = (int)(blockIdx.x >> 3); gi < per_xcd; gi += (int)(gridDim.x >> 3)) {
+    const int grp = (int)(blockIdx.x & 7) * per_xcd + gi;
+    if (grp >= n_groups) break;
+    const int list = p.grp_list[grp];
+    if (list < 0) continue;
+    const int64_t lo = p.list_off[list], hi = p.list_off[list + 1];
+    if (hi <= lo) continue;
+    if (!first) __syncthreads();                                             // the previous group's tables, totals and histograms are done with
+    first = false;
     uint32_t* wbuf = reinterpret_cast<uint32_t*>(smem + TAB_BYTES + 512) + wave * WAVE_CAP;   // this wave's survivors: (row - lo) << 3 | query slot
     const int* gq = p.grp_q + (int64_t)grp * QG;
     uint2* surv = reinterpret_cast<uint2*>(p.surv);                           // {row, list} per survivor
@@ -163,25 +172,35 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
 
     // ---- the 8 queries' byte tables -> [half][code][slot] x 8 B: a 4 x 8 byte transpose per thread and step
 #if !(GNNLM_IVF8_EXP & 2)
-    for (int e4 = tid; e4 < QLUT_BYTES / 4; e4 += NTH) {
-        uint32_t w[QG];
+    {
+        constexpr int FILL = QLUT_BYTES / 4 / NTH;       // dwords of each query's table per thread
+        constexpr int FB = SUMS ? 1 : FILL;              // of which in flight at once (the threshold pass has no registers to spare)
 #pragma unroll
-        for (int j = 0; j < QG; ++j)
-            w[j] = qs[j] >= 0 ? reinterpret_cast<const uint32_t*>(p.qlut + (int64_t)qs[j] * QLUT_BYTES)[e4] : 0u;
-        uint32_t o[8];
+        for (int i0 = 0; i0 < FILL; i0 += FB) {
+            uint32_t w[FB][QG];
 #pragma unroll
-        for (int hq = 0; hq < 2; ++hq) {                 // queries 4 hq .. 4 hq + 3 -> dword hq of the four entries
-            const uint32_t a = w[4 * hq], b = w[4 * hq + 1], c = w[4 * hq + 2], d = w[4 * hq + 3];
-            const uint32_t t0 = GNNLM_PERM(b, a, 0x05010400u), t1 = GNNLM_PERM(b, a, 0x07030602u);
-            const uint32_t t2 = GNNLM_PERM(d, c, 0x05010400u), t3 = GNNLM_PERM(d, c, 0x07030602u);
-            o[0 + hq] = GNNLM_PERM(t2, t0, 0x05040100u);
-            o[2 + hq] = GNNLM_PERM(t2, t0, 0x07060302u);
-            o[4 + hq] = GNNLM_PERM(t3, t1, 0x05040100u);
-            o[6 + hq] = GNNLM_PERM(t3, t1, 0x07060302u);
+            for (int it = 0; it < FB; ++it)
+#pragma unroll
+                for (int j = 0; j < QG; ++j)
+                    w[it][j] = qs[j] >= 0 ? reinterpret_cast<const uint32_t*>(p.qlut + (int64_t)qs[j] * QLUT_BYTES)[tid + (i0 + it) * NTH] : 0u;
+#pragma unroll
+            for (int it = 0; it < FB; ++it) {
+                uint32_t o[8];
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {         // queries 4 hq .. 4 hq + 3 -> dword hq of the four entries
+                    const uint32_t a = w[it][4 * hq], b = w[it][4 * hq + 1], c = w[it][4 * hq + 2], d = w[it][4 * hq + 3];
+                    const uint32_t t0 = GNNLM_PERM(b, a, 0x05010400u), t1 = GNNLM_PERM(b, a, 0x07030602u);
+                    const uint32_t t2 = GNNLM_PERM(d, c, 0x05010400u), t3 = GNNLM_PERM(d, c, 0x07030602u);
+                    o[0 + hq] = GNNLM_PERM(t2, t0, 0x05040100u);
+                    o[2 + hq] = GNNLM_PERM(t2, t0, 0x07060302u);
+                    o[4 + hq] = GNNLM_PERM(t3, t1, 0x05040100u);
+                    o[6 + hq] = GNNLM_PERM(t3, t1, 0x07060302u);
+                }
+                uint4* dst = reinterpret_cast<uint4*>(smem) + 2 * (tid + (i0 + it) * NTH);
+                dst[0] = uint4{o[0], o[1], o[2], o[3]};
+                dst[1] = uint4{o[4], o[5], o[6], o[7]};
+            }
         }
-        uint4* dst = reinterpret_cast<uint4*>(smem) + 2 * e4;
-        dst[0] = uint4{o[0], o[1], o[2], o[3]};
-        dst[1] = uint4{o[4], o[5], o[6], o[7]};
     }
 #endif
     // ---- integer thresholds: lane column j = lane % 16 (the D layout of the MFMA: D[key 4 g + r][query j])
@@ -234,6 +253,8 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     auto load_tile = [&](int u) -> v4u {
 #if GNNLM_IVF8_EXP & 1
         return v4u{(uint32_t)u * 2654435761u + lane, (uint32_t)u * 40503u ^ lane, (uint32_t)u + 77u * lane, (uint32_t)u * 3u + lane};
+#elif GNNLM_IVF8_EXP & 256
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane((u & 3) * 1024), 0);   // always the same four tiles: cache hits
 #else
         return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane(u * 1024), 0);   // (u is wave-uniform: tell the compiler)
 #endif
@@ -316,7 +337,7 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
 #if !(GNNLM_IVF8_EXP & 64)
         if (mine) wbuf[wcnt + rank] = (uint32_t)local_row << 3 | (uint32_t)(j & 7);
 #endif
-        wcnt += __builtin_popcountll(m);
+        wcnt = __builtin_amdgcn_readfirstlane(wcnt + __builtin_popcountll(m));   // (scalar: the compiler's divergence analysis gives up on it)
 #if GNNLM_IVF8_EXP & 128
         wcnt = 0;
 #endif
@@ -327,7 +348,7 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     // step.  Look-up results alternate between two register sets, code bytes rotate through three: the loop is unrolled six
     // times so that every name is static.
     auto step = [&](v4i (&Xc)[8], v4i (&Xn)[8], const v4u& cn, v4u& cl, int u) {
-        cl = load_tile(u + 3 * NW);
+        cl = load_tile(u + GNNLM_IVF8_PF * NW);
         lookups(cn, Xn);
         v4i acc = {0, 0, 0, 0};
 #pragma unroll
@@ -394,8 +415,21 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         int u = wv;
         v4i XA[8], XB[8];
         v4u C0 = load_tile(u), C1 = load_tile(u + NW), C2 = load_tile(u + 2 * NW);   // (loads beyond the list's tiles return zeros)
+#if GNNLM_IVF8_PF == 4
+        v4u C3 = load_tile(u + 3 * NW);
+#endif
         lookups(C0, XA);
         while (true) {
+#if GNNLM_IVF8_PF == 4
+            if (u >= nt) break;
+            step(XA, XB, C1, C0, u); u += NW;
+            if (u >= nt) break;
+            step(XB, XA, C2, C1, u); u += NW;
+            if (u >= nt) break;
+            step(XA, XB, C3, C2, u); u += NW;
+            if (u >= nt) break;
+            step(XB, XA, C0, C3, u); u += NW;
+#else
             if (u >= nt) break;
             step(XA, XB, C1, C0, u); u += NW;
             if (u >= nt) break;
@@ -408,6 +442,7 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
             step(XA, XB, C2, C1, u); u += NW;
             if (u >= nt) break;
             step(XB, XA, C0, C2, u); u += NW;
+#endif
         }
     }
     if (SUMS) {
@@ -418,7 +453,7 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
             if (qs[u] < 0 || ob < 0) continue;
             for (int e = tid; e < HIST_BINS; e += NTH) p.out_hist[ob + e] = hist[u * HIST_BINS + e];
         }
-        return;
+        continue;
     }
     // ---- end of the task: the 16 waves' regions -> the queries' lists with ONE global atomic per query slot for the whole
     // workgroup (the counters are contended: 30 lists x their groups add to every query's): per-wave slot totals meet in LDS
@@ -434,6 +469,7 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     }
     __syncthreads();
     write_entries(lane < QG ? wtot[wave * QG + lane] : 0);
+    }
 }
 
 // Threshold from the histograms of a query's D dense lists (written by the SUMS pass): a LOWER bound of its k-th best exact
@@ -609,7 +645,10 @@ int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream) {
     GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<false>, SCAN_LDS);
     GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<true>, SUMS_LDS);
     ProfScope prof(d.out_hist ? K_IVF8S : K_IVF8, stream, 0.0, 0.0);   // work figures are device-side (list lengths): bench.py computes them
-    const int64_t grid = 8 * cdiv((int64_t)d.max_groups, (int64_t)8);
+    int dev = 0, cus = 0;
+    GNNLM_HIP(hipGetDevice(&dev));
+    GNNLM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t grid = std::min<int64_t>(8 * cdiv((int64_t)d.max_groups, (int64_t)8), 8 * cdiv((int64_t)std::max(cus, 8), (int64_t)8));   // persistent: one per CU
     if (d.out_hist) hipLaunchKernelGGL(ivfpq_scan8_kernel<true>, dim3((unsigned)grid), dim3(NTH), SUMS_LDS, stream, d);
     else hipLaunchKernelGGL(ivfpq_scan8_kernel<false>, dim3((unsigned)grid), dim3(NTH), SCAN_LDS, stream, d);
     GNNLM_LAUNCH_CHECK();
