@@ -27,6 +27,8 @@ after ``add_with_ids`` (knn/index_builder.py:79-150), the file ``KNNModel`` is p
                 vector<int32> neighbors  int32 entry_point  int32 max_level  int32 efConstruction  int32 efSearch  int32 upper_beam
   ivf_header := header  uint64 nlist  uint64 nprobe  index (quantizer)  int8 direct_map_type  vector<int64> direct_map
                 [vector<(int64, int64)> if direct_map_type == 2]
+  index      |= fourcc ("IxMp" | "IxM2") header  index  vector<int64> id_map      (IndexIDMap[2]: `IDMap,,Flat`, what
+                                                                                  index_builder.py:49-53 builds for < 30,000 keys)
   invlists   := fourcc "ilar"  uint64 nlist  uint64 code_size  fourcc ("full" | "sprs")  vector<uint64> sizes
                 { uint8 codes[n * code_size]  int64 ids[n] } for every non-empty list          ("sprs": sizes = (list, n) pairs)
 
@@ -256,3 +258,41 @@ def write_ivfpq_index(path, R, coarse, pq, list_off, list_ids, list_codes, nprob
             if sizes[l]:
                 f.write(np.ascontiguousarray(codes[off[l]:off[l + 1]]).tobytes())
                 f.write(np.ascontiguousarray(ids[off[l]:off[l + 1]]).tobytes())
+
+
+def read_flat_index(path):
+    """A faiss ``Flat`` index, bare or inside an ``IDMap`` (``index_factory(d, "IDMap,,Flat")``: the auto type of
+    knn/index_builder.py:49-53 for datastores under 30,000 keys) -> dict(xb f32 [n, d], ids i64 [n] | None, metric "ip" | "l2")."""
+    r = _R(np.memmap(path, dtype=np.uint8, mode="r"))
+    cc = r.fourcc()
+    mapped = cc in ("IxMp", "IxM2")
+    if mapped:
+        _header(r)
+        cc = r.fourcc()
+    if cc not in ("IxFI", "IxF2", "IxFl"):
+        raise ValueError(f"{path}: not a Flat index ('{cc}')")
+    d, ntotal, _, metric = _header(r)
+    xb = r.vector(np.float32)
+    if xb.size != d * ntotal:
+        raise ValueError(f"{path}: Flat index holds {xb.size} floats, expected {ntotal} x {d}")
+    ids = None
+    if mapped:
+        ids = r.vector(np.int64)
+        if ids.size != ntotal:
+            raise ValueError(f"{path}: id map of {ids.size} entries over {ntotal} vectors")
+    return {"xb": xb.reshape(ntotal, d), "ids": ids, "metric": "ip" if metric == 0 else "l2"}
+
+
+def write_flat_index(path, xb, ids=None, metric="ip"):
+    """The inverse (``faiss.write_index`` of ``Flat`` / ``IDMap,,Flat``)."""
+    xb = np.ascontiguousarray(xb, dtype=np.float32)
+    n, d = xb.shape
+    mt = 0 if metric == "ip" else 1
+    hdr = struct.pack("<iqqq?i", d, n, 1 << 20, 1 << 20, True, mt)
+    with open(path, "wb") as f:
+        if ids is not None:
+            f.write(b"IxMp" + hdr)
+        f.write((b"IxFI" if mt == 0 else b"IxF2") + hdr + struct.pack("<Q", xb.size) + xb.tobytes())
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+            f.write(struct.pack("<Q", ids.size) + ids.tobytes())

@@ -33,8 +33,10 @@ class ExactIndex:
     Neither the [n, N] score matrix nor a sort of it ever exists.  Cosine: the per-key 1/|key| is a column scale of
     the merge (index_builder.py:90-95,118 normalises the keys it adds)."""
 
-    def __init__(self, keys, metric="ip", cosine=False, device="cuda", chunk_rows=65536, score_bytes=256 << 20):
+    def __init__(self, keys, metric="ip", cosine=False, device="cuda", chunk_rows=65536, score_bytes=256 << 20, id_map=None):
         self.metric, self.cosine, self.device = metric, cosine, torch.device(device)
+        # id_map: row -> external id (faiss IndexIDMap: add_with_ids, index_builder.py:99); None = the row number
+        self.id_map = None if id_map is None else torch.as_tensor(np.asarray(id_map), dtype=torch.int64).to(self.device)
         self.chunk_rows, self.score_bytes = chunk_rows, score_bytes
         if isinstance(keys, torch.Tensor):
             self.keys = keys.to(self.device).contiguous()
@@ -82,6 +84,8 @@ class ExactIndex:
                                alpha=1.0 if ip else -2.0, largest=ip, init=(r0 == 0))
         if not ip:
             val += (q ** 2).sum(-1, keepdim=True)           # |q|^2 + |k|^2 - 2 q.k
+        if self.id_map is not None and self.ntotal:
+            idx = torch.where(idx >= 0, self.id_map[idx.clamp_min(0)], idx)
         return val, idx
 
     def search(self, queries, k):
@@ -143,6 +147,11 @@ class KNNModel(object):
                     return index
                 except ValueError as e:
                     LOGGING.warning("%s", e)
+            elif faiss_io.sniff(self.index_file) in ("IxMp", "IxM2", "IxFI", "IxF2", "IxFl"):
+                # `IDMap,,Flat`: what index_builder.py:49-53 builds for small datastores -- exact search over the file's vectors
+                z = faiss_io.read_flat_index(self.index_file)
+                LOGGING.info("faiss Flat file %s (%d vectors) searched on %s", self.index_file, z["xb"].shape[0], self.device)
+                return ExactIndex(torch.from_numpy(np.ascontiguousarray(z["xb"])), z["metric"], False, self.device, id_map=z["ids"])
         try:
             import faiss
         except ImportError:

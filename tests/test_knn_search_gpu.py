@@ -301,6 +301,46 @@ def test_knn_model_reads_faiss_index_file(dev, tmp_path):
         KNNModel(f, str(dd), k=64, probe=6, no_load_keys=True, metric_type="do_not_recomp_ip", device=dev)
 
 
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_knn_model_reads_faiss_flat_file(dev, tmp_path, metric):
+    """`--index-file` pointing at an `IDMap,,Flat` file (index_builder.py:49-53: the auto type for small datastores; the keys
+    are normalised before they are added for "cosine", :90-95): exact search over the FILE's vectors with the file's ids."""
+    import json, os
+    from gnnlm_amd import faiss_io
+    from gnnlm_amd.knn_model import ExactIndex, KNNModel
+    rs = np.random.RandomState(15)
+    N, d, V, k, n = 5000, 64, 40, 32, 19
+    keys = rs.randn(N, d).astype(np.float32)
+    vals = rs.randint(0, V, N).astype(np.int16)
+    dd = tmp_path / "train_dstore"
+    os.makedirs(dd)
+    keys.astype(np.float16).tofile(dd / "keys.npy"); vals.tofile(dd / "vals.npy")
+    json.dump({"dstore_size": N, "hidden_size": d, "vocab_size": V, "dstore_fp16": True, "val_size": 1}, open(dd / "info.json", "w"))
+    ids = rs.permutation(N).astype(np.int64)                             # add_with_ids in some other order than the rows
+    xb = keys[ids] / np.sqrt((keys[ids] ** 2).sum(1, keepdims=True)) if metric == "cosine" else keys[ids]
+    f = str(dd / f"faiss_store.{metric}")
+    faiss_io.write_flat_index(f, xb, ids, metric="ip" if metric == "cosine" else "l2")
+    fn = "do_not_recomp_ip" if metric == "cosine" else "do_not_recomp_l2"
+    m = KNNModel(f, str(dd), k=k, no_load_keys=True, metric_type=fn, device=dev)
+    assert isinstance(m.index, ExactIndex) and m.index.ntotal == N
+    q = rs.randn(n, d).astype(np.float32)
+    sims, knns = m.search_sims(torch.from_numpy(q).to(dev), k)
+    sims, knns = sims.cpu().numpy(), knns.cpu().numpy()
+    if metric == "cosine":
+        qn = q / np.sqrt((q ** 2).sum(1, keepdims=True))
+        ref = qn.astype(np.float64) @ xb.T.astype(np.float64)
+    else:
+        ref = -((q[:, None, :].astype(np.float64) - xb[None].astype(np.float64)) ** 2).sum(-1)
+    order = np.argsort(-ref, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(knns, ids[order])
+    np.testing.assert_allclose(sims, np.take_along_axis(ref, order, 1), rtol=2e-5, atol=2e-5)
+    targets = torch.from_numpy(vals[ids[order[:, 3]]].astype(np.int64)).to(dev)
+    p, rec = m.get_knn_prob(torch.from_numpy(q).to(dev), targets=targets, t=1.0, return_recall=True)
+    p_ref, rec_ref = oknn.knn_target_prob(np.take_along_axis(ref, order, 1).astype(np.float32), ids[order], vals, targets.cpu().numpy(), 1.0)
+    np.testing.assert_allclose(p.cpu().numpy(), p_ref.numpy(), rtol=2e-4, atol=1e-6)
+    assert np.array_equal(rec.cpu().numpy(), rec_ref.numpy())
+
+
 @pytest.mark.parametrize("k", [64, 1024, 2000])
 @pytest.mark.parametrize("largest", [True, False])
 def test_topk_select_from_ragged_candidate_lists(dev, k, largest):

@@ -116,6 +116,33 @@ def test_faiss_quantizer_file_round_trip(tmp_path):
         read_pq_quantizer(f)
 
 
+def test_faiss_flat_index_file_round_trip(tmp_path):
+    """`IDMap,,Flat` / `Flat` files (the auto index type of knn/index_builder.py:49-53 for small datastores): layout spot checks,
+    writer and reader agree, both metrics, other kinds are refused."""
+    import pytest
+    from gnnlm_amd.faiss_io import read_flat_index, sniff, write_flat_index
+    rs = np.random.RandomState(2)
+    xb = rs.randn(37, 12).astype(np.float32)
+    ids = rs.permutation(1000)[:37].astype(np.int64)
+    f = str(tmp_path / "faiss_store.l2")
+    for metric in ("ip", "l2"):
+        for ids_ in (ids, None):
+            write_flat_index(f, xb, ids_, metric=metric)
+            assert sniff(f) == ("IxMp" if ids_ is not None else ("IxFI" if metric == "ip" else "IxF2"))
+            z = read_flat_index(f)
+            assert np.array_equal(z["xb"], xb) and z["metric"] == metric
+            assert (z["ids"] is None) == (ids_ is None) and (ids_ is None or np.array_equal(z["ids"], ids_))
+    write_flat_index(f, xb, ids, metric="l2")
+    raw = open(f, "rb").read()
+    # IxMp | header | IxF2 | header (int32 d, int64 ntotal, ..., int32 metric = 1) | uint64 n floats | data | uint64 n ids | ids
+    assert raw[:4] == b"IxMp" and raw[37:41] == b"IxF2" and struct.unpack_from("<iq", raw, 41) == (12, 37)
+    assert struct.unpack_from("<i", raw, 41 + 29)[0] == 1 and struct.unpack_from("<Q", raw, 74)[0] == 37 * 12
+    assert struct.unpack_from("<Q", raw, 82 + 37 * 12 * 4)[0] == 37
+    open(f, "wb").write(b"IxPq" + raw[4:])
+    with pytest.raises(ValueError):
+        read_flat_index(f)
+
+
 def test_faiss_ivfpq_index_file_round_trip(tmp_path):
     """The kNN index file layout (faiss IndexPreTransform(OPQ) -> IndexIVFPQ over an IndexFlatIP, index_builder.py:79-150)
     restated in faiss_io.py: byte-level spot checks of the layout, writer and reader agree (dense and sparse list-size
