@@ -36,12 +36,15 @@ import torch
 from . import _lib, ops
 
 
-def _kmeans(x, k, iters, gen, spherical=False):
+def _kmeans(x, k, iters, gen, spherical=False, init=None):
     """Lloyd's algorithm (squared L2) on the device; empty clusters are re-seeded from random points.  ``spherical``: the
     centroids are L2-normalised after every update (faiss ClusteringParameters.spherical, set by index_factory for
-    METRIC_INNER_PRODUCT coarse quantizers)."""
+    METRIC_INNER_PRODUCT coarse quantizers).  ``init``: centroids to start from (OPQ's inner PQ rounds)."""
     n = x.shape[0]
-    cen = x[torch.randperm(n, generator=gen, device=x.device)[:k]].clone()
+    if init is not None:
+        cen = init.clone()
+    else:
+        cen = x[torch.randperm(n, generator=gen, device=x.device)[:k]].clone()
     if cen.shape[0] < k:
         cen = torch.cat([cen, cen[torch.randint(0, cen.shape[0], (k - cen.shape[0],), generator=gen, device=x.device)]])
     for _ in range(iters):
@@ -59,6 +62,36 @@ def _kmeans(x, k, iters, gen, spherical=False):
             new[dead] = x[torch.randint(0, n, (dead.numel(),), generator=gen, device=x.device)]
         cen = new / new.norm(dim=1, keepdim=True).clamp_min(1e-20) if spherical else new
     return cen
+
+
+def _pq_assign(x, cen):
+    """x [n, dsub], cen [256, dsub] -> nearest centroid per row (squared L2), in chunks."""
+    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    c2 = (cen ** 2).sum(1)
+    for s in range(0, x.shape[0], 1 << 18):
+        out[s:s + (1 << 18)] = (c2[None, :] - 2 * x[s:s + (1 << 18)] @ cen.t()).argmin(1)
+    return out
+
+
+def train_opq(x, M, R0, iters, gen, pq_iters=4):
+    """The OPQ rotation (Ge et al., "Optimized Product Quantization", the non-parametric solution; what faiss's OPQMatrix trains
+    for the ``OPQ64_1024`` block of the reference's index type, knn/index_builder.py:60-64): alternate (a) a product quantizer of
+    M x 256 centroids on the rotated vectors x R^T (k-means per sub-space, warm-started from the previous round) and (b) the
+    orthogonal Procrustes solution R^T = U V^T, U S V^T = x^T y, y = the quantizer's reconstruction of x R^T -- the rotation
+    under which the quantizer loses least.  x [n, d] f32 on the device, R0 [d, d] orthonormal start; -> R [d, d]."""
+    n, d = x.shape
+    dsub = d // M
+    R, cents = R0.clone(), [None] * M
+    for _ in range(iters):
+        xr = x @ R.t()
+        y = torch.empty_like(xr)
+        for m in range(M):
+            sub = xr[:, m * dsub:(m + 1) * dsub].contiguous()
+            cents[m] = _kmeans(sub, 256, pq_iters, gen, init=cents[m])
+            y[:, m * dsub:(m + 1) * dsub] = cents[m][_pq_assign(sub, cents[m])]
+        U, _, Vt = torch.linalg.svd((x.t() @ y).double())
+        R = (U @ Vt).t().to(torch.float32).contiguous()
+    return R
 
 
 def build_groups(pl, nlist, seg=None):
@@ -151,7 +184,11 @@ class IVFPQIndex:
 
     # ------------------------------------------------------------------------------------------ offline producer
     @classmethod
-    def build(cls, keys, nlist, M, device="cuda", cosine=True, nprobe=32, iters=10, train_size=262144, seed=0, chunk=1 << 18, **kw):
+    def build(cls, keys, nlist, M, device="cuda", cosine=True, nprobe=32, iters=10, train_size=262144, seed=0, chunk=1 << 18,
+              opq_iters=0, **kw):
+        """Train (rotation, coarse centroids, residual product quantizer) on a sample and add every key.  ``opq_iters`` = 0: a
+        random orthonormal rotation (spreads the variance over the sub-spaces); > 0: that many rounds of OPQ training from it
+        (``train_opq``: what the reference's ``OPQ64_1024`` block asks faiss for)."""
         device = torch.device(device)
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
@@ -168,7 +205,10 @@ class IVFPQIndex:
         R = torch.linalg.qr(torch.randn(d, d, generator=cpu_gen, dtype=torch.float64))[0].to(torch.float32).to(device)
         pick = np.sort(np.random.RandomState(seed).choice(N, size=min(N, train_size), replace=False))
         xt = torch.cat([rows(int(s), int(min(N, s + chunk)))[torch.from_numpy(pick[(pick >= s) & (pick < s + chunk)] - s).to(device)]
-                        for s in range(0, N, chunk)]) @ R.t()
+                        for s in range(0, N, chunk)])
+        if opq_iters > 0:
+            R = train_opq(xt, M, R, opq_iters, gen)
+        xt = xt @ R.t()
         coarse = _kmeans(xt, nlist, iters, gen, spherical=cosine)
         resid = xt - coarse[(xt @ coarse.t()).argmax(1)]                      # inner-product assignment (IndexFlatIP quantizer)
         pq = torch.stack([_kmeans(resid[:, m * dsub:(m + 1) * dsub].contiguous(), 256, iters, gen) for m in range(M)])

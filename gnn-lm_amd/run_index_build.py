@@ -28,6 +28,7 @@ def get_parser():
     p.add_argument("--max-train", type=int, default=1000000)
     p.add_argument("--chunk-size", type=int, default=1 << 18)
     p.add_argument("--nprobe", type=int, default=32)
+    p.add_argument("--opq-iters", type=int, default=10, help="rounds of OPQ training when --index-type has an OPQ block (0: random rotation)")
     p.add_argument("--overwrite", action="store_true")
     p.add_argument("--cuda", type=int, default=0)
     return p
@@ -52,7 +53,8 @@ def main(args):
     nlist, M = parse_index_type(args.index_type)
     nlist = max(1, min(nlist, ds.dstore_size // 30 or 1))                       # index_builder.py:56: at least ~30 keys per list
     index = IVFPQIndex.build(ds.keys, nlist, M, device=torch.device("cuda", max(args.cuda, 0)), cosine=(args.metric == "cosine"),
-                             nprobe=args.nprobe, train_size=args.max_train, seed=args.seed, chunk=args.chunk_size)
+                             nprobe=args.nprobe, train_size=args.max_train, seed=args.seed, chunk=args.chunk_size,
+                             opq_iters=args.opq_iters if "OPQ" in args.index_type else 0)
     index.save(out)
     print(f"Save index of {index.ntotal} keys ({nlist} lists, PQ{M}) to {out}")
     return out
