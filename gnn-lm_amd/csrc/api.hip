@@ -537,7 +537,7 @@ size_t gnnlm_sizeof(const char* name) {
 #define GNNLM_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
     GNNLM_SZ(gnnlm_gemm_t) GNNLM_SZ(gnnlm_gather_t) GNNLM_SZ(gnnlm_star_attn_t) GNNLM_SZ(gnnlm_chain_attn_t)
     GNNLM_SZ(gnnlm_adaptive_softmax_t) GNNLM_SZ(gnnlm_knn_interp_t) GNNLM_SZ(gnnlm_hgt_layer_t)
-    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t) GNNLM_SZ(gnnlm_ivfpq_scan8_t) GNNLM_SZ(gnnlm_ivfpq_rescore_t) GNNLM_SZ(gnnlm_ivfpq_tau_t) GNNLM_SZ(gnnlm_ivfpq_sumfilter_t) GNNLM_SZ(gnnlm_peer_gather_t) GNNLM_SZ(gnnlm_shards_t)
+    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t) GNNLM_SZ(gnnlm_ivfpq_scan8_t) GNNLM_SZ(gnnlm_ivfpq_rescore_t) GNNLM_SZ(gnnlm_ivfpq_tau_t) GNNLM_SZ(gnnlm_peer_gather_t) GNNLM_SZ(gnnlm_shards_t)
 #undef GNNLM_SZ
     return 0;
 }
@@ -627,7 +627,6 @@ int gnnlm_ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int32_
 int gnnlm_ivfpq_scan8(const gnnlm_ivfpq_scan8_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_scan8(*d, (hipStream_t)stream); }
 int gnnlm_ivfpq_rescore(const gnnlm_ivfpq_rescore_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_rescore(*d, (hipStream_t)stream); }
 int gnnlm_ivfpq_tau(const gnnlm_ivfpq_tau_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_tau(*d, (hipStream_t)stream); }
-int gnnlm_ivfpq_sumfilter(const gnnlm_ivfpq_sumfilter_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_sumfilter(*d, (hipStream_t)stream); }
 int gnnlm_masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, void* stream) {
     return masked_sum_f64(x, mask, n, out, (hipStream_t)stream);
 }
@@ -649,7 +648,7 @@ int gnnlm_hgt_forward(const gnnlm_hgt_t* m, const gnnlm_hgt_io_t* io, void* work
 static const char* kKernelNames[K_COUNT] = {"gemm_nt_f32_kernel", "gather_decode_kernel", "star_attn_kernel",
                                             "chain_attn_kernel", "causal_attn_kernel", "layernorm_kernel",
                                             "row_lse_pick_kernel", "knn_interp_kernel", "misc", "split_planes_kernel",
-                                            "topk_merge_kernel", "ivfpq_scan_kernel", "ivfpq_scan8_kernel", "ivfpq_rescore_kernel", "ivfpq_sums_kernel", "ivfpq_tau_kernel", "ivfpq_sumfilter_kernel"};
+                                            "topk_merge_kernel", "ivfpq_scan_kernel", "ivfpq_scan8_kernel", "ivfpq_rescore_kernel", "ivfpq_sums_kernel", "ivfpq_tau_kernel"};
 const char* gnnlm_kernel_name(int32_t kernel_id) {
     return kernel_id >= 0 && kernel_id < K_COUNT ? kKernelNames[kernel_id] : nullptr;
 }

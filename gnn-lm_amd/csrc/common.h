@@ -31,7 +31,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // Opt-in per-kernel timing with HIP events on the launch stream (bench.py's live roofline).
 enum KernelId { K_GEMM = 0, K_GATHER = 1, K_STAR = 2, K_CHAIN = 3, K_CAUSAL = 4, K_LAYERNORM = 5, K_LSE = 6,
-                K_KNN = 7, K_MISC = 8, K_SPLIT = 9, K_TOPK = 10, K_IVF = 11, K_IVF8 = 12, K_RESCORE = 13, K_IVF8S = 14, K_TAU = 15, K_SUMFILTER = 16, K_COUNT = 17 };
+                K_KNN = 7, K_MISC = 8, K_SPLIT = 9, K_TOPK = 10, K_IVF = 11, K_IVF8 = 12, K_RESCORE = 13, K_IVF8S = 14, K_TAU = 15, K_COUNT = 16 };
 extern unsigned g_prof_mask;
 void prof_start(int kid, hipStream_t s);
 // flops / bytes: algorithmic work of the launch; if scale_dev != null the work is multiplied by

@@ -145,9 +145,6 @@ constexpr int NW = GNNLM_IVF8_NW, NTH = 64 * NW;
 #ifndef GNNLM_IVF8_PF
 #define GNNLM_IVF8_PF 3         // tiles of code bytes in flight per wave (A/B: 4)
 #endif
-#ifndef GNNLM_IVF8_SEXP
-#define GNNLM_IVF8_SEXP 0       // ablation builds of the threshold pass: 1 no histogram atomics, 2 no sum stores
-#endif
 #ifndef GNNLM_IVF8_EXP
 #define GNNLM_IVF8_EXP 0        // ablation builds (no survivors): 1 no code loads, 2 no table fill, 4 no look-ups, 8 no MFMAs, 16 nothing else
 #endif
@@ -166,16 +163,29 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     const int n_groups = min(*p.n_groups, p.max_groups);
     const int per_xcd = (n_groups + 7) >> 3;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
+    // The first group of a workgroup is b / 8; the next ones come from the XCD's counter (work_ctr: lists of different lengths
+    // stay balanced) or, without one, by striding
     bool first = true;
-    for (int gi = (int)(blockIdx.x >> 3); gi < per_xcd; gi += (int)(gridDim.x >> 3)) {
+    int gi = (int)(blockIdx.x >> 3);
+    int* next_s = reinterpret_cast<int*>(smem + TAB_BYTES);                   // (free between two groups)
+    for (;;) {
+    if (!first) {
+        __syncthreads();                                                     // the previous group's tables, totals and histograms are done with
+        if (p.work_ctr) {
+            if (tid == 0) *next_s = (int)(gridDim.x >> 3) + atomicAdd(&p.work_ctr[(blockIdx.x & 7) * 16], 1);
+            __syncthreads();
+            gi = *next_s;
+            __syncthreads();
+        } else gi += (int)(gridDim.x >> 3);
+    }
+    first = false;
+    if (gi >= per_xcd) break;
     const int grp = (int)(blockIdx.x & 7) * per_xcd + gi;
     if (grp >= n_groups) break;
     const int list = p.grp_list[grp];
     if (list < 0) continue;
     const int64_t lo = p.list_off[list], hi = p.list_off[list + 1];
     if (hi <= lo) continue;
-    if (!first) __syncthreads();                                             // the previous group's tables, totals and histograms are done with
-    first = false;
     uint32_t* wbuf = reinterpret_cast<uint32_t*>(smem + TAB_BYTES + 512) + wave * WAVE_CAP;   // this wave's survivors: (row - lo) << 3 | query slot
     const int* gq = p.grp_q + (int64_t)grp * QG;
     uint2* surv = reinterpret_cast<uint2*>(p.surv);                           // {row, list} per survivor
@@ -223,14 +233,9 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     const int qs_lane = lane < QG ? gq[lane] : -1;                           // lanes 0..7: the query of slot `lane` (flush of the survivors)
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem + TAB_BYTES);          // SUMS: [8 queries][HIST_BINS] counters
     uint32_t* hist_j = nullptr;                                              // this lane's query (lanes j < 8 of a live query)
-    uint16_t* sum_j = nullptr;                                               // ... and where its sums are kept (threshold pass with out_sums)
     if (SUMS) {
         for (int e = tid; e < QG * HIST_BINS; e += NTH) hist[e] = 0u;
         if (qj >= 0 && p.grp_out[(int64_t)grp * QG + j] >= 0) hist_j = hist + j * HIST_BINS;
-        if (qj >= 0 && p.out_sums) {
-            const int64_t sb = p.grp_sum[grp];
-            if (sb >= 0) sum_j = p.out_sums + sb + 16 * j + 4 * (lane >> 4);   // + 128 u per tile: the lane's four keys of query slot j
-        }
     }
     if (!SUMS && qj >= 0) T = filter_threshold(p.qmeta, qj, p.coarse[(int64_t)qj * p.ld_coarse + list], p.tau[qj]);
 #if GNNLM_IVF8_EXP & 32
@@ -390,7 +395,6 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         if (SUMS) {
             // the lane's four keys (rows 4 g .. 4 g + 3 of the tile) of query j -> four counters of the query's histogram (LDS
             // atomics without return: nothing waits for them); the two edge tiles count the list's own rows only
-#if !(GNNLM_IVF8_SEXP & 1)
             if (hist_j) {
                 const int r0 = 16 * u + 4 * g - row_shift;
                 const bool edge = u == 0 || u == nt - 1;
@@ -398,14 +402,6 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
                 for (int r = 0; r < 4; ++r)
                     if (!edge || (unsigned)(r0 + r) < (unsigned)len) atomicAdd(&hist_j[(acc[r] + 128 * 64) >> HIST_SHIFT], 1u);
             }
-#endif
-#if !(GNNLM_IVF8_SEXP & 2)
-            if (sum_j)                                                       // (rows of the edge tiles outside the list: sumfilter skips them)
-                *reinterpret_cast<u32x2*>(sum_j + 128 * u) = u32x2{(uint32_t)(acc[0] + 128 * 64) | (uint32_t)(acc[1] + 128 * 64) << 16,
-                                                                   (uint32_t)(acc[2] + 128 * 64) | (uint32_t)(acc[3] + 128 * 64) << 16};
-#else
-            if (sum_j && acc[0] == 0x12345) *sum_j = 1;
-#endif
         } else {
             // four compares straight into scalar masks; a tile with survivors (about every second one) appends them mask by mask.
             // The two edge tiles of the list share rows with the neighbouring lists: they take the same steps with the range test
@@ -488,74 +484,6 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     __syncthreads();
     write_entries(lane < QG ? wtot[wave * QG + lane] : 0);
     }
-}
-
-// The filter over STORED sums (threshold pass with out_sums): one workgroup per group of that pass; a thread takes 16 bytes = the
-// sums of 8 keys of one query slot per step; survivors are staged per slot in LDS and appended with one global atomic per slot.
-__global__ __launch_bounds__(1024) void ivfpq_sumfilter_kernel(gnnlm_ivfpq_sumfilter_t p) {
-    constexpr int CAPS = 2048;                                               // staged entries per slot (a step adds at most 1024)
-    __shared__ uint32_t buf[QG][CAPS];
-    __shared__ int cnt[QG], gbase[QG], Ts_s[QG], qs_s[QG];
-    const int tid = threadIdx.x;
-    const int grp = blockIdx.x;
-    if (grp >= min(*p.n_groups, p.max_groups)) return;
-    const int list = p.grp_list[grp];
-    const int64_t sb = p.grp_sum[grp];
-    if (list < 0 || sb < 0) return;
-    const int64_t lo = p.list_off[list], hi = p.list_off[list + 1];
-    if (hi <= lo) return;
-    const int nt = (int)(((hi - 1) >> 4) - (lo >> 4)) + 1;
-    const int row_shift = (int)(lo & 15), len = (int)(hi - lo);
-    if (tid < QG) {
-        const int q = p.grp_q[(int64_t)grp * QG + tid];
-        int Ts = 1 << 20;
-        if (q >= 0) {
-            const int T = filter_threshold(p.qmeta, q, p.coarse[(int64_t)q * p.ld_coarse + list], p.tau[q]);
-            Ts = (T >= (1 << 20) ? (1 << 20) : (T <= -(1 << 20) ? -(1 << 20) : T)) + 128 * 64;   // against the stored sum_u
-        }
-        Ts_s[tid] = Ts;
-        qs_s[tid] = q;
-        cnt[tid] = 0;
-    }
-    __syncthreads();
-    const uint4* src = reinterpret_cast<const uint4*>(p.sums + sb);
-    uint2* surv = reinterpret_cast<uint2*>(p.surv);
-    auto flush = [&]() {                                                     // (every thread; cnt is stable)
-        if (tid < QG) gbase[tid] = (cnt[tid] > 0 && qs_s[tid] >= 0) ? atomicAdd(&p.surv_cnt[(int64_t)qs_s[tid] * SURV_CNT_STRIDE], cnt[tid]) : 0;
-        __syncthreads();
-#pragma unroll
-        for (int sl = 0; sl < QG; ++sl) {
-            const int n = cnt[sl], q = qs_s[sl];
-            const int64_t b = gbase[sl];
-            if (q < 0) continue;
-            for (int e = tid; e < n; e += 1024)
-                if (b + e < p.cap) surv[(int64_t)q * p.cap + b + e] = uint2{(uint32_t)(lo + buf[sl][e]), (uint32_t)list};
-        }
-        __syncthreads();
-        if (tid < QG) cnt[tid] = 0;
-        __syncthreads();
-    };
-    const int chunks = nt * 16;                                              // 16-byte chunks: (tile, slot, half)
-    for (int c0 = 0; c0 < chunks; c0 += 1024) {
-        const int c = c0 + tid;
-        if (c < chunks) {
-            const int sl = (c >> 1) & 7, r0 = (c >> 4) * 16 + (c & 1) * 8 - row_shift;
-            const int Ts = Ts_s[sl];
-            const uint4 v = src[c];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int su = (int)((w[e >> 1] >> (16 * (e & 1))) & 0xffffu);
-                if (su >= Ts && (unsigned)(r0 + e) < (unsigned)len) buf[sl][atomicAdd(&cnt[sl], 1)] = (uint32_t)(r0 + e);
-            }
-        }
-        __syncthreads();
-        bool full = false;
-#pragma unroll
-        for (int sl = 0; sl < QG; ++sl) full |= cnt[sl] > CAPS - 1024;
-        if (full) flush();
-    }
-    flush();
 }
 
 // Threshold from the histograms of a query's D dense lists (written by the SUMS pass): a LOWER bound of its k-th best exact
@@ -728,7 +656,6 @@ int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream) {
                   "ivfpq_scan8: null operand");
     GNNLM_REQUIRE(d.M == 64 && (uintptr_t)d.tiles % 16 == 0 && (uintptr_t)d.qlut % 4 == 0, "ivfpq_scan8: need M = 64, aligned images");
     GNNLM_REQUIRE(!d.out_hist || d.grp_out, "ivfpq_scan8: out_hist needs grp_out");
-    GNNLM_REQUIRE(!d.out_sums || (d.out_hist && d.grp_sum && (uintptr_t)d.out_sums % 8 == 0), "ivfpq_scan8: out_sums needs the threshold pass and grp_sum");
     GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<false>, SCAN_LDS);
     GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<true>, SUMS_LDS);
     ProfScope prof(d.out_hist ? K_IVF8S : K_IVF8, stream, 0.0, 0.0);   // work figures are device-side (list lengths): bench.py computes them
@@ -738,18 +665,6 @@ int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream) {
     const int64_t grid = std::min<int64_t>(8 * cdiv((int64_t)d.max_groups, (int64_t)8), 8 * cdiv((int64_t)std::max(cus, 8), (int64_t)8));   // persistent: one per CU
     if (d.out_hist) hipLaunchKernelGGL(ivfpq_scan8_kernel<true>, dim3((unsigned)grid), dim3(NTH), SUMS_LDS, stream, d);
     else hipLaunchKernelGGL(ivfpq_scan8_kernel<false>, dim3((unsigned)grid), dim3(NTH), SCAN_LDS, stream, d);
-    GNNLM_LAUNCH_CHECK();
-    return OK;
-}
-
-int ivfpq_sumfilter(const gnnlm_ivfpq_sumfilter_t& d, hipStream_t stream) {
-    GNNLM_REQUIRE(d.max_groups >= 0, "ivfpq_sumfilter: bad group count");
-    if (d.max_groups == 0) return OK;
-    GNNLM_REQUIRE(d.sums && d.grp_sum && d.list_off && d.grp_list && d.grp_q && d.n_groups && d.qmeta && d.coarse && d.tau && d.surv &&
-                      d.surv_cnt && d.cap > 0 && (uintptr_t)d.sums % 16 == 0,
-                  "ivfpq_sumfilter: null operand or misaligned sums");
-    ProfScope prof(K_SUMFILTER, stream, 0.0, 0.0);
-    hipLaunchKernelGGL(ivfpq_sumfilter_kernel, dim3((unsigned)d.max_groups), dim3(1024), 0, stream, d);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

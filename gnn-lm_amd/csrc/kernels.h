@@ -21,7 +21,6 @@ int ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int M, uint8
 int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream);
 int ivfpq_rescore(const gnnlm_ivfpq_rescore_t& d, hipStream_t stream);
 int ivfpq_tau(const gnnlm_ivfpq_tau_t& d, hipStream_t stream);
-int ivfpq_sumfilter(const gnnlm_ivfpq_sumfilter_t& d, hipStream_t stream);
 
 int gemm_nt(const GemmParams& p, hipStream_t stream);
 // big-tile split-bf16 path (gemm_split.hip): taken by gemm_nt for precision != 0 when the problem fills the chip

@@ -131,7 +131,7 @@ class IVFPQIndex:
     LABEL_BITS = 24                                                          # payload = id << 24 | label (ids < 2^39, labels < 2^24)
 
     def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=None, cand_cap=16384,
-                 score_bytes=6 << 30, scan=None, reuse_sums=True, sum_bytes=8 << 30):
+                 score_bytes=6 << 30, scan=None):
         self.R, self.coarse, self.pq = R, coarse, pq                         # [d, d], [nlist, d], [M, 256, dsub]  f32
         self.list_off, self.list_ids, self.list_codes = list_off, list_ids, list_codes   # i64 [nlist+1], i64 [N], u8 [N, M]
         self.nprobe, self.cosine, self.dense_probes, self.cand_cap = nprobe, cosine, dense_probes, cand_cap
@@ -156,16 +156,6 @@ class IVFPQIndex:
         # bound a little loose, 6 lists give the tighter threshold (fewer survivors to re-score) for less time
         if self.dense_probes is None:
             self.dense_probes = 6 if self.tiles is not None else 2
-        # the threshold pass keeps the integer sums of its lists (uint16 per (query, key)) and the filter takes those lists from
-        # the stored sums instead of scanning them again; a (query, list) segment holds `sum_rows` rows, longer lists (the tail of
-        # a skewed index) are scanned twice as before.  sum_bytes bounds the buffer of one query block.
-        self.sum_rows, self.sum_bytes = 0, sum_bytes
-        if self.tiles is not None:
-            lens = list_off[1:] - list_off[:-1]
-            rows16 = torch.where(lens > 0, (((list_off[1:] - 1) >> 4) - (list_off[:-1] >> 4) + 1) << 4, torch.zeros_like(lens))
-            self.list_rows16 = rows16
-            mean16 = -(-int(2 * self.ntotal / max(self.nlist, 1)) // 16) * 16 + 32
-            self.sum_rows = min(int(rows16.max().item()), mean16) if reuse_sums else 0
         self.stats = {}                                                      # device-side work counters of the last search (bench.py)
 
     def attach_vals(self, vals):
@@ -382,15 +372,15 @@ class IVFPQIndex:
         ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=False, row_ncols=cc.clamp(max=cap))
         return cc
 
-    def _scan8(self, qlut, qmeta, cs, groups, tau=None, surv=None, hist=None, sums=None):
+    def _scan8(self, qlut, qmeta, cs, groups, tau=None, surv=None, hist=None):
         d = _lib.gnnlm_ivfpq_scan8_t()
         d.tiles, d.list_off, d.M = self.tiles.data_ptr(), self.list_off.data_ptr(), self.M
         d.qlut, d.qmeta, d.coarse, d.ld_coarse = qlut.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0)
         d.grp_list, d.grp_q, d.n_groups, d.max_groups = groups[0].data_ptr(), groups[1].data_ptr(), groups[2].data_ptr(), groups[3]
+        ctr = torch.zeros(8, 16, device=self.device, dtype=torch.int32)          # the persistent workgroups' work counters (one per XCD)
+        d.work_ctr = ctr.data_ptr()
         if hist is not None:
             d.out_hist, d.grp_out = hist.data_ptr(), groups[4].data_ptr()
-            if sums is not None:
-                d.out_sums, d.grp_sum = sums[0].data_ptr(), sums[1].data_ptr()
         else:
             d.tau, d.surv, d.surv_cnt, d.cap = tau.data_ptr(), surv[0].data_ptr(), surv[1].data_ptr(), surv[0].shape[1]
         _lib.call_desc("gnnlm_ivfpq_scan8", d)
@@ -404,17 +394,7 @@ class IVFPQIndex:
         nq, cap = pv.shape[0], cv.shape[1]
         qlut, qmeta = ops.ivfpq_quantize_lut(lut, self.M)
         hist = torch.empty(nq, dense, 1024, device=dev, dtype=torch.int32)      # per (query, list): sum_u >> 4 counted on the device
-        g1 = self._groups(pi[:, :dense], seg=1024)
-        gcap = min(nq * dense, g1[3])                                          # groups in use <= pairs and <= pairs / 8 + nlist + 1
-        keep = self.sum_rows > 0 and 16 * gcap * self.sum_rows <= self.sum_bytes
-        sums = None
-        if keep:
-            # the pass also KEEPS the sums of every group whose list fits a segment: [group][tile][8 query slots][16 keys] uint16
-            sbuf = torch.empty(gcap * self.sum_rows * 8, device=dev, dtype=torch.int16)
-            fits = (g1[0] >= 0) & (self.list_rows16[g1[0].clamp(min=0).long()] <= self.sum_rows)
-            grp_sum = torch.where(fits, torch.arange(g1[3], device=dev) * (self.sum_rows * 8), torch.full((g1[3],), -1, device=dev, dtype=torch.int64))
-            sums = (sbuf, grp_sum)
-        self._scan8(qlut, qmeta, cs, g1, hist=hist, sums=sums)
+        self._scan8(qlut, qmeta, cs, self._groups(pi[:, :dense], seg=1024), hist=hist)
         tau = torch.empty(nq, device=dev, dtype=torch.float32)
         t = _lib.gnnlm_ivfpq_tau_t()
         t.hist, t.D = hist.data_ptr(), dense
@@ -423,21 +403,9 @@ class IVFPQIndex:
         _lib.call_desc("gnnlm_ivfpq_tau", t)
         surv = torch.empty(nq, cap, 2, device=dev, dtype=torch.int32)
         sc16 = torch.zeros(nq, 16, device=dev, dtype=torch.int32)              # one 64-byte line per counter (column 0)
-        pi2 = pi
-        if keep:                                                               # the dense lists: from the stored sums ...
-            f = _lib.gnnlm_ivfpq_sumfilter_t()
-            f.sums, f.grp_sum, f.list_off = sbuf.data_ptr(), grp_sum.data_ptr(), self.list_off.data_ptr()
-            f.grp_list, f.grp_q, f.n_groups, f.max_groups = g1[0].data_ptr(), g1[1].data_ptr(), g1[2].data_ptr(), gcap
-            f.qmeta, f.coarse, f.ld_coarse, f.tau = qmeta.data_ptr(), cs.data_ptr(), cs.stride(0), tau.data_ptr()
-            f.surv, f.surv_cnt, f.cap = surv.data_ptr(), sc16.data_ptr(), cap
-            _lib.call_desc("gnnlm_ivfpq_sumfilter", f)
-            pd = pi[:, :dense]
-            stored = (pd >= 0) & (self.list_rows16[pd.clamp(min=0)] <= self.sum_rows)
-            pi2 = pi.clone()
-            pi2[:, :dense] = torch.where(stored, torch.full_like(pd, -1), pd)
-        g2 = self._groups(pi2)
+        g2 = self._groups(pi)
         self.stats["groups"] = self.stats.get("groups", 0) + g2[2][0]
-        self._scan8(qlut, qmeta, cs, g2, tau=tau, surv=(surv, sc16))          # ... every other (query, list) pair: scanned
+        self._scan8(qlut, qmeta, cs, g2, tau=tau, surv=(surv, sc16))
         sc = sc16[:, 0]
         r = _lib.gnnlm_ivfpq_rescore_t()
         r.codes, r.payload, r.M = self.list_codes.data_ptr(), self.payload.data_ptr(), self.M

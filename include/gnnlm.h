@@ -318,7 +318,6 @@ int gnnlm_ivfpq_pack_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M,
  *                              reaches the integer image of tau[q] -- a superset of {score > tau[q]}
  *   gnnlm_ivfpq_tau            the threshold itself: a lower bound of the k-th best score from histograms of the integer sums of
  *                              the first D lists (gnnlm_ivfpq_scan8 with out_hist), replacing the float32 dense round + its k-selection
- *   gnnlm_ivfpq_sumfilter      the same filter for the D lists of the threshold pass, from the sums that pass stored
  *   gnnlm_ivfpq_rescore        exact scores of the survivors (summation order of gnnlm_ivfpq_scan's packed kernel),
  *                              score > tau[q] -> (cand_val, cand_id = payload[row]); cand_cnt[q] counts all of them
  * ---------------------------------------------------------------------------------------------- */
@@ -337,24 +336,12 @@ typedef struct gnnlm_ivfpq_scan8 {
      * histogrammed per query (1024 bins of 16) and written to out_hist[grp_out[group * 8 + j] .. + 1024) for query j of the group
      * (grp_out < 0: skipped; every (query, list) pair belongs to exactly one group: plain stores) */
     uint32_t* out_hist;  const int64_t* grp_out;
-    /* ... and, with out_sums != NULL, the sums themselves (uint16) are kept, group-major: key (tile u, row i) of the list for
-     * query slot j of the group at out_sums[grp_sum[group] + (8 u + j) * 16 + i] (tile-relative: the first tile starts at the
-     * 16-row boundary below the list; a wave's store covers 256 contiguous bytes; grp_sum < 0: not kept).
-     * gnnlm_ivfpq_sumfilter then filters these groups from the stored sums: no second scan of their lists */
-    uint16_t* out_sums;  const int64_t* grp_sum;
+    /* the workgroups are persistent (one per CU); with work_ctr != NULL ([8, 16] int32, ZEROED by the caller before every call:
+     * one counter per XCD, one 64-byte line each) a workgroup fetches its next group from its XCD's counter -- lists of very
+     * different lengths stay balanced; NULL: static striding */
+    int32_t* work_ctr;
 } gnnlm_ivfpq_scan8_t;
 int gnnlm_ivfpq_scan8(const gnnlm_ivfpq_scan8_t* desc, void* stream);
-/* The filter of gnnlm_ivfpq_scan8 applied to STORED sums: one workgroup per group of the threshold pass (same task table); groups
- * with grp_sum < 0 are skipped (the caller leaves their pairs to gnnlm_ivfpq_scan8).  Same threshold arithmetic, same survivor
- * records, same counters. */
-typedef struct gnnlm_ivfpq_sumfilter {
-    const uint16_t* sums;  const int64_t* grp_sum;
-    const int64_t* list_off;
-    const int32_t* grp_list;  const int32_t* grp_q;  const int32_t* n_groups;  int32_t max_groups;
-    const float* qmeta;  const float* coarse;  int64_t ld_coarse;  const float* tau;
-    uint32_t* surv;  int32_t* surv_cnt;  int32_t cap;
-} gnnlm_ivfpq_sumfilter_t;
-int gnnlm_ivfpq_sumfilter(const gnnlm_ivfpq_sumfilter_t* desc, void* stream);
 /* tau[q] = a lower bound of query q's k-th best score over its first D probed lists, from the threshold pass's histograms
  * ([n, D, 1024] uint32; list d of query q = probe_list[q, d] with bias probe_bias[q, d]): at least k keys of those lists score
  * above it; -inf if they hold fewer than k keys */

@@ -277,69 +277,6 @@ def test_mfma_search_identical_to_f32_scan(dev, small_index):
     _same_search(mixed, f32, many, 1024)
 
 
-def test_dense_lists_filtered_from_stored_sums(dev, small_index):
-    """The threshold pass keeps the integer sums of its lists and gnnlm_ivfpq_sumfilter filters those lists from them: the
-    survivors are exactly the ones gnnlm_ivfpq_scan8 finds by scanning the lists again; lists longer than a segment (and a
-    sum budget that does not fit) fall back to the second scan; the search result is the same either way."""
-    from gnnlm_amd import _lib, ops
-    from gnnlm_amd.ivfpq import IVFPQIndex
-    index, q = small_index
-    args = (index.R, index.coarse, index.pq, index.list_off, index.list_ids, index.list_codes)
-    assert index.sum_rows > 0
-    qd = torch.from_numpy(q).to(dev)
-    nq, D, cap = q.shape[0], 3, 32768
-    cs, pi, lut = _prepare(index, qd, dev)
-    qlut, qmeta = ops.ivfpq_quantize_lut(lut, 64)
-    rows16 = index.list_rows16.cpu().numpy()
-    pi_h = pi.cpu().numpy()
-    for seg_rows in (int(rows16.max()), int(np.sort(rows16)[len(rows16) // 2])):          # every list fits / half of them do
-        g1 = index._groups(pi[:, :D], seg=1024)
-        hist = torch.zeros(nq, D, 1024, device=dev, dtype=torch.int32)
-        sbuf = torch.zeros(g1[3] * seg_rows * 8, device=dev, dtype=torch.int16)
-        fits = (g1[0] >= 0) & (index.list_rows16[g1[0].clamp(min=0).long()] <= seg_rows)
-        grp_sum = torch.where(fits, torch.arange(g1[3], device=dev) * (seg_rows * 8), torch.full((g1[3],), -1, device=dev, dtype=torch.int64))
-        index._scan8(qlut, qmeta, cs, g1, hist=hist, sums=(sbuf, grp_sum))
-        hist0 = torch.zeros_like(hist)
-        index._scan8(qlut, qmeta, cs, g1, hist=hist0)
-        assert torch.equal(hist, hist0)                                                    # keeping the sums changes nothing else
-        rs = np.random.RandomState(seg_rows)
-        tau = torch.from_numpy(np.quantile(cs.cpu().numpy(), 0.9, axis=1).astype(np.float32) + 0.05 * rs.rand(nq).astype(np.float32)).to(dev)
-        tau[0], tau[1] = float("-inf"), float("inf")
-        # (a) from the stored sums
-        surv_a = torch.zeros(nq, cap, 2, device=dev, dtype=torch.int32)
-        cnt_a = torch.zeros(nq, 16, device=dev, dtype=torch.int32)
-        f = _lib.gnnlm_ivfpq_sumfilter_t()
-        f.sums, f.grp_sum, f.list_off = sbuf.data_ptr(), grp_sum.data_ptr(), index.list_off.data_ptr()
-        f.grp_list, f.grp_q, f.n_groups, f.max_groups = g1[0].data_ptr(), g1[1].data_ptr(), g1[2].data_ptr(), g1[3]
-        f.qmeta, f.coarse, f.ld_coarse, f.tau = qmeta.data_ptr(), cs.data_ptr(), cs.stride(0), tau.data_ptr()
-        f.surv, f.surv_cnt, f.cap = surv_a.data_ptr(), cnt_a.data_ptr(), cap
-        _lib.call_desc("gnnlm_ivfpq_sumfilter", f)
-        # (b) by scanning the same (query, list) pairs: those whose list fits a segment
-        pd = pi[:, :D].clone()
-        pd[index.list_rows16[pd.clamp(min=0)] > seg_rows] = -1
-        surv_b = torch.zeros(nq, cap, 2, device=dev, dtype=torch.int32)
-        cnt_b = torch.zeros(nq, 16, device=dev, dtype=torch.int32)
-        index._scan8(qlut, qmeta, cs, index._groups(pd), tau=tau, surv=(surv_b, cnt_b))
-        ca, cb = cnt_a[:, 0].cpu().numpy(), cnt_b[:, 0].cpu().numpy()
-        assert np.array_equal(ca, cb) and ca[1] == 0 and ca[0] == sum(int(index.list_off[l + 1] - index.list_off[l]) for l in pi_h[0, :D] if rows16[l] <= seg_rows)
-        sa, sb = surv_a.cpu().numpy().astype(np.int64), surv_b.cpu().numpy().astype(np.int64)
-        for r in range(nq):
-            n = min(int(ca[r]), cap)
-            key = lambda x: np.sort(x[:n, 0] * 4096 + x[:n, 1])
-            assert np.array_equal(key(sa[r]), key(sb[r])), r
-    # the search: with the sums kept (default), with segments that hold only the shorter lists, without
-    short = IVFPQIndex(*args, nprobe=9)
-    short.sum_rows = int(np.sort(rows16)[len(rows16) // 2])
-    none = IVFPQIndex(*args, nprobe=9, reuse_sums=False)
-    tiny_budget = IVFPQIndex(*args, nprobe=9, sum_bytes=1 << 10)
-    assert none.sum_rows == 0
-    for k in (1024, 64):
-        v0, i0 = index.search(q, k)
-        for other in (short, none, tiny_budget):
-            v1, i1 = other.search(q, k)
-            assert np.array_equal(v0, v1) and np.array_equal(i0, i1)
-
-
 def test_labels_travel_with_the_search(dev, small_index):
     """attach_vals: the search returns vals[ids] with the neighbours (knn/knn_model.py:198 without the gather), ids and
     scores unchanged, -1 padding reads the last label like numpy's wrap-around."""

@@ -10,8 +10,7 @@ from gnnlm_amd.synthetic import synthetic_ivfpq_index
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     N = int(os.environ.get("N", 103227021)); n = int(os.environ.get("NQ", 8192)); k = int(os.environ.get("K", 1024))
-    idx = synthetic_ivfpq_index(N, 1024, 4096, 64, dev, dense_probes=(int(os.environ["DENSE"]) if "DENSE" in os.environ else None), cand_cap=int(os.environ.get("CAP", 16384)),
-                               reuse_sums=not os.environ.get("NOREUSE"))
+    idx = synthetic_ivfpq_index(N, 1024, 4096, 64, dev, skew=float(os.environ.get("SKEW", 0.0)), dense_probes=(int(os.environ["DENSE"]) if "DENSE" in os.environ else None), cand_cap=int(os.environ.get("CAP", 16384)))
     if os.environ.get("PLAIN"):
         idx.packed_codes = None                            # the row-major kernels (A/B)
     torch.manual_seed(0)
@@ -23,7 +22,7 @@ if __name__ == "__main__":
     prof = _lib.profile_end()
     st = {k_: (float(v_.item()) if torch.is_tensor(v_) else v_) for k_, v_ in idx.stats.items()}
     print(f"scan={'mfma' if idx.tiles is not None else 'f32'} cand_cap={idx.cand_cap} pairs/query={st['pairs'] / n:.0f} survivors/query={st['survivors'] / n:.0f} "
-          f"candidates/query={st['candidates'] / n:.0f} filter groups={st.get('groups', 0):.0f}")
+          f"candidates/query={st['candidates'] / n:.0f} filter groups={st.get('groups', 0):.0f} searched again={st['requeried']}")
     print(f"IVF-PQ search: {n} queries, k={k}, nprobe={idx.nprobe}, N={N}: {dt * 1e3:.1f} ms = {n / dt:.0f} queries/s")
     for kn, e in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
         print(f"   {kn:24s} {e['launches']:4d} launches {e['total_ms']:9.2f} ms")
