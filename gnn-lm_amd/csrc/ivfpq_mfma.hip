@@ -560,47 +560,55 @@ __global__ __launch_bounds__(1024) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore
     const int n = min(p.surv_cnt[q * SURV_CNT_STRIDE], p.cap);
     if (tid == 0) ccnt = 0;
     const uint2* surv = reinterpret_cast<const uint2*>(p.surv) + q * p.cap;
-    // the first two survivors' code rows are requested before the table arrives; from then on a thread always has the rows of
-    // its next two survivors in flight (random 64-byte reads: an HBM round trip is longer than one survivor's 64 look-ups)
-    uint32_t rowA = 0u, listA = 0u, rowB = 0u, listB = 0u;
-    v4u crA[M / 16], crB[M / 16];
+    // Three loads deep, in an order that never drains the queue (s_waitcnt vmcnt counts in issue order): survivor i's code row and
+    // bias are consumed while row i + 1 and the RECORD {row, list} of survivor i + 2 are in flight; a step issues record i + 3 first,
+    // then bias and row i + 2 (their addresses come from a record that is one step old: waiting for it leaves the younger loads in
+    // flight).  Over a loop's back edge the compiler's wait insertion loses the issue order and drains the queue at the loop head
+    // (vmcnt(0)); the first 16 steps (16384 survivors: every capacity the search uses by default) are therefore unrolled -- straight-
+    // line code, exact waits, no copies between the register sets.  Indices beyond n are clamped (unconditional loads).
+    const int last = max(n - 1, 0);
+    auto record = [&](int e, uint2& rec) __attribute__((always_inline)) { rec = surv[min(e, last)]; };
+    auto rowload = [&](const uint2& rec, v4u (&cr)[M / 16], float& bias) __attribute__((always_inline)) {
+        bias = p.coarse[q * p.ld_coarse + rec.y];                           // (first: the youngest loads of a step are the row's)
+        const v4u* crow = reinterpret_cast<const v4u*>(p.codes + (int64_t)rec.x * M);
 #pragma unroll
-    for (int c16 = 0; c16 < M / 16; ++c16) crA[c16] = crB[c16] = v4u{0u, 0u, 0u, 0u};
-    auto fetch = [&](int e, uint32_t& r32, uint32_t& l32, v4u (&cr)[M / 16]) {
-        if (e < n) {
-            const uint2 sv = surv[e];
-            r32 = sv.x;
-            l32 = sv.y;
-            const v4u* crow = reinterpret_cast<const v4u*>(p.codes + (int64_t)r32 * M);
-#pragma unroll
-            for (int c16 = 0; c16 < M / 16; ++c16) cr[c16] = crow[c16];
-        }
+        for (int c16 = 0; c16 < M / 16; ++c16) cr[c16] = crow[c16];
     };
-    fetch(tid, rowA, listA, crA);
-    fetch(tid + NT, rowB, listB, crB);
+    uint2 recC = uint2{0u, 0u}, recD = recC;                                // records in flight (alternating)
+    v4u cr0[M / 16], cr1[M / 16];                                           // code rows: two register sets, alternating -- no copies
+    float bias0 = 0.f, bias1 = 0.f;
+    uint32_t rid0 = 0u, rid1 = 0u;
     if (n > 0) {
         const float4* src = reinterpret_cast<const float4*>(p.lut + q * p.ld_lut);
         float4* dst = reinterpret_cast<float4*>(rtab);
         for (int e = tid; e < M * 64; e += NT) dst[e] = src[e];
+        uint2 r0, r1;
+        record(tid, r0);
+        record(tid + NT, r1);
+        record(tid + 2 * NT, recC);
+        rowload(r0, cr0, bias0);
+        rid0 = r0.x;
+        rowload(r1, cr1, bias1);
+        rid1 = r1.x;
     }
     __syncthreads();
     const float tau = p.tau[q];
     const uint8_t* cb = reinterpret_cast<const uint8_t*>(cdw + tid);        // byte m of the row: cb[(m >> 2) * 4 * NT + (m & 3)]
-    for (int e = tid; e < n; e += NT) {
-        const int64_t row = rowA;
-        const uint32_t lst = listA;
+    // one survivor: its row (set `cr`) -> LDS, the next loads issued (record i + 3 into rec_new, then row i + 2 -- named by rec_old,
+    // which arrived a step ago -- into the set just freed), then the 64 look-ups
+    auto one = [&](int e, v4u (&cr)[M / 16], float& bset, uint32_t& rset, const uint2& rec_old, uint2& rec_new) __attribute__((always_inline)) {
+        const int64_t row = rset;
+        const float bias = bset;
 #pragma unroll
         for (int c16 = 0; c16 < M / 16; ++c16) {
-            cdw[(4 * c16 + 0) * NT + tid] = crA[c16].x;
-            cdw[(4 * c16 + 1) * NT + tid] = crA[c16].y;
-            cdw[(4 * c16 + 2) * NT + tid] = crA[c16].z;
-            cdw[(4 * c16 + 3) * NT + tid] = crA[c16].w;
+            cdw[(4 * c16 + 0) * NT + tid] = cr[c16].x;
+            cdw[(4 * c16 + 1) * NT + tid] = cr[c16].y;
+            cdw[(4 * c16 + 2) * NT + tid] = cr[c16].z;
+            cdw[(4 * c16 + 3) * NT + tid] = cr[c16].w;
         }
-        rowA = rowB;
-        listA = listB;
-#pragma unroll
-        for (int c16 = 0; c16 < M / 16; ++c16) crA[c16] = crB[c16];
-        fetch(e + 2 * NT, rowB, listB, crB);
+        record(e + 3 * NT, rec_new);
+        rowload(rec_old, cr, bset);
+        rset = rec_old.x;
         const int rot = (int)(row & 31);
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
@@ -612,17 +620,35 @@ __global__ __launch_bounds__(1024) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore
                 a1 = a1 + rtab[m1 * 256 + cb[(m1 >> 2) * (4 * NT) + (m1 & 3)]];
             }
         }
-        const float score = p.coarse[q * p.ld_coarse + lst] + (a0 + a1);
+        const float score = bias + (a0 + a1);
         if (score > tau) {
             const int pos = atomicAdd(&ccnt, 1);
             if (pos < p.cand_cap) {
                 p.cand_val[q * p.cand_cap + pos] = score;
-                p.cand_id[q * p.cand_cap + pos] = p.payload[row];
-            }
+                p.cand_id[q * p.cand_cap + pos] = row;                       // the payload follows below: a load here would make the loop
+            }                                                                // wait for it AND for the code rows requested before it
         }
+    };
+    int e = tid;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {                                         // 16 steps, straight-line
+        if (e >= n) break;
+        one(e, cr0, bias0, rid0, recC, recD);
+        e += NT;
+        if (e >= n) break;
+        one(e, cr1, bias1, rid1, recD, recC);
+        e += NT;
+    }
+    for (; e < n; e += 2 * NT) {                                             // beyond 16384 survivors (a doubled capacity): the rolled loop
+        one(e, cr0, bias0, rid0, recC, recD);
+        if (e + NT >= n) break;
+        one(e + NT, cr1, bias1, rid1, recD, recC);
     }
     __syncthreads();
     if (tid == 0) p.cand_cnt[q] = ccnt;
+    // rows -> payloads (ids, labels): every thread's loads independent of each other, nothing else in flight
+    const int nc = min(ccnt, p.cand_cap);
+    for (int e = tid; e < nc; e += NT) p.cand_id[q * p.cand_cap + e] = p.payload[p.cand_id[q * p.cand_cap + e]];
 }
 
 }  // namespace

@@ -9,6 +9,7 @@
 // Order: better value first; equal values by ascending id (what a stable argsort of the full row gives), so the
 // result does not depend on the chunking.
 #include <cmath>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -193,6 +194,179 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(TopkParams p) {
     }
 }
 
+// ---- the whole row in ONE chunk (init = 1: the final k-selection of the IVF-PQ search over a few thousand candidates per query,
+// the probe selection over the coarse scores).  No running state to merge with, so select first, sort once: a radix select on the
+// order-preserving integer image of the score (three digit passes: 11 + 11 + 10 bits, histogram in LDS, the digit whose suffix
+// count reaches what is still needed) gives the k-th best value; values tied with it are taken by ascending id (a radix select
+// over the id's digits, only when ties straddle the cut); the selected entries -- exactly min(k, valid) of them -- go to LDS
+// and through one bitonic sort.  Same order as the merge kernel: better value first, equal values by ascending id.
+template <int KP, int EPT>
+__global__ __launch_bounds__(256) void topk_select_kernel(TopkParams p) {
+    constexpr int NT = 256, NB = 2048;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int64_t* id = reinterpret_cast<int64_t*>(smem_raw);                 // [KP]
+    float* val = reinterpret_cast<float*>(id + KP);                     // [KP]
+    __shared__ int hist[NB];
+    __shared__ int wtot[4];
+    __shared__ int dig_s, above_s, cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const float sign = p.largest ? 1.f : -1.f;
+    const float NEG = -INFINITY;
+    const float* srow = p.scores + row * p.ld;
+    const int ncols = p.row_ncols ? min(p.ncols, p.row_ncols[row]) : p.ncols;
+    // column c -> (valid, value, order-preserving key, id); -0 and +0 share a key (they compare equal)
+    auto entry = [&](int c, float& v, uint32_t& key, int64_t& cid) -> bool {
+        v = srow[c] * p.alpha;
+        if (p.col_scale) v *= p.col_scale[c];
+        if (p.col_bias) v += p.col_bias[c];
+        v = v * sign + 0.f;
+        cid = p.ids ? p.ids[row * p.ld_ids + c] : (p.col_ids ? p.col_ids[c] : p.col0 + c);
+        const uint32_t u = __float_as_uint(v);
+        key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        return cid >= 0 && v > NEG;
+    };
+    // the highest digit whose suffix count over hist[0 .. nb) reaches `need` (-1: the whole histogram holds fewer); above_s = the
+    // count of the digits above it.  Thread t owns the 8 bins [8 t, 8 t + 8); suffix sums over lanes by shuffles, over waves in LDS
+    auto pick = [&](int need) -> int {
+        int own[8], mine = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { own[b] = hist[8 * tid + b]; mine += own[b]; }
+        int suf = mine;                                                  // sum over lanes >= lane of this wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_down(suf, d, 64);
+            if (lane + d < 64) suf += o;
+        }
+        if (lane == 0) wtot[wave] = suf;
+        if (tid == 0) { dig_s = -1; above_s = 0; }
+        __syncthreads();
+        for (int w = wave + 1; w < 4; ++w) suf += wtot[w];               // threads >= tid
+        if (suf >= need && suf - mine < need) {                          // the crossing is inside this thread's bins: exactly one thread
+            int acc_ = suf - mine;
+#pragma unroll
+            for (int b = 7; b >= 0; --b) {
+                if (acc_ + own[b] >= need) { dig_s = 8 * tid + b; above_s = acc_; break; }
+                acc_ += own[b];
+            }
+        }
+        __syncthreads();
+        return dig_s;
+    };
+    // The first EPT * 256 columns of the row live in REGISTERS (key and id; every load issued before the first use: one memory
+    // round trip instead of one per pass and step -- the passes are latency-bound otherwise); longer rows take the rest from
+    // memory in every pass.  key 0 = no entry (valid keys are > key(-inf)).
+    uint32_t rkey[EPT];
+    int64_t rid[EPT];
+    {
+        float rv[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int c = tid + e * NT;
+            rv[e] = NEG;
+            rid[e] = -1;
+            if (c < ncols) {
+                rv[e] = srow[c];
+                rid[e] = p.ids ? p.ids[row * p.ld_ids + c] : (p.col_ids ? p.col_ids[c] : p.col0 + c);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int c = tid + e * NT;
+            float x = rv[e] * p.alpha;
+            if (c < ncols) {
+                if (p.col_scale) x *= p.col_scale[c];
+                if (p.col_bias) x += p.col_bias[c];
+            }
+            x = x * sign + 0.f;
+            const uint32_t u = __float_as_uint(x);
+            rkey[e] = (c < ncols && rid[e] >= 0 && x > NEG) ? ((u & 0x80000000u) ? ~u : (u | 0x80000000u)) : 0u;
+        }
+    }
+    auto value_of_key = [](uint32_t key) { return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key); };
+    constexpr int C0 = EPT * NT;                                         // first column that is not in registers
+    uint32_t prefix = 0u, mask = 0u;
+    int need = p.k;
+    bool all = false;                                                    // fewer valid entries than k: everything is selected
+    constexpr int SHIFT[3] = {21, 10, 0}, BITS[3] = {11, 11, 10};
+#pragma unroll
+    for (int ps = 0; ps < 3; ++ps) {
+        for (int e = tid; e < NB; e += NT) hist[e] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (rkey[e] != 0u && (rkey[e] & mask) == prefix) atomicAdd(&hist[(rkey[e] >> SHIFT[ps]) & ((1u << BITS[ps]) - 1u)], 1);
+        for (int c = C0 + tid; c < ncols; c += NT) {
+            float v; uint32_t key; int64_t cid;
+            if (entry(c, v, key, cid) && (key & mask) == prefix) atomicAdd(&hist[(key >> SHIFT[ps]) & ((1u << BITS[ps]) - 1u)], 1);
+        }
+        __syncthreads();
+        const int d = pick(need);
+        if (d < 0) { all = true; break; }                                // (only the first pass can come up short)
+        need -= above_s;
+        prefix |= (uint32_t)d << SHIFT[ps];
+        mask |= ((1u << BITS[ps]) - 1u) << SHIFT[ps];
+        __syncthreads();
+    }
+    // `need` of the entries with key == prefix are still to be taken, by ascending id.  hist[d] of the last pass = how many there are
+    int64_t id_cut = 0x7fffffffffffffffll;
+    if (!all) {
+        const int ties = hist[prefix & ((1u << BITS[2]) - 1u)];
+        __syncthreads();
+        if (ties > need) {                                               // ties straddle the cut: the need-th smallest id among them
+            uint64_t ipre = 0ull, imask = 0ull;
+            int ineed = need;
+            for (int sh = 55; sh >= 0; sh -= 11) {                       // ids are < 2^63: digits of 11 bits from bit 65 down (the top one short)
+                const int s2 = sh < 0 ? 0 : sh;
+                for (int e = tid; e < NB; e += NT) hist[e] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < EPT; ++e)
+                    if (rkey[e] == prefix && ((uint64_t)rid[e] & imask) == ipre)               // (prefix != 0: a real entry)
+                        atomicAdd(&hist[NB - 1 - (int)(((uint64_t)rid[e] >> s2) & (NB - 1))], 1);   // reversed digit: smaller ids are "better"
+                for (int c = C0 + tid; c < ncols; c += NT) {
+                    float v; uint32_t key; int64_t cid;
+                    if (entry(c, v, key, cid) && key == prefix && ((uint64_t)cid & imask) == ipre)
+                        atomicAdd(&hist[NB - 1 - (int)(((uint64_t)cid >> s2) & (NB - 1))], 1);
+                }
+                __syncthreads();
+                const int d = pick(ineed);
+                ineed -= above_s;
+                ipre |= (uint64_t)(NB - 1 - d) << s2;
+                imask |= (uint64_t)(NB - 1) << s2;
+                __syncthreads();
+            }
+            id_cut = (int64_t)ipre;                                      // ids are unique per row: exactly `need` tied entries have id <= id_cut
+        }
+    }
+    if (tid == 0) cnt = 0;
+    for (int e = tid; e < KP; e += NT) { val[e] = NEG; id[e] = (int64_t)0x7fffffffffffffffll; }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        if (rkey[e] == 0u) continue;
+        if (all || rkey[e] > prefix || (rkey[e] == prefix && rid[e] <= id_cut)) {
+            const int pos = atomicAdd(&cnt, 1);
+            if (pos < KP) { val[pos] = value_of_key(rkey[e]); id[pos] = rid[e]; }
+        }
+    }
+    for (int c = C0 + tid; c < ncols; c += NT) {
+        float v; uint32_t key; int64_t cid;
+        if (!entry(c, v, key, cid)) continue;
+        if (all || key > prefix || (key == prefix && cid <= id_cut)) {
+            const int pos = atomicAdd(&cnt, 1);
+            if (pos < KP) { val[pos] = v; id[pos] = cid; }
+        }
+    }
+    __syncthreads();
+    bitonic_sort_desc<NT>(val, id, KP, tid);
+    for (int e = tid; e < p.k; e += NT) {
+        const bool real = val[e] > NEG;
+        p.best_val[row * p.k + e] = real ? sign * val[e] : (p.largest ? NEG : INFINITY);
+        p.best_id[row * p.k + e] = real ? id[e] : (int64_t)-1;
+    }
+}
+
 }  // namespace
 
 int topk_merge(const gnnlm_topk_t& d, hipStream_t stream) {
@@ -204,6 +378,21 @@ int topk_merge(const gnnlm_topk_t& d, hipStream_t stream) {
                  d.k, d.largest, d.init, d.best_val, d.best_id, d.row_ncols, d.ids, d.ld_ids};
     ProfScope prof(K_TOPK, stream, 0.0, 4.0 * (double)d.n * d.ncols + 24.0 * (double)d.n * d.k);
     const dim3 grid((unsigned)d.n), block(256);
+    static const bool merge_only = getenv("GNNLM_TOPK_MERGE_ONLY") != nullptr;       // A/B switch (tests): the merge kernel for everything
+    if (d.init && !merge_only) {                                                      // the whole row at once: select, then one sort
+#define GNNLM_TOPK_SELECT(KP)                                                                                          \
+    {                                                                                                                  \
+        if (d.ncols <= 4096) hipLaunchKernelGGL((topk_select_kernel<KP, 16>), grid, block, (size_t)KP * 12, stream, p); \
+        else hipLaunchKernelGGL((topk_select_kernel<KP, 20>), grid, block, (size_t)KP * 12, stream, p);                \
+    }
+        if (d.k <= 64) GNNLM_TOPK_SELECT(64)
+        else if (d.k <= 256) GNNLM_TOPK_SELECT(256)
+        else if (d.k <= 1024) GNNLM_TOPK_SELECT(1024)
+        else GNNLM_TOPK_SELECT(2048)
+#undef GNNLM_TOPK_SELECT
+        GNNLM_LAUNCH_CHECK();
+        return OK;
+    }
 #define GNNLM_TOPK_LAUNCH(KP)                                                                                    \
     {                                                                                                            \
         const size_t lds = (size_t)2 * KP * 12;                                                                  \
