@@ -379,7 +379,8 @@ int topk_merge(const gnnlm_topk_t& d, hipStream_t stream) {
     ProfScope prof(K_TOPK, stream, 0.0, 4.0 * (double)d.n * d.ncols + 24.0 * (double)d.n * d.k);
     const dim3 grid((unsigned)d.n), block(256);
     static const bool merge_only = getenv("GNNLM_TOPK_MERGE_ONLY") != nullptr;       // A/B switch (tests): the merge kernel for everything
-    if (d.init && !merge_only) {                                                      // the whole row at once: select, then one sort
+    if (d.init && !merge_only && d.ncols <= 16384) {                                  // the whole (not too wide) row at once: select, then one sort;
+                                                                                      // wide first chunks (exact search: 65536 columns) keep the counting pre-pass of the merge kernel: 2 passes over the row, not 4
 #define GNNLM_TOPK_SELECT(KP)                                                                                          \
     {                                                                                                                  \
         if (d.ncols <= 4096) hipLaunchKernelGGL((topk_select_kernel<KP, 16>), grid, block, (size_t)KP * 12, stream, p); \
