@@ -120,6 +120,7 @@ def lib():
         L.gnnlm_ivfpq_pack_lut.argtypes = [vp, i64, i64, i32, vp, vp]
         L.gnnlm_ivfpq_pack_tiles.argtypes = [vp, i64, i32, vp, vp]
         L.gnnlm_ivfpq_quantize_lut.argtypes = [vp, i64, i64, i32, vp, vp, vp]
+        L.gnnlm_ivfpq_build_groups.argtypes = [vp, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp]
         L.gnnlm_hgt_workspace_bytes.argtypes = [vp, vp]
         L.gnnlm_hgt_forward.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
         for nm in ("gnnlm_gemm_nt", "gnnlm_pq_gather_decode", "gnnlm_star_attn", "gnnlm_chain_attn",

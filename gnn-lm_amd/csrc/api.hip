@@ -621,6 +621,10 @@ int gnnlm_ivfpq_pack_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M,
 int gnnlm_ivfpq_pack_tiles(const uint8_t* codes, int64_t N, int32_t M, uint8_t* out, void* stream) {
     return ivfpq_pack_tiles(codes, N, M, out, (hipStream_t)stream);
 }
+int gnnlm_ivfpq_build_groups(const int64_t* probe_list, int64_t ld_probe, int64_t n, int32_t P, int32_t nlist, int64_t seg, int32_t* grp_list,
+                             int32_t* grp_q, int64_t* grp_out, int32_t* n_groups, int32_t* scratch, void* stream) {
+    return ivfpq_build_groups(probe_list, ld_probe, n, P, nlist, seg, grp_list, grp_q, grp_out, n_groups, scratch, (hipStream_t)stream);
+}
 int gnnlm_ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M, uint8_t* qlut, float* qmeta, void* stream) {
     return ivfpq_quantize_lut(lut, ld_lut, n, M, qlut, qmeta, (hipStream_t)stream);
 }

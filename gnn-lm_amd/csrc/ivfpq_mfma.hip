@@ -134,6 +134,52 @@ __device__ __forceinline__ int filter_threshold(const float* __restrict__ qmeta,
     return !(thr == thr) || thr <= -1.0e9f ? -(1 << 30) : (thr >= 1.0e9f ? 0x7fffffff : (int)floorf(thr) - 128 * 64);
 }
 
+// ---- the scan's task table (gnnlm_ivfpq_build_groups): pairs per list, group offsets, scatter.  cnt / fill: [nlist + 1] each
+__global__ __launch_bounds__(256) void groups_fill_kernel(int32_t* grp_list, int32_t* grp_q, int64_t* grp_out, int64_t G, int32_t* scratch, int nlist) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < G) grp_list[e] = -1;
+    if (e < G * QG) { grp_q[e] = -1; if (grp_out) grp_out[e] = -1; }
+    if (e < 2 * (int64_t)(nlist + 1)) scratch[e] = 0;
+}
+__global__ __launch_bounds__(256) void groups_count_kernel(const int64_t* __restrict__ pl, int64_t ld, int64_t n, int P, int nlist, int32_t* cnt) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * P) return;
+    const int64_t l = pl[(e / P) * ld + e % P];
+    if (l >= 0 && l < nlist) atomicAdd(&cnt[l], 1);
+}
+// one workgroup: cnt[l] -> the first group of list l (exclusive prefix of ceil(cnt / 8)), in place; n_groups = the total
+__global__ __launch_bounds__(1024) void groups_scan_kernel(int32_t* cnt, int nlist, int32_t* n_groups) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nlist + 1023) / 1024, lo = tid * per, hi = min(nlist, lo + per);
+    int mine = 0;
+    for (int l = lo; l < hi; ++l) mine += (cnt[l] + QG - 1) / QG;
+    part[tid] = mine;
+    __syncthreads();
+    for (int step = 1; step < 1024; step <<= 1) {                            // inclusive prefix over the threads
+        const int other = tid >= step ? part[tid - step] : 0;
+        __syncthreads();
+        part[tid] += other;
+        __syncthreads();
+    }
+    int at = part[tid] - mine;
+    for (int l = lo; l < hi; ++l) { const int g = (cnt[l] + QG - 1) / QG; cnt[l] = at; at += g; }
+    if (tid == 1023) *n_groups = part[1023];
+}
+__global__ __launch_bounds__(256) void groups_scatter_kernel(const int64_t* __restrict__ pl, int64_t ld, int64_t n, int P, int nlist, int64_t seg,
+                                                             const int32_t* __restrict__ goff, int32_t* fill, int32_t* grp_list, int32_t* grp_q,
+                                                             int64_t* grp_out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * P) return;
+    const int64_t q = e / P, l = pl[q * ld + e % P];
+    if (l < 0 || l >= nlist) return;
+    const int pos = atomicAdd(&fill[l], 1);
+    const int64_t g = goff[l] + pos / QG;
+    grp_list[g] = (int32_t)l;
+    grp_q[g * QG + pos % QG] = (int32_t)q;
+    if (grp_out) grp_out[g * QG + pos % QG] = e * seg;
+}
+
 #define GNNLM_PERM(hi_, lo_, sel_) __builtin_amdgcn_perm((hi_), (lo_), (sel_))
 #ifndef GNNLM_IVF8_NW
 #define GNNLM_IVF8_NW 16         // waves per workgroup of the scan (A/B: 8)
@@ -660,6 +706,23 @@ int ivfpq_pack_tiles(const uint8_t* codes, int64_t N, int M, uint8_t* out, hipSt
     if (threads == 0) return OK;
     GNNLM_REQUIRE(cdiv(threads, (int64_t)256) < (1ll << 31), "ivfpq_pack_tiles: too many rows for one launch");
     hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)cdiv(threads, (int64_t)256)), dim3(256), 0, stream, codes, N, out);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int ivfpq_build_groups(const int64_t* pl, int64_t ld, int64_t n, int P, int nlist, int64_t seg, int32_t* grp_list, int32_t* grp_q,
+                       int64_t* grp_out, int32_t* n_groups, int32_t* scratch, hipStream_t stream) {
+    GNNLM_REQUIRE(n >= 0 && P > 0 && nlist > 0 && n * P < (1ll << 31) && ld >= P, "ivfpq_build_groups: bad shape");
+    GNNLM_REQUIRE(pl && grp_list && grp_q && n_groups && scratch, "ivfpq_build_groups: null operand");
+    const int64_t G = n * P / QG + nlist + 1, pairs = n * P;
+    const int64_t fill = std::max<int64_t>(G * QG, 2 * (int64_t)(nlist + 1));
+    hipLaunchKernelGGL(groups_fill_kernel, dim3((unsigned)cdiv(fill, (int64_t)256)), dim3(256), 0, stream, grp_list, grp_q, grp_out, G, scratch, nlist);
+    if (pairs > 0)
+        hipLaunchKernelGGL(groups_count_kernel, dim3((unsigned)cdiv(pairs, (int64_t)256)), dim3(256), 0, stream, pl, ld, n, P, nlist, scratch);
+    hipLaunchKernelGGL(groups_scan_kernel, dim3(1), dim3(1024), 0, stream, scratch, nlist, n_groups);
+    if (pairs > 0)
+        hipLaunchKernelGGL(groups_scatter_kernel, dim3((unsigned)cdiv(pairs, (int64_t)256)), dim3(256), 0, stream, pl, ld, n, P, nlist, seg, scratch,
+                           scratch + nlist + 1, grp_list, grp_q, grp_out);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

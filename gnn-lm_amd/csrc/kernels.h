@@ -17,6 +17,8 @@ int ivfpq_pack_codes(const uint8_t* codes, int64_t N, int M, uint8_t* out, hipSt
 int ivfpq_pack_lut(const float* lut, int64_t ld_lut, int64_t n, int M, float* out, hipStream_t stream);
 
 int ivfpq_pack_tiles(const uint8_t* codes, int64_t N, int M, uint8_t* out, hipStream_t stream);
+int ivfpq_build_groups(const int64_t* pl, int64_t ld, int64_t n, int P, int nlist, int64_t seg, int32_t* grp_list, int32_t* grp_q,
+                       int64_t* grp_out, int32_t* n_groups, int32_t* scratch, hipStream_t stream);
 int ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int M, uint8_t* qlut, float* qmeta, hipStream_t stream);
 int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream);
 int ivfpq_rescore(const gnnlm_ivfpq_rescore_t& d, hipStream_t stream);

@@ -28,6 +28,7 @@ orthonormal R gives a valid index).  It runs on the GPU with torch ops -- offlin
 
 PARITY UNPINNED against faiss itself (not in the image, no version pinned): the pin is the numpy restatement
 ``oracle/ivfpq.py`` over the SAME index arrays (tests/test_knn_search_gpu.py)."""
+import ctypes
 import os
 
 import numpy as np
@@ -269,7 +270,21 @@ class IVFPQIndex:
         _lib.call_desc("gnnlm_ivfpq_scan", s)
 
     def _groups(self, pl, seg=None):
-        return build_groups(pl, self.nlist, seg)
+        """The scan's task table on the device (gnnlm_ivfpq_build_groups: histogram, prefix, scatter -- four small launches instead
+        of the ~25 of ``build_groups``, the torch reference of the same table); same tuple."""
+        if not pl.is_cuda or os.environ.get("GNNLM_IVF_TORCH_GROUPS"):
+            return build_groups(pl, self.nlist, seg)
+        nq, P = pl.shape
+        dev = pl.device
+        G = nq * P // 8 + self.nlist + 1
+        grp_list = torch.empty(G, dtype=torch.int32, device=dev)
+        grp_q = torch.empty(G, 8, dtype=torch.int32, device=dev)
+        grp_out = torch.empty(G, 8, dtype=torch.int64, device=dev) if seg is not None else None
+        n_groups = torch.empty(1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(2 * (self.nlist + 1), dtype=torch.int32, device=dev)
+        _lib.call("gnnlm_ivfpq_build_groups", ctypes.c_void_p(pl.data_ptr()), pl.stride(0), nq, P, self.nlist, seg or 0, _lib.ptr(grp_list),
+                  _lib.ptr(grp_q), _lib.ptr(grp_out), _lib.ptr(n_groups), _lib.ptr(scratch), _lib.stream())
+        return (grp_list, grp_q, n_groups, G) if seg is None else (grp_list, grp_q, n_groups, G, grp_out)
 
     def search_device(self, q, k, query_block=None, return_vals=False):
         """The search, on device tensors: (scores [n, k] descending, ids [n, k], -1 padded[, vals [n, k] int32 with

@@ -323,6 +323,13 @@ int gnnlm_ivfpq_pack_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M,
  * ---------------------------------------------------------------------------------------------- */
 int gnnlm_ivfpq_pack_tiles(const uint8_t* codes, int64_t N, int32_t M, uint8_t* out, void* stream);
 int gnnlm_ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int32_t M, uint8_t* qlut, float* qmeta, void* stream);
+/* The task table of gnnlm_ivfpq_scan8 from the probe table: (query, probe) pairs of probe_list [n, P] (row stride ld_probe; -1 = none)
+ * -> groups of up to 8 queries that probe the same list, in list order: grp_list [G], grp_q [G, 8] (-1 padded), n_groups [1]
+ * (device), optionally grp_out [G, 8] = (query * P + probe slot) * seg (the pair's segment of a [n, P, seg] array; NULL: not
+ * wanted).  G = n * P / 8 + nlist + 1 entries must be allocated; scratch: 2 * (nlist + 1) int32.  Which queries of a list share a
+ * group is not specified (positions come from atomics); the searches' results do not depend on it. */
+int gnnlm_ivfpq_build_groups(const int64_t* probe_list, int64_t ld_probe, int64_t n, int32_t P, int32_t nlist, int64_t seg,
+                             int32_t* grp_list, int32_t* grp_q, int64_t* grp_out, int32_t* n_groups, int32_t* scratch, void* stream);
 typedef struct gnnlm_ivfpq_scan8 {
     const uint8_t* tiles;  const int64_t* list_off;  int32_t M;
     const uint8_t* qlut;  const float* qmeta;

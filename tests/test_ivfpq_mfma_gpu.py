@@ -137,6 +137,31 @@ def test_groups(dev, small_index):
     for l in np.unique(live[live >= 0]):
         rows = grp_q[:ng][live == l]
         assert ((rows >= 0).sum(1)[:-1] == 8).all()
+    # the device builder (gnnlm_ivfpq_build_groups) against the torch reference of the table: same lists, same group counts, same
+    # queries per list (which queries share a group is left open), the segment offsets of the threshold pass, a strided probe table
+    from gnnlm_amd.ivfpq import build_groups
+    big = torch.from_numpy(np.stack([rs.permutation(index.nlist)[:9] for _ in range(300)])).to(dev)
+    big[5, 1] = -1
+    for tab, seg in ((pl, None), (big[:, :4], 1024), (big, 16)):
+        dev_t, ref_t = index._groups(tab, seg), build_groups(tab, index.nlist, seg)
+        ngd, ngr = int(dev_t[2].item()), int(ref_t[2].item())
+        assert ngd == ngr and dev_t[3] == ref_t[3]
+        gl, gq = dev_t[0].cpu().numpy(), dev_t[1].cpu().numpy()
+        assert np.array_equal(gl, ref_t[0].cpu().numpy()) and (gq[ngd:] == -1).all()
+        rq = ref_t[1].cpu().numpy()
+        P = tab.shape[1]
+        tab_h = tab.cpu().numpy()
+        for l in np.unique(gl[:ngd]):
+            assert sorted(gq[:ngd][gl[:ngd] == l].reshape(-1)) == sorted(rq[:ngr][gl[:ngr] == l].reshape(-1))
+            assert ((gq[:ngd][gl[:ngd] == l] >= 0).sum(1)[:-1] == 8).all()
+        if seg is not None:
+            go = dev_t[4].cpu().numpy()
+            assert (go[ngd:] == -1).all() and ((go >= 0) == (gq >= 0)).all()
+            for g_ in range(ngd):
+                for s_ in range(8):
+                    if gq[g_, s_] >= 0:
+                        slot = int(np.nonzero(tab_h[gq[g_, s_]] == gl[g_])[0][0])
+                        assert go[g_, s_] == (gq[g_, s_] * P + slot) * seg
 
 
 def test_filter_is_superset_with_bounded_excess(dev, small_index):
