@@ -255,6 +255,50 @@ def test_threshold_pass_is_a_lower_bound(dev, small_index):
             assert tau_h[r] > kth - 112 * dl[r] - 1e-4, (D, k, r, tau_h[r], kth, dl[r])   # and not a loose one (64 + bins of 16 twice + slack)
 
 
+def test_rescore_long_survivor_lists(dev, small_index):
+    """gnnlm_ivfpq_rescore on its own: 0, 1, 1023 .. 40,000 survivors per query (past the 16 unrolled steps of 1024 survivors: the
+    rolled tail), every score against the float64 sum and the payload of every candidate."""
+    from gnnlm_amd import _lib
+    index, q = small_index
+    qd = torch.from_numpy(q[:8]).to(dev)
+    nq, cap = 8, 40960
+    cs, pi, lut = _prepare(index, qd, dev)
+    rs = np.random.RandomState(12)
+    off = index.list_off.cpu().numpy()
+    counts = [0, 1, 1023, 1025, 16384, 16385, 20000, 40000]
+    surv = np.zeros((nq, cap, 2), np.int32)
+    rows_of = []
+    for r, n in enumerate(counts):
+        rows = rs.choice(index.ntotal, size=n, replace=False) if n else np.zeros(0, np.int64)
+        surv[r, :n, 0] = rows
+        surv[r, :n, 1] = np.searchsorted(off, rows, side="right") - 1
+        rows_of.append(rows)
+    sc16 = np.zeros((nq, 16), np.int32)
+    sc16[:, 0] = counts
+    tau = torch.full((nq,), float("-inf"), device=dev)
+    cv = torch.zeros(nq, cap, device=dev)
+    ci = torch.full((nq, cap), -7, device=dev, dtype=torch.int64)
+    cc = torch.zeros(nq, device=dev, dtype=torch.int32)
+    surv_d, sc_d = torch.from_numpy(surv).to(dev), torch.from_numpy(sc16).to(dev)
+    r_ = _lib.gnnlm_ivfpq_rescore_t()
+    r_.codes, r_.payload, r_.M = index.list_codes.data_ptr(), index.payload.data_ptr(), 64
+    r_.lut, r_.ld_lut, r_.coarse, r_.ld_coarse, r_.tau = lut.data_ptr(), lut.stride(0), cs.data_ptr(), cs.stride(0), tau.data_ptr()
+    r_.surv, r_.surv_cnt, r_.cap, r_.n = surv_d.data_ptr(), sc_d.data_ptr(), cap, nq
+    r_.cand_val, r_.cand_id, r_.cand_cnt, r_.cand_cap = cv.data_ptr(), ci.data_ptr(), cc.data_ptr(), cap
+    _lib.call_desc("gnnlm_ivfpq_rescore", r_)
+    assert cc.cpu().numpy().tolist() == counts                               # tau = -inf: every survivor is a candidate
+    lut_h = lut.cpu().numpy().astype(np.float64).reshape(nq, 64, 256)
+    cs_h, codes, payload = cs.cpu().numpy().astype(np.float64), index.list_codes.cpu().numpy().astype(np.int64), index.payload.cpu().numpy()
+    cv_h, ci_h = cv.cpu().numpy(), ci.cpu().numpy()
+    for r, n in enumerate(counts):
+        rows = rows_of[r]
+        ref = cs_h[r, surv[r, :n, 1]] + lut_h[r][np.arange(64)[None, :], codes[rows]].sum(1)
+        by_id = dict(zip(payload[rows].tolist(), ref.tolist()))
+        assert sorted(ci_h[r, :n].tolist()) == sorted(payload[rows].tolist()) and (ci_h[r, n:] == -7).all()
+        got_ref = np.array([by_id[i] for i in ci_h[r, :n].tolist()])
+        np.testing.assert_allclose(cv_h[r, :n], got_ref, rtol=2e-5, atol=2e-5)
+
+
 def _assert_same(va, ia, vb, ib, what=None):
     """Scores bit-identical; ids identical except inside runs of exactly equal scores (keys with identical codes): the
     float32 dense round breaks such ties by list position, the candidate merge by id."""
