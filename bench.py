@@ -499,7 +499,9 @@ def knn_search(args, eng, batches, dev, step_ms):
                 "lds_lookup_bytes_per_s_TB": round(lookups / sec / 1e12, 2), "lds_frac_of_150TBps": round(lookups / sec / 1e12 / 150.0, 4),
                 "list_bytes_GBps": round(pairs_filter / 8 * 64 / sec / 1e9, 1),
                 "avg_us": round(filt["total_ms"] * 1e3 / max(1, filt["launches"]), 1), "launches": filt["launches"],
-                "table_byte_lookups": lookups, "traffic": None}
+                "table_byte_lookups": lookups, "traffic": pmc_traffic("search:ivfpq_scan8_kernel<false>")[0],
+                "traffic_note": "HBM bytes of the launch (FETCH_SIZE x 2 + WRITE_SIZE from tools/profile_search.sh's own PMC passes, profiles/pmc_traffic.json): "
+                                "the list bytes above are what the groups request; most of them hit in the XCD's L2"}
     # THROUGH THE DROP-IN DRIVER: eval_lm.main -> SequenceScorer.generate -> KNNModel.interpolate with the search inside the
     # reference's own timer (fairseq_cli/eval_lm.py:214-219), 32 one-block batches per launch as in `driver_path`
     drv = None

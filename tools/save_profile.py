@@ -22,6 +22,34 @@ py = [sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f"FETCH_SIZ
 open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.csv"), "w").write(subprocess.run(py, capture_output=True, text=True, check=True).stdout)
 open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w").write(
     subprocess.run(py + ["--json", f"--profile={tag}"], capture_output=True, text=True, check=True).stdout)
+# the search's kernels (tools/profile_search.sh <tag>, if it ran): FETCH_SIZE / WRITE_SIZE in KB per launch, the same corrections
+stxt = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_search.txt")
+if os.path.exists(stxt):
+    import ast
+    import json
+    import re
+    acc = {}
+    for l in open(stxt):
+        m = re.match(r"pmc_ivf8([fw]) (\S+?)[(,<]?\S* (\{.*\})\s*$", l) if l.startswith("pmc_ivf8f") or l.startswith("pmc_ivf8w") else None
+        if not m:
+            continue
+        name = l.split(" ", 2)[1]
+        vals = ast.literal_eval(m.group(3))
+        key = "search:" + ("ivfpq_scan8_kernel<false>" if name.startswith("ivfpq_scan8_kernel<false>") else
+                           "ivfpq_scan8_kernel<true>" if name.startswith("ivfpq_scan8_kernel<true>") else
+                           "ivfpq_rescore_kernel" if name.startswith("ivfpq_rescore") else
+                           "ivfpq_tau_kernel" if name.startswith("ivfpq_tau") else "topk_kernel")
+        e = acc.setdefault(key, {"launches": 1, "fetch_size_bytes_raw": 0.0, "write_size_bytes_raw": 0.0})
+        if "FETCH_SIZE" in vals:
+            e["fetch_size_bytes_raw"] = float(vals["FETCH_SIZE"]) * 1024
+        if "WRITE_SIZE" in vals:
+            e["write_size_bytes_raw"] = float(vals["WRITE_SIZE"]) * 1024
+    pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    t = json.load(open(pj))
+    for k, e in acc.items():
+        e["hbm_bytes_per_launch"] = 2 * e["fetch_size_bytes_raw"] + e["write_size_bytes_raw"]
+        t[k] = e
+    json.dump(t, open(pj, "w"), indent=1, sort_keys=True)
 line = [l for l in open(os.path.join(ROOT, "gpurun_out", f"prof_{tag}.bench.json")) if l.startswith("{")][0]
 open(os.path.join(ROOT, "profiles", f"{tag}_bench_under_rocprof.json"), "w").write(line)
 print("saved profiles/", tag)
