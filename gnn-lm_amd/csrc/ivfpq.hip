@@ -34,10 +34,18 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(gnnlm_ivfpq_scan_t p) {
         }
     }
     if (len == 0) return;
-    {   // the query's table -> LDS (coalesced 16-B pieces)
+    {   // the query's table -> LDS (coalesced 16-B pieces); L2 metric: 2 <q'_m, p_mc> - (|p_mc|^2 + 2 <c_l,m, p_mc>) per entry
         const float4* src = reinterpret_cast<const float4*>(p.lut + (int64_t)q * p.ld_lut);
         float4* dst = reinterpret_cast<float4*>(lut);
-        for (int e = tid; e < M * 64; e += 256) dst[e] = src[e];
+        if (p.list_term) {
+            const float4* lt = reinterpret_cast<const float4*>(p.list_term + list * p.ld_list_term);
+            for (int e = tid; e < M * 64; e += 256) {
+                const float4 a = src[e], b = lt[e];
+                dst[e] = float4{2.f * a.x - b.x, 2.f * a.y - b.y, 2.f * a.z - b.z, 2.f * a.w - b.w};
+            }
+        } else {
+            for (int e = tid; e < M * 64; e += 256) dst[e] = src[e];
+        }
     }
     __syncthreads();
     const float bias = p.probe_bias[(int64_t)q * p.ld_probe + slot];
@@ -558,6 +566,13 @@ int ivfpq_scan(const gnnlm_ivfpq_scan_t& d, hipStream_t stream) {
     const size_t lds = (size_t)d.M * 256 * sizeof(float);
     GNNLM_LDS_OPT_IN(&ivfpq_scan_kernel, 128 * 1024);
     ProfScope prof(K_IVF, stream, 0.0, 0.0);
+    GNNLM_REQUIRE(!d.list_term || (!d.packed && d.ld_list_term >= (int64_t)d.M * 256 && d.ld_list_term % 4 == 0 && (uintptr_t)d.list_term % 16 == 0),
+                  "ivfpq_scan: the L2 metric runs on row-major codes with 16-byte aligned list tables");
+    if (d.list_term) {
+        hipLaunchKernelGGL(ivfpq_scan_kernel, dim3((unsigned)d.n_tasks), dim3(256), lds, stream, d);
+        GNNLM_LAUNCH_CHECK();
+        return OK;
+    }
     if (d.packed) {
         GNNLM_REQUIRE(d.M == 32 || d.M == 64, "ivfpq_scan: the packed image exists for M = 32 and 64");
         const int64_t n_pairs = cdiv(d.n_tasks, (int64_t)2);

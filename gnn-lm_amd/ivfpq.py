@@ -132,13 +132,16 @@ class IVFPQIndex:
     LABEL_BITS = 24                                                          # payload = id << 24 | label (ids < 2^39, labels < 2^24)
 
     def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=None, cand_cap=16384,
-                 score_bytes=6 << 30, scan=None):
+                 score_bytes=6 << 30, scan=None, metric="ip", list_term_bytes=4 << 30):
         self.R, self.coarse, self.pq = R, coarse, pq                         # [d, d], [nlist, d], [M, 256, dsub]  f32
         self.list_off, self.list_ids, self.list_codes = list_off, list_ids, list_codes   # i64 [nlist+1], i64 [N], u8 [N, M]
         self.nprobe, self.cosine, self.dense_probes, self.cand_cap = nprobe, cosine, dense_probes, cand_cap
         self.score_bytes = score_bytes                                       # budget of the dense round's score rows per query block
         self.payload, self.has_vals, self.val_last = list_ids, False, 0      # what a candidate carries through the selection
         self.device = R.device
+        if metric not in ("ip", "l2") or (metric == "l2" and cosine):
+            raise ValueError("IVFPQIndex: metric is 'ip' (cosine: inner product of normalised vectors) or 'l2'")
+        self.metric = metric
         self.d, self.nlist = coarse.shape[1], coarse.shape[0]
         self.M, _, self.dsub = pq.shape
         self.ntotal = list_ids.shape[0]
@@ -148,7 +151,22 @@ class IVFPQIndex:
         # M = 64: the int8-MFMA search's image of the code rows (tiles of 16 rows, rotated byte order; csrc/ivfpq_mfma.hip)
         self.packed_codes = self.tiles = None
         scan = scan or os.environ.get("GNNLM_IVF_SCAN", "mfma")              # "f32": the float32 scan everywhere (A/B, tests)
-        if self.M == 64 and self.ntotal and self.ntotal < (1 << 32) and scan != "f32":
+        self.list_term = None
+        if metric == "l2":
+            # squared distances with residual codes: |q' - c_l - r|^2 = |q' - c_l|^2 + sum_m (T[l][m][code] - 2 <q'_m, p_mc>) with the
+            # per-list table T[l][m][c] = |p_mc|^2 + 2 <c_l,m, p_mc> (faiss IndexIVFPQ's precomputed table); the scan adds it to the
+            # query's table while it fills LDS (gnnlm_ivfpq_scan, list_term).  nlist * M KiB of HBM: built when that is affordable
+            need = self.nlist * self.M * 1024
+            if need > list_term_bytes:
+                raise ValueError(f"IVFPQIndex: the L2 metric keeps a [nlist, M, 256] float32 table ({need / 2**30:.1f} GiB here, "
+                                 f"list_term_bytes = {list_term_bytes / 2**30:.1f} GiB)")
+            self.coarse_n2 = (coarse ** 2).sum(1).contiguous()
+            cross = torch.einsum("lmd,mcd->lmc", coarse.reshape(self.nlist, self.M, self.dsub), pq)
+            self.list_term = ((pq ** 2).sum(2)[None] + 2.0 * cross).reshape(self.nlist, self.M * 256).contiguous()
+            scan = "rowmajor"
+        if scan == "rowmajor":
+            pass                                                             # the row-major kernels (one table per (query, list) task)
+        elif self.M == 64 and self.ntotal and self.ntotal < (1 << 32) and scan != "f32":
             self.tiles = ops.ivfpq_pack_tiles(self.list_codes)
         elif self.M in (32, 64) and self.ntotal:
             self.packed_codes = torch.empty(-(-self.ntotal // 64) * 64 * self.M, dtype=torch.uint8, device=self.device)
@@ -176,7 +194,7 @@ class IVFPQIndex:
     # ------------------------------------------------------------------------------------------ offline producer
     @classmethod
     def build(cls, keys, nlist, M, device="cuda", cosine=True, nprobe=32, iters=10, train_size=262144, seed=0, chunk=1 << 18,
-              opq_iters=0, **kw):
+              opq_iters=0, metric="ip", **kw):
         """Train (rotation, coarse centroids, residual product quantizer) on a sample and add every key.  ``opq_iters`` = 0: a
         random orthonormal rotation (spreads the variance over the sub-spaces); > 0: that many rounds of OPQ training from it
         (``train_opq``: what the reference's ``OPQ64_1024`` block asks faiss for)."""
@@ -200,8 +218,12 @@ class IVFPQIndex:
         if opq_iters > 0:
             R = train_opq(xt, M, R, opq_iters, gen)
         xt = xt @ R.t()
+        l2 = metric == "l2"
+        assert not (l2 and cosine), "the L2 index takes the keys as they are"
         coarse = _kmeans(xt, nlist, iters, gen, spherical=cosine)
-        resid = xt - coarse[(xt @ coarse.t()).argmax(1)]                      # inner-product assignment (IndexFlatIP quantizer)
+        # the list of a vector: the centroid with the largest inner product (IndexFlatIP quantizer) / the nearest one (IndexFlatL2)
+        nearest = lambda x: ((x @ coarse.t()) - (0.5 * (coarse ** 2).sum(1)[None, :] if l2 else 0.0)).argmax(1)
+        resid = xt - coarse[nearest(xt)]
         pq = torch.stack([_kmeans(resid[:, m * dsub:(m + 1) * dsub].contiguous(), 256, iters, gen) for m in range(M)])
         # add every key: list assignment + residual PQ codes (HIP argmin kernel of TorchPQCodec.encode)
         assign = torch.empty(N, dtype=torch.int64, device=device)
@@ -209,7 +231,7 @@ class IVFPQIndex:
         norm2 = (pq ** 2).sum(2).contiguous()
         for s in range(0, N, chunk):
             x = rows(s, min(N, s + chunk)) @ R.t()
-            a = (x @ coarse.t()).argmax(1)
+            a = nearest(x)
             assign[s:s + chunk] = a
             r = (x - coarse[a]).contiguous()
             _lib.call("gnnlm_pq_encode", _lib.ptr(r), r.stride(0), _lib.ptr(pq), _lib.ptr(norm2), M, dsub, r.shape[0],
@@ -218,17 +240,18 @@ class IVFPQIndex:
         off = torch.zeros(nlist + 1, dtype=torch.int64, device=device)
         off[1:] = torch.cumsum(torch.bincount(assign, minlength=nlist), 0)
         return cls(R.contiguous(), coarse.contiguous(), pq.contiguous(), off, order.contiguous(), codes[order].contiguous(),
-                   nprobe=nprobe, cosine=cosine, **kw)
+                   nprobe=nprobe, cosine=cosine, metric=metric, **kw)
 
     def save(self, path):
         np.savez(path, **{k: getattr(self, k).cpu().numpy() for k in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")},
-                 meta=np.array([self.nprobe, int(self.cosine)]))
+                 meta=np.array([self.nprobe, int(self.cosine), int(self.metric == "l2")]))
 
     @classmethod
     def load(cls, path, device="cuda", **kw):
         z = np.load(path)
         t = lambda k: torch.from_numpy(z[k]).to(device)
         kw.setdefault("nprobe", int(z["meta"][0]))
+        kw.setdefault("metric", "l2" if len(z["meta"]) > 2 and z["meta"][2] else "ip")
         return cls(t("R"), t("coarse"), t("pq"), t("list_off"), t("list_ids"), t("list_codes"), cosine=bool(z["meta"][1]), **kw)
 
     @classmethod
@@ -237,10 +260,13 @@ class IVFPQIndex:
         ``--index-file``) read without faiss (faiss_io.read_ivfpq_index) -- inner-product indexes with residual codes."""
         from . import faiss_io
         z = faiss_io.read_ivfpq_index(path)
-        if z["metric"] != "ip" or z["coarse_metric"] != "ip" or not z["by_residual"]:
-            raise ValueError(f"{path}: the on-device search covers inner-product IVF-PQ with residual codes (the cosine / ip "
-                             f"indexes of knn/index_builder.py), found metric={z['metric']} coarse={z['coarse_metric']} "
+        if z["metric"] != z["coarse_metric"] or not z["by_residual"]:
+            raise ValueError(f"{path}: the on-device search covers IVF-PQ with residual codes whose coarse quantizer has the index's "
+                             f"metric (what knn/index_builder.py builds), found metric={z['metric']} coarse={z['coarse_metric']} "
                              f"by_residual={z['by_residual']}")
+        kw.setdefault("metric", z["metric"])
+        if z["metric"] == "l2":
+            cosine = False
         d = z["coarse"].shape[1]
         R = z["R"] if z["R"] is not None else np.eye(d, dtype=np.float32)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
@@ -263,6 +289,8 @@ class IVFPQIndex:
         s.lut, s.ld_lut = lut.data_ptr(), lut.stride(0)
         s.probe_list, s.probe_bias, s.ld_probe = probe_id.data_ptr(), probe_val.data_ptr(), probe_id.stride(0)
         s.task_q, s.task_p, s.n_tasks = task_q.data_ptr(), task_p.data_ptr(), order.numel()
+        if self.list_term is not None:
+            s.list_term, s.ld_list_term = self.list_term.data_ptr(), self.list_term.stride(0)
         if tau is None:
             s.out_val, s.ld_out, s.p0, s.seg = out.data_ptr(), out.stride(0), p_lo, self.max_list       # scores only (out_id NULL)
         else:
@@ -318,6 +346,8 @@ class IVFPQIndex:
             self.stats = dict(main, requeried=int(bad.numel()))               # (the counters describe the main pass)
             break
         self._overflow = None
+        if self.metric == "l2":
+            val = -val                                                        # scores are -distance: squared distances, ascending, +inf padded
         if not self.has_vals:
             return (val, idx, None) if return_vals else (val, idx)
         ids = idx >> self.LABEL_BITS                                          # -1 stays -1
@@ -350,7 +380,11 @@ class IVFPQIndex:
         cs = ops.gemm_nt(qr, self.coarse)                                       # <q', c_l>
         pv = torch.empty(nq, nprobe, device=dev, dtype=torch.float32)
         pi = torch.empty(nq, nprobe, device=dev, dtype=torch.int64)
-        ops.topk_merge(cs, pv, pi, largest=True, init=True)                     # the nprobe best lists, best first
+        if self.metric == "l2":                                                 # the nprobe NEAREST lists: argmax <q', c> - |c|^2 / 2
+            ops.topk_merge(cs, pv, pi, largest=True, init=True, col_bias=-0.5 * self.coarse_n2)
+            pv = (2.0 * pv - (qr ** 2).sum(1, keepdim=True)).contiguous()      # the list's bias: -|q' - c_l|^2
+        else:
+            ops.topk_merge(cs, pv, pi, largest=True, init=True)                 # the nprobe best lists, best first
         lens = self.list_off[1:] - self.list_off[:-1]
         self.stats["pairs"] += lens[pi.clamp(min=0)].masked_fill(pi < 0, 0).sum()
         lut = torch.empty(nq, self.M * 256, device=dev, dtype=torch.float32)    # lut[q][m][c] = <q'_m, p_mc>: M small GEMMs

@@ -22,7 +22,8 @@ def get_parser():
     p = argparse.ArgumentParser()
     p.add_argument("--dstore-dir", type=str, required=True)
     p.add_argument("--index-type", type=str, default="OPQ64_1024,IVF4096,PQ64")
-    p.add_argument("--metric", type=str, default="cosine", choices=["ip", "cosine"])
+    p.add_argument("--metric", type=str, default="cosine", choices=["l2", "ip", "cosine"],
+                   help="l2: squared distances (the reference's own default, knn/run_index_build.py:50); the recipes pass cosine")
     p.add_argument("--suffix", type=str, default="")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--max-train", type=int, default=1000000)
@@ -54,7 +55,7 @@ def main(args):
     nlist = max(1, min(nlist, ds.dstore_size // 30 or 1))                       # index_builder.py:56: at least ~30 keys per list
     index = IVFPQIndex.build(ds.keys, nlist, M, device=torch.device("cuda", max(args.cuda, 0)), cosine=(args.metric == "cosine"),
                              nprobe=args.nprobe, train_size=args.max_train, seed=args.seed, chunk=args.chunk_size,
-                             opq_iters=args.opq_iters if "OPQ" in args.index_type else 0)
+                             opq_iters=args.opq_iters if "OPQ" in args.index_type else 0, metric="l2" if args.metric == "l2" else "ip")
     index.save(out)
     print(f"Save index of {index.ntotal} keys ({nlist} lists, PQ{M}) to {out}")
     return out

@@ -294,6 +294,11 @@ typedef struct gnnlm_ivfpq_scan {
     const float* tau;  float* cand_val;  int64_t* cand_id;  int32_t* cand_cnt;  int32_t cap;   /* filtered: rows of `cap` slots, cand_cnt[q] counts ALL survivors */
     int32_t packed;                       /* ABI 5: nonzero = `codes` is the image of gnnlm_ivfpq_pack_codes and `lut` the tables of
                                            * gnnlm_ivfpq_pack_lut (M = 32 or 64): the bank-conflict-free scan */
+    /* L2 metric (faiss METRIC_L2 with residual codes: `IndexBuilder`'s default, knn/index_builder.py:26,118): the score of key x
+     * in list l is  -|q' - c_l - r(x)|^2 = probe_bias - sum_m (list_term[l][m][code_m] - 2 lut[q][m][code_m])  with
+     * list_term[l][m][c] = |p_mc|^2 + 2 <c_l,m , p_mc>  ([nlist, M * 256], row stride ld_list_term; faiss's "precomputed table")
+     * and probe_bias = -|q' - c_l|^2.  list_term != NULL selects it (row-major codes, packed = 0); larger score = nearer */
+    const float* list_term;  int64_t ld_list_term;
 } gnnlm_ivfpq_scan_t;
 int gnnlm_ivfpq_scan(const gnnlm_ivfpq_scan_t* desc, void* stream);
 

@@ -1,5 +1,7 @@
 """On-device kNN search: the running top-k merge kernel and the chunked exact index against a
 stable argsort / the oracle's brute-force search (knn/knn_model.py:87-101 contract: best first, -1 padding)."""
+import struct
+
 import numpy as np
 import pytest
 import torch
@@ -293,12 +295,75 @@ def test_knn_model_reads_faiss_index_file(dev, tmp_path):
     v0, i0 = built.search(qn, 64)
     v1, i1 = m.index.search(qn, 64)
     assert np.array_equal(i0, i1) and np.array_equal(v0, v1)
-    # an L2 index is refused by the on-device search (and, without faiss or keys, by KNNModel)
-    faiss_io.write_ivfpq_index(f, arrs["R"], arrs["coarse"], arrs["pq"], arrs["list_off"], arrs["list_ids"], arrs["list_codes"], metric="l2")
+    # an index whose coarse quantizer has another metric than the index is refused (and, without faiss or keys, by KNNModel)
+    raw = bytearray(open(f, "rb").read())
+    at = raw.index(b"IwPQ") + 4 + 4 + 8 + 8 + 8 + 1                            # the IVF index's metric_type (header: d, ntotal, 2 x dummy, is_trained)
+    assert struct.unpack_from("<i", raw, at)[0] == 0
+    struct.pack_into("<i", raw, at, 1)
+    open(f, "wb").write(bytes(raw))
     with pytest.raises(ValueError):
         IVFPQIndex.from_faiss_file(f, device=dev)
     with pytest.raises(ValueError):
         KNNModel(f, str(dd), k=64, probe=6, no_load_keys=True, metric_type="do_not_recomp_ip", device=dev)
+
+
+def test_ivfpq_l2_index(dev, tmp_path):
+    """The L2 metric (`IndexBuilder`'s default, knn/index_builder.py:26,118; `faiss_store.l2`): squared distances with residual
+    codes, the nearest lists probed -- built here, searched on the device, against the float64 IVFADC oracle; the same index
+    through a faiss-format file and `KNNModel(... metric_type="do_not_recomp_l2")`, and through `run_index_build --metric l2`."""
+    import json, os
+    from gnnlm_amd import faiss_io, run_index_build
+    from gnnlm_amd.ivfpq import IVFPQIndex
+    from gnnlm_amd.knn_model import KNNModel
+    from oracle import ivfpq as oivf
+    rs = np.random.RandomState(31)
+    N, d, M, nlist, V = 40_000, 128, 32, 40, 50
+    centres = 2.0 * rs.randn(25, d).astype(np.float32)
+    keys = (centres[rs.randint(0, 25, N)] + 0.7 * rs.randn(N, d)).astype(np.float32)
+    q = (centres[rs.randint(0, 25, 33)] + 0.7 * rs.randn(33, d)).astype(np.float32)
+    idx = IVFPQIndex.build(keys, nlist, M, device=dev, cosine=False, metric="l2", nprobe=8, iters=6, seed=4)
+    assert idx.metric == "l2" and idx.tiles is None and idx.packed_codes is None and idx.list_term is not None
+    arrs = [getattr(idx, a).cpu().numpy() for a in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")]
+    exact = np.argsort(((q[:, None, :].astype(np.float64) - keys[None].astype(np.float64)) ** 2).sum(-1), axis=1)[:, :10]
+    for k in (1024, 64):
+        dist, ids = idx.search(q, k)
+        d_ref, i_ref = oivf.search(q, *arrs, k=k, nprobe=8, metric="l2")
+        assert (np.diff(dist, axis=1) >= 0).all()                            # ascending squared distances
+        assert np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, i_ref)]) > 0.998
+        np.testing.assert_allclose(dist, d_ref, rtol=2e-4, atol=2e-4)
+    assert np.mean([len(set(a[:50]) & set(b)) / 10 for a, b in zip(i_ref, exact)]) > 0.8   # (and the index finds the true neighbours)
+    # fewer keys than k in the probed lists: +inf / -1 padding
+    small = IVFPQIndex(*[getattr(idx, a) for a in ("R", "coarse", "pq", "list_off", "list_ids", "list_codes")], nprobe=1, cosine=False, metric="l2")
+    dist, ids = small.search(q[:4], 2000)
+    assert (ids[:, -1] == -1).all() and np.isinf(dist[:, -1]).all() and (dist[:, -1] > 0).all()
+    # the faiss file of such an index -> KNNModel
+    vals = rs.randint(0, V, N).astype(np.int16)
+    dd = tmp_path / "train_dstore"
+    os.makedirs(dd)
+    keys.astype(np.float16).tofile(dd / "keys.npy"); vals.tofile(dd / "vals.npy")
+    json.dump({"dstore_size": N, "hidden_size": d, "vocab_size": V, "dstore_fp16": True, "val_size": 1}, open(dd / "info.json", "w"))
+    f = str(dd / "faiss_store.l2")
+    faiss_io.write_ivfpq_index(f, *arrs, nprobe=1, metric="l2")
+    m = KNNModel(f, str(dd), k=64, probe=8, no_load_keys=True, metric_type="do_not_recomp_l2", device=dev)
+    assert isinstance(m.index, IVFPQIndex) and m.index.metric == "l2" and not m.cosine
+    sims, knns = m.search_sims(torch.from_numpy(q).to(dev), 64)
+    d_ref, i_ref = oivf.search(q, *arrs, k=64, nprobe=8, metric="l2")
+    assert np.mean([len(set(a) & set(b)) / 64 for a, b in zip(knns.cpu().numpy(), i_ref)]) > 0.998
+    np.testing.assert_allclose(sims.cpu().numpy(), -d_ref, rtol=2e-4, atol=2e-4)   # knn_model.py:139: sims = -dists
+    targets = torch.from_numpy(vals[i_ref[:, 1]].astype(np.int64)).to(dev)
+    p, rec = m.get_knn_prob(torch.from_numpy(q).to(dev), targets=targets, t=10.0, return_recall=True)
+    p_ref, rec_ref = oknn.knn_target_prob((-d_ref).astype(np.float32), i_ref, vals, targets.cpu().numpy(), 10.0)
+    np.testing.assert_allclose(p.cpu().numpy(), p_ref.numpy(), rtol=2e-3, atol=1e-6)
+    assert np.abs(rec.cpu().numpy() - rec_ref.numpy()).max() <= 1
+    # the producer
+    os.remove(f)
+    out = run_index_build.main(run_index_build.get_parser().parse_args(
+        ["--dstore-dir", str(dd), "--index-type", "OPQ32_128,IVF40,PQ32", "--metric", "l2", "--nprobe", "8", "--opq-iters", "2"]))
+    assert out.endswith("faiss_store.l2.gnnlm.npz")
+    m2 = KNNModel(str(dd / "faiss_store.l2"), str(dd), k=64, probe=8, no_load_keys=True, metric_type="do_not_recomp_l2", device=dev)
+    assert m2.index.metric == "l2"
+    d2, i2 = m2.index.search(q, 10)
+    assert np.mean([len(set(a) & set(b)) / 10 for a, b in zip(i2, exact)]) > 0.5
 
 
 def test_opq_training_lowers_the_quantisation_error(dev):
