@@ -346,6 +346,28 @@ def test_mfma_search_identical_to_f32_scan(dev, small_index):
     _same_search(mixed, f32, many, 1024)
 
 
+def test_search_result_does_not_depend_on_the_grouping(dev, small_index):
+    """Which queries of a list share a workgroup, and in which order survivors and candidates are appended, is decided by
+    atomics (gnnlm_ivfpq_build_groups, the survivor counters): the RESULT must not depend on it -- repeated searches, the torch
+    reference of the task table and a shuffled query order all give the same scores and ids, bit for bit."""
+    import os
+    index, q = small_index
+    qd = torch.from_numpy(np.concatenate([q, q[::-1], q[5:25]])).to(dev)
+    v0, i0 = index.search_device(qd, 1024)
+    for _ in range(3):
+        v, i = index.search_device(qd, 1024)
+        assert torch.equal(v, v0) and torch.equal(i, i0)
+    os.environ["GNNLM_IVF_TORCH_GROUPS"] = "1"
+    try:
+        v, i = index.search_device(qd, 1024)
+    finally:
+        del os.environ["GNNLM_IVF_TORCH_GROUPS"]
+    assert torch.equal(v, v0) and torch.equal(i, i0)
+    perm = torch.randperm(qd.shape[0], generator=torch.Generator().manual_seed(3)).to(dev)
+    v, i = index.search_device(qd[perm].contiguous(), 1024)
+    assert torch.equal(v, v0[perm]) and torch.equal(i, i0[perm])
+
+
 def test_labels_travel_with_the_search(dev, small_index):
     """attach_vals: the search returns vals[ids] with the neighbours (knn/knn_model.py:198 without the gather), ids and
     scores unchanged, -1 padding reads the last label like numpy's wrap-around."""
