@@ -281,7 +281,9 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     uint32_t* hist_j = nullptr;                                              // this lane's query (lanes j < 8 of a live query)
     if (SUMS) {
         for (int e = tid; e < QG * HIST_BINS; e += NTH) hist[e] = 0u;
-        if (qj >= 0 && p.grp_out[(int64_t)grp * QG + j] >= 0) hist_j = hist + j * HIST_BINS;
+        // lanes j >= 8 hold nothing of their own (the MFMA's columns 8 .. 15): they count HALF of the keys of lane j - 8
+        const int jq = j & 7, qjq = gq[jq];
+        if (qjq >= 0 && p.grp_out[(int64_t)grp * QG + jq] >= 0) hist_j = hist + jq * HIST_BINS;
     }
     if (!SUMS && qj >= 0) T = filter_threshold(p.qmeta, qj, p.coarse[(int64_t)qj * p.ld_coarse + list], p.tau[qj]);
 #if GNNLM_IVF8_EXP & 32
@@ -441,12 +443,17 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         if (SUMS) {
             // the lane's four keys (rows 4 g .. 4 g + 3 of the tile) of query j -> four counters of the query's histogram (LDS
             // atomics without return: nothing waits for them); the two edge tiles count the list's own rows only
+            // keys 2, 3 of lane (g, j) move to lane (g, j + 8) (row_shr:8 inside the row of 16 lanes): two atomics per lane on all
+            // 64 lanes instead of four on half of them
+            const int b2 = __builtin_amdgcn_update_dpp(0, acc[2], 0x118, 0xf, 0xf, false);
+            const int b3 = __builtin_amdgcn_update_dpp(0, acc[3], 0x118, 0xf, 0xf, false);
             if (hist_j) {
-                const int r0 = 16 * u + 4 * g - row_shift;
+                const bool up = j >= 8;
+                const int s0 = up ? b2 : acc[0], s1 = up ? b3 : acc[1];
+                const int r0 = 16 * u + 4 * g + (up ? 2 : 0) - row_shift;
                 const bool edge = u == 0 || u == nt - 1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (!edge || (unsigned)(r0 + r) < (unsigned)len) atomicAdd(&hist_j[(acc[r] + 128 * 64) >> HIST_SHIFT], 1u);
+                if (!edge || (unsigned)r0 < (unsigned)len) atomicAdd(&hist_j[(s0 + 128 * 64) >> HIST_SHIFT], 1u);
+                if (!edge || (unsigned)(r0 + 1) < (unsigned)len) atomicAdd(&hist_j[(s1 + 128 * 64) >> HIST_SHIFT], 1u);
             }
         } else {
             // four compares straight into scalar masks; a tile with survivors (about every second one) appends them mask by mask.
