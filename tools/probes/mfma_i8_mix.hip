@@ -130,9 +130,16 @@ void run(int wps) {
     hipFree(out); hipFree(clk);
 }
 int main() {
-    run<8, 0, 0, 0>(4); run<0, 0, 16, 0>(4);
-    run<8, 0, 16, 1, 2>(4); run<8, 0, 8, 1, 66>(4);
-    run<8, 5, 16, 1, 2>(4); run<8, 5, 8, 1, 66>(4);
-    run<8, 0, 16, 1, 7>(4); run<8, 0, 8, 1, 71>(4);
+    // the pipes alone, in pairs, all three
+    run<8, 0, 0, 0>(4); run<0, 0, 16, 0>(4); run<0, 21, 0, 0>(4);
+    run<8, 0, 16, 0>(4); run<8, 21, 0, 0>(4); run<0, 21, 16, 0>(4); run<8, 21, 16, 0>(4);
+    // the scan's structure: MFMAs read the previous tile's look-ups, look-up addresses from v_perm_b32, compare + ballot, code loads
+    run<8, 21, 16, 1>(4); run<8, 0, 16, 1, 2>(4); run<8, 5, 16, 1, 2>(4);
+    run<8, 5, 16, 1, 7>(4); run<8, 5, 16, 1, 19>(4); run<8, 5, 16, 1, 35>(4);
+    run<8, 5, 16, 1, 15>(4); run<8, 5, 16, 1, 10>(4);
+    // 16 queries per look-up (ds_read_b128): half the addresses and LDS instructions for the same 128 pairs
+    run<8, 0, 8, 1, 66>(4); run<8, 5, 8, 1, 66>(4); run<8, 0, 8, 1, 71>(4);
+    // waves per SIMD
+    run<8, 5, 16, 1, 7>(3); run<8, 5, 16, 1, 7>(2); run<8, 5, 16, 1, 7>(1);
     return 0;
 }
