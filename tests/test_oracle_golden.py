@@ -260,3 +260,39 @@ def test_datastore_format(golden, name):
         vals = vals.reshape(-1)
     assert np.array_equal(keys, g[name + ".keys"]) and keys.dtype == g[name + ".keys"].dtype
     assert np.array_equal(vals, g[name + ".vals"]) and vals.dtype == g[name + ".vals"].dtype
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_ivfpq_oracle_is_adc_over_the_reconstruction(metric):
+    """oracle/ivfpq.py (faiss absent: no golden vectors for the search itself): with every list probed its result is the exact
+    k-selection over the RECONSTRUCTED vectors ``c_list + decode(code)`` -- inner products with the rotated query, or squared
+    distances to it -- i.e. the ADC tables are only a factorisation of that computation; ties by ascending id; -1 / inf padding."""
+    from oracle import ivfpq as oivf
+    rs = np.random.RandomState(17)
+    d, M, nlist, N, k = 32, 8, 6, 500, 40
+    R = np.linalg.qr(rs.randn(d, d))[0].astype(np.float32)
+    coarse = rs.randn(nlist, d).astype(np.float32)
+    pq = (0.3 * rs.randn(M, 256, d // M)).astype(np.float32)
+    sizes = [120, 0, 200, 3, 77, 100]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ids = rs.permutation(N).astype(np.int64)
+    codes = rs.randint(0, 256, (N, M)).astype(np.uint8)
+    codes[10] = codes[11]                                                    # two keys of one list with identical codes: a tie
+    q = rs.randn(9, d).astype(np.float32)
+    lists = np.searchsorted(off, np.arange(N), side="right") - 1
+    rec = coarse[lists].astype(np.float64) + pq.astype(np.float64)[np.arange(M)[None, :], codes.astype(np.int64)].reshape(N, d)
+    qr = q.astype(np.float64) @ R.astype(np.float64).T
+    v, i = oivf.search(q, R, coarse, pq, off, ids, codes, k=k, nprobe=nlist, metric=metric)
+    if metric == "ip":
+        full = qr @ rec.T
+        order = np.stack([np.lexsort((ids, -full[r]))[:k] for r in range(len(q))])
+        assert (np.diff(v, axis=1) <= 1e-12).all()
+    else:
+        full = ((qr[:, None, :] - rec[None]) ** 2).sum(-1)
+        order = np.stack([np.lexsort((ids, full[r]))[:k] for r in range(len(q))])
+        assert (np.diff(v, axis=1) >= -1e-12).all()
+    assert np.array_equal(i, ids[order])
+    np.testing.assert_allclose(v, np.take_along_axis(full, order, 1), rtol=1e-10, atol=1e-10)
+    # fewer keys than k in the probed lists
+    v1, i1 = oivf.search(q[:2], R, coarse, pq, off, ids, codes, k=300, nprobe=1, metric=metric)
+    assert (i1[:, -1] == -1).all() and np.isinf(v1[:, -1]).all() and (v1[:, -1] > 0) .all() == (metric == "l2")
