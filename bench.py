@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams per GPU: the step's blocks are split into this many independent sub-batches "
                          "enqueued on separate streams (HBM/L2-bound and MFMA-bound kernels of different sub-batches overlap)")
+    ap.add_argument("--settle-s", type=float, default=0.6,
+                    help="untimed back-to-back steps run before the timed region until this many seconds of GPU work have "
+                         "passed AND two successive chunks agree within 2 %% (clock / power state settled)")
+    ap.add_argument("--settle-max-s", type=float, default=6.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the first block before timing")
     ap.add_argument("--no-extras", dest="extras", action="store_false",
@@ -574,6 +578,32 @@ def knn_search(args, eng, batches, dev, step_ms):
             "tokens_per_s_step_plus_search": round(n / (dt + step2), 1)}
 
 
+def read_sclk(device_index, sysfs_only=False):
+    """Best effort: the shader clock (MHz) the device reports right now -- sysfs `pp_dpm_sclk` (the line marked `*`), else
+    `rocm-smi --showclocks` (a subprocess: not from inside the timed region); None when neither is readable as this user.
+    Read while kernels are queued (the host runs ahead of the device) it is the clock UNDER LOAD; after a sync it is the idle clock."""
+    import glob
+    import re
+    import subprocess
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if cards:
+            txt = open(cards[min(device_index, len(cards) - 1)]).read()
+            m = re.search(r"(\d+)\s*M[Hh]z\s*\*", txt)
+            if m:
+                return int(m.group(1))
+    except OSError:
+        pass
+    if sysfs_only:
+        return None
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"sclk clock level:?\s*\S*:?\s*\(?(\d+)\s*M[Hh]z", out)
+        return int(m.group(1)) if m else None
+    except (OSError, subprocess.SubprocessError):
+        return None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, written by
     tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same
@@ -742,10 +772,8 @@ def main():
                 ops.masked_sum_f64(out["logp"], None, acc)
             graphs[bi] = gph
 
-    # ---- warm-up; the first warm-up step after initialisation is profiled kernel by kernel
-    step(0)
-    barrier()
-    # ---- parity gate: the engine that is about to be timed against the oracle on a prefix of its first block
+    # ---- parity gate FIRST (7 s of CPU-only oracle with the GPU idle: nothing timed may follow it closely): the engine that is
+    # about to be timed against the oracle on a prefix of its first block
     parity = None
     if rank == 0 and fetcher is None and not args.no_parity:
         parity = verify_block(eng, batches[0], args, cpu_model, min(args.tokens_per_sample, 256 if args.layers == 1 else 64))
@@ -756,8 +784,10 @@ def main():
         ref = eng.score(batches[0], args.lmbda, args.temperature)["logp"]
         eng.hgt.gemm_precision = eng.asm.gemm_precision = ops.PRECISIONS[args.precision]
         dlogp = (got.double() - ref.double()).abs().max().item()
-    # two profiled warm-up steps, the second one is kept: the first absorbs one-time costs that would otherwise be
-    # charged to whatever kernel they happen beside (event / pinned-slot pools, profiler tool start-up)
+    # ---- warm-up: one plain step, then two profiled ones of which the second is kept (the first absorbs one-time costs that
+    # would otherwise be charged to whatever kernel they happen beside: event / pinned-slot pools, profiler tool start-up)
+    step(0)
+    barrier()
     for i in (1, 2):
         _lib.profile_begin()
         step(i)
@@ -767,17 +797,51 @@ def main():
         step(i + 3)
     dominant = max(kern, key=lambda k_: kern[k_]["total_ms"])
     names = [_lib.lib().gnnlm_kernel_name(i).decode() for i in range(12)]
-    # ---- timed region: exactly K steps, the dominant kernel bracketed by HIP events on its stream
     if args.graph:
         capture_graphs()
+    # ---- settle (untimed): keep stepping back to back until at least `--settle-s` seconds of GPU work have run and two
+    # successive chunks agree within 2 % -- the driver's 20-step window is 0.1 s long, and 0.1 s right after seconds of host-only
+    # work is timed at whatever clock / power state the part is still ramping through (BENCH_r03: 5.58 ms against 4.73)
+    settle = {"seconds": 0.0, "steps": 0, "chunks_ms_per_step": []}
+    chunk_n = max(10, min(args.steps, 50))
+    nstep = [args.warmup]
+    while settle["seconds"] < args.settle_max_s:
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(chunk_n):
+            if args.graph:
+                graphs[nstep[0] % len(batches)].replay()
+            else:
+                step(nstep[0])
+            nstep[0] += 1
+        settle["sclk_mhz_under_load"] = read_sclk(local_rank, sysfs_only=True)     # the chunk is still running on the device
+        torch.cuda.synchronize()
+        el = time.perf_counter() - tc
+        if world > 1:                                             # every rank must take the same decision: the steps hold collectives
+            tel = torch.tensor([el], device=dev, dtype=torch.float64)
+            all_reduce(tel, dist.ReduceOp.MAX)
+            el = tel.item()
+        settle["seconds"] += el
+        settle["steps"] += chunk_n
+        settle["chunks_ms_per_step"].append(round(el / chunk_n * 1e3, 4))
+        c = settle["chunks_ms_per_step"]
+        if settle["seconds"] >= args.settle_s and len(c) >= 2 and abs(c[-1] - c[-2]) <= 0.02 * c[-1]:
+            break
+    settle["seconds"] = round(settle["seconds"], 3)
+    # ---- timed region: exactly K steps, the dominant kernel bracketed by HIP events on its stream; one more event per step
+    # boundary on the same stream gives the per-step times (median / min / max beside the wall-clock mean)
     for a in accs:
         a.zero_()
     pending.clear()                                               # nothing fetched ahead of the timed region
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     if args.graph:
         t0 = time.perf_counter()
+        marks[0].record()
         for i in range(args.steps):
             graphs[i % len(batches)].replay()
+            marks[i + 1].record()
+        sclk_timed = read_sclk(local_rank, sysfs_only=True)
         barrier()
         dt = time.perf_counter() - t0
         prof = dict(kern[dominant])                               # from the profiled warm-up step (see --graph)
@@ -785,11 +849,15 @@ def main():
     else:
         _lib.profile_begin(1 << names.index(dominant))
         t0 = time.perf_counter()
+        marks[0].record()
         for i in range(args.steps):
             step(i, last=(i == args.steps - 1))
+            marks[i + 1].record()
+        sclk_timed = read_sclk(local_rank, sysfs_only=True)       # host ahead of the device: the clock of the timed steps (~0.1 ms of host time)
         barrier()
         dt = time.perf_counter() - t0
         prof = _lib.profile_end()[dominant]
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if args.streams == 1 else []
     for a in accs[1:]:
         acc += a
     link_bytes_per_step = replicated = None
@@ -866,7 +934,12 @@ def main():
         res = {
             "metric": "eval tokens/sec on WikiText-103 (k=1024, GNN+KNN); test ppl match",
             "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step_median": (round(per_step[len(per_step) // 2], 4) if per_step else None),
+            "ms_per_step_min": (round(per_step[0], 4) if per_step else None),
+            "ms_per_step_max": (round(per_step[-1], 4) if per_step else None),
+            "settle": settle, "sclk_mhz_timed_region": sclk_timed,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "value_with_search": (search["tokens_per_s_step_plus_search"] if search is not None else None),
             "dtype": "f32" if args.precision == "f32" else f"f32 via {args.precision} split-bf16 MFMA", "data": "synthetic",

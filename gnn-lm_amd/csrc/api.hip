@@ -345,8 +345,8 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             a.Z = b.Z; a.has_nb = b.has_nb;
             a.n_store = m.n_store;
             if (ntgt || dense0) { a.nb_valid = valid; a.nb_valid_stride = n_g; }        // centre slot of each group
-            if (dedup) a.x_index = io.group_index;
             else if (io.fetched_valid) { a.nb_valid = io.fetched_valid; a.nb_valid_stride = io.fetched_centres_only ? 1 : n_g; }
+            if (dedup) a.x_index = io.group_index;
             if (l == 0 && !dense0) {
                 a.codes = io.fetched_codes ? io.fetched_codes : m.codes;
                 if (!io.fetched_codes) a.shards = m.shards;

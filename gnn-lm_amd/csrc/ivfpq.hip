@@ -565,9 +565,9 @@ int ivfpq_scan(const gnnlm_ivfpq_scan_t& d, hipStream_t stream) {
     else GNNLM_REQUIRE(d.out_val && d.seg > 0 && d.ld_out >= d.seg, "ivfpq_scan: dense mode needs the output rows");
     const size_t lds = (size_t)d.M * 256 * sizeof(float);
     GNNLM_LDS_OPT_IN(&ivfpq_scan_kernel, 128 * 1024);
-    ProfScope prof(K_IVF, stream, 0.0, 0.0);
     GNNLM_REQUIRE(!d.list_term || (!d.packed && d.ld_list_term >= (int64_t)d.M * 256 && d.ld_list_term % 4 == 0 && (uintptr_t)d.list_term % 16 == 0),
                   "ivfpq_scan: the L2 metric runs on row-major codes with 16-byte aligned list tables");
+    ProfScope prof(K_IVF, stream, 0.0, 0.0);
     if (d.list_term) {
         hipLaunchKernelGGL(ivfpq_scan_kernel, dim3((unsigned)d.n_tasks), dim3(256), lds, stream, d);
         GNNLM_LAUNCH_CHECK();

@@ -231,7 +231,17 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     const int list = p.grp_list[grp];
     if (list < 0) continue;
     const int64_t lo = p.list_off[list], hi = p.list_off[list + 1];
-    if (hi <= lo) continue;
+    if (hi <= lo) {
+        // an empty list: the threshold pass still owes ivfpq_tau_kernel a (zero) histogram for every (query, list) pair of the group
+        if (SUMS) {
+            for (int u = 0; u < QG; ++u) {
+                const int64_t ob = p.grp_out[(int64_t)grp * QG + u];
+                if (p.grp_q[(int64_t)grp * QG + u] < 0 || ob < 0) continue;
+                for (int e = tid; e < HIST_BINS; e += NTH) p.out_hist[ob + e] = 0u;
+            }
+        }
+        continue;
+    }
     uint32_t* wbuf = reinterpret_cast<uint32_t*>(smem + TAB_BYTES + 512) + wave * WAVE_CAP;   // this wave's survivors: (row - lo) << 3 | query slot
     const int* gq = p.grp_q + (int64_t)grp * QG;
     uint2* surv = reinterpret_cast<uint2*>(p.surv);                           // {row, list} per survivor

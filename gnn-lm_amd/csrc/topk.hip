@@ -342,20 +342,32 @@ __global__ __launch_bounds__(256) void topk_select_kernel(TopkParams p) {
     if (tid == 0) cnt = 0;
     for (int e = tid; e < KP; e += NT) { val[e] = NEG; id[e] = (int64_t)0x7fffffffffffffffll; }
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        if (rkey[e] == 0u) continue;
-        if (all || rkey[e] > prefix || (rkey[e] == prefix && rid[e] <= id_cut)) {
-            const int pos = atomicAdd(&cnt, 1);
-            if (pos < KP) { val[pos] = value_of_key(rkey[e]); id[pos] = rid[e]; }
+    // two phases: the entries strictly above the cut first, the tied ones (by id) behind them -- with ids that are NOT unique
+    // within a row more than `need` tied entries can pass `cid <= id_cut`, and the `pos < KP` guard must then drop tied entries
+    // only, never a strictly better one
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+        if (phase == 1) {
+            if (all) break;
+            __syncthreads();
         }
-    }
-    for (int c = C0 + tid; c < ncols; c += NT) {
-        float v; uint32_t key; int64_t cid;
-        if (!entry(c, v, key, cid)) continue;
-        if (all || key > prefix || (key == prefix && cid <= id_cut)) {
-            const int pos = atomicAdd(&cnt, 1);
-            if (pos < KP) { val[pos] = v; id[pos] = cid; }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            if (rkey[e] == 0u) continue;
+            const bool take = phase == 0 ? (all || rkey[e] > prefix) : (rkey[e] == prefix && rid[e] <= id_cut);
+            if (take) {
+                const int pos = atomicAdd(&cnt, 1);
+                if (pos < KP) { val[pos] = value_of_key(rkey[e]); id[pos] = rid[e]; }
+            }
+        }
+        for (int c = C0 + tid; c < ncols; c += NT) {
+            float v; uint32_t key; int64_t cid;
+            if (!entry(c, v, key, cid)) continue;
+            const bool take = phase == 0 ? (all || key > prefix) : (key == prefix && cid <= id_cut);
+            if (take) {
+                const int pos = atomicAdd(&cnt, 1);
+                if (pos < KP) { val[pos] = v; id[pos] = cid; }
+            }
         }
     }
     __syncthreads();

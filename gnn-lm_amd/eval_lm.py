@@ -20,6 +20,7 @@ Output: the reference's two final lines (eval_lm.py:325-331).
 import argparse
 import ast
 import json
+import struct
 import logging
 import math
 import os
@@ -195,6 +196,62 @@ def block_ranges(n_tokens, block, context_window=0):
     return out
 
 
+_MMAP_IDX_DTYPES = {1: np.uint8, 2: np.int8, 3: np.int16, 4: np.int32, 5: np.int64, 6: np.float64, 7: np.float64, 8: np.uint16}
+
+
+def fairseq_token_stream(data, split):
+    """The split's token stream as fairseq binarised it (``DATA/{split}.bin/.idx``, MMapIndexedDataset:
+    fairseq/data/indexed_dataset.py:350-420): header ``MMIDIDX\0\0`` + <Q version 1 + <B dtype code + <Q n_sentences, then
+    int32 sizes.  Read without fairseq; None when the pair is absent or in another format (the legacy ``TNTIDX`` index)."""
+    idx, binf = os.path.join(data, split + ".idx"), os.path.join(data, split + ".bin")
+    if not (os.path.exists(idx) and os.path.exists(binf)):
+        return None
+    with open(idx, "rb") as f:
+        if f.read(9) != b"MMIDIDX\x00\x00":
+            return None
+        version, code, n_sent = struct.unpack("<QBQ", f.read(17))
+        if version != 1 or code not in _MMAP_IDX_DTYPES:
+            return None
+        sizes = np.frombuffer(f.read(4 * n_sent), dtype=np.int32)
+    total = int(sizes.astype(np.int64).sum())
+    return np.memmap(binf, mode="r", dtype=_MMAP_IDX_DTYPES[code], shape=(total,))
+
+
+def check_tables(args, info, n_store):
+    """The driver takes the targets from ``{split}_dstore/vals.npy`` (row i = the i-th token of the split: the reference saves
+    them in iteration order, fairseq_cli/eval_lm.py:238-242) instead of fairseq's ``.bin/.idx``.  That is only the same thing
+    when every per-token file of the split describes the same tokens -- checked here instead of assumed: file sizes against
+    ``info.json``, and the token stream itself whenever the binarised split is there."""
+    split, data = args.gen_subset, args.data
+    n_tok, d = info["dstore_size"], info["hidden_size"]
+    vdt = np.dtype(vals_dtype(info["dstore_fp16"], info.get("vocab_size")))
+    if info.get("val_size", 1) != 1:
+        raise ValueError(f"{dstore_path(data, split)}/info.json: val_size must be 1 (labels), found {info.get('val_size')}")
+    want = {feature_path(data, split): n_tok * d * (2 if info["dstore_fp16"] else 4),
+            value_path(data, split): n_tok * vdt.itemsize,
+            neighbor_path(data, split, args.gcn_k): n_tok * args.gcn_k * 8}
+    for path, size in want.items():
+        if not os.path.exists(path):
+            raise FileNotFoundError("Dataset not found: {} ({})".format(split, path))
+        have = os.path.getsize(path)
+        if have != size:
+            raise ValueError(f"{path}: {have} bytes, but info.json (dstore_size {n_tok}, hidden_size {d}, fp16 {info['dstore_fp16']}, "
+                             f"vocab {info.get('vocab_size')}) and --gcn-k {args.gcn_k} imply {size}: the per-token files of the "
+                             f"'{split}' split do not describe the same tokens")
+    stream = fairseq_token_stream(data, split)
+    if stream is not None:
+        if stream.shape[0] < n_tok:
+            raise ValueError(f"{data}/{split}.bin holds {stream.shape[0]} tokens, {dstore_path(data, split)} has {n_tok} rows")
+        vals = np.memmap(value_path(data, split), mode="r", shape=(n_tok,), dtype=vdt)
+        for s in range(0, n_tok, 1 << 24):                      # targets = the token stream itself (monolingual_dataset.py:86-94)
+            a, b = np.asarray(stream[s:s + (1 << 24)]).astype(np.int64), np.asarray(vals[s:s + (1 << 24)]).astype(np.int64)
+            if not np.array_equal(a[:len(b)], b):
+                at = s + int(np.nonzero(a[:len(b)] != b)[0][0])
+                raise ValueError(f"{value_path(data, split)} row {at} = {int(vals[at])} but token {at} of {data}/{split}.bin is "
+                                 f"{int(stream[at])}: the datastore was not written over this split in corpus order")
+        logger.info("targets of %s_dstore/vals.npy == token stream of %s.bin (%d tokens)", split, split, n_tok)
+
+
 def load_tables(args, device):
     split, data = args.gen_subset, args.data
     info = json.load(open(os.path.join(dstore_path(data, split), "info.json")))
@@ -202,12 +259,16 @@ def load_tables(args, device):
     n_tok, d = info["dstore_size"], info["hidden_size"]
     if not os.path.exists(feature_path(data, split)):
         raise FileNotFoundError("Dataset not found: {} ({})".format(split, feature_path(data, split)))
+    check_tables(args, info, tinfo["dstore_size"])
     feats = np.memmap(feature_path(data, split), mode="r", shape=(n_tok, d),
                       dtype=np.float16 if info["dstore_fp16"] else np.float32)
     targets = np.memmap(value_path(data, split), mode="r", shape=(n_tok,),
                         dtype=vals_dtype(info["dstore_fp16"], info.get("vocab_size")))
     nbrs = np.memmap(neighbor_path(data, split, args.gcn_k), mode="r", dtype=np.int64, shape=(n_tok, args.gcn_k))
     codes = np.load(quantized_feature_path(data, "train"), mmap_mode="r")                  # language_modeling.py:274-276
+    if codes.ndim != 2 or codes.dtype != np.uint8 or codes.shape[0] != tinfo["dstore_size"]:
+        raise ValueError(f"{quantized_feature_path(data, 'train')}: {codes.dtype} {codes.shape}, expected uint8 "
+                         f"[{tinfo['dstore_size']}, M] (one code row per key of train_dstore)")
     up = lambda a: torch.from_numpy(np.array(a)).to(device)
     tg = up(targets).long()
     return {"n_tok": n_tok, "d": d, "vocab": info.get("vocab_size"), "n_store": tinfo["dstore_size"],

@@ -79,9 +79,9 @@ def train_opq(x, M, R0, iters, gen, pq_iters=4):
     for the ``OPQ64_1024`` block of the reference's index type, knn/index_builder.py:60-64): alternate (a) a product quantizer of
     M x 256 centroids on the rotated vectors x R^T (k-means per sub-space, warm-started from the previous round) and (b) the
     orthogonal Procrustes solution R^T = U V^T, U S V^T = x^T y, y = the quantizer's reconstruction of x R^T -- the rotation
-    under which the quantizer loses least.  x [n, d] f32 on the device, R0 [d, d] orthonormal start; -> R [d, d]."""
+    under which the quantizer loses least.  x [n, d] f32 on the device, R0 [d_out, d] with orthonormal rows; -> R [d_out, d]."""
     n, d = x.shape
-    dsub = d // M
+    dsub = R0.shape[0] // M                                                   # R0 [d_out, d]: d_out < d for an `OPQ<M>_<d_out>` block that reduces
     R, cents = R0.clone(), [None] * M
     for _ in range(iters):
         xr = x @ R.t()
@@ -90,7 +90,7 @@ def train_opq(x, M, R0, iters, gen, pq_iters=4):
             sub = xr[:, m * dsub:(m + 1) * dsub].contiguous()
             cents[m] = _kmeans(sub, 256, pq_iters, gen, init=cents[m])
             y[:, m * dsub:(m + 1) * dsub] = cents[m][_pq_assign(sub, cents[m])]
-        U, _, Vt = torch.linalg.svd((x.t() @ y).double())
+        U, _, Vt = torch.linalg.svd((x.t() @ y).double(), full_matrices=False)
         R = (U @ Vt).t().to(torch.float32).contiguous()
     return R
 
@@ -339,8 +339,11 @@ class IVFPQIndex:
             main = {k_: (v_.clone() if torch.is_tensor(v_) else v_) for k_, v_ in self.stats.items()}
             while True:                                                       # every probed list in the threshold / dense round
                 v2, i2, o2 = self._search_once(sub, k, query_block, self.nprobe, cap2)
-                if o2 is None or cap2 >= (1 << 22) or int(o2.max().item()) <= cap2:
+                if o2 is None or int(o2.max().item()) <= cap2:
                     break
+                if cap2 >= (1 << 22):                                         # survivors beyond the capacity would be dropped silently
+                    raise _lib.GnnlmError(f"ivfpq search: {int(o2.max().item())} survivors of one query exceed the largest candidate "
+                                     f"capacity ({cap2}); lower k / nprobe or search this index with scan='f32'")
                 cap2 *= 2
             val[bad], idx[bad] = v2, i2
             self.stats = dict(main, requeried=int(bad.numel()))               # (the counters describe the main pass)

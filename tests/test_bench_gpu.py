@@ -16,7 +16,7 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 def run_bench(*extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--blocks", "2", "--steps", "3", "--warmup", "2",
-           "--n-store", "30000", "--gcn-k", "16", "--k", "32", "--tokens-per-sample", "32", *extra]
+           "--n-store", "30000", "--gcn-k", "16", "--k", "32", "--tokens-per-sample", "32", "--settle-s", "0.05", *extra]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -34,6 +34,10 @@ def test_bench_contract(extra):
     assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 2 and r["higher_is_better"] is True
     assert r["unit"] == "tokens/s" and r["value"] > 0 and r["vs_baseline"] is None and r["scaling"] == "weak"
     assert "workload" in r["config"]
+    # the timed region follows an untimed settle phase; per-step HIP-event times ride beside the wall-clock mean
+    assert r["settle"]["steps"] >= 20 and len(r["settle"]["chunks_ms_per_step"]) >= 2
+    assert r["ms_per_step_min"] <= r["ms_per_step_median"] <= r["ms_per_step_max"]
+    assert r["ms_per_step_median"] <= r["ms_per_step"] * 1.5 and "sclk_mhz_timed_region" in r
     roof = r["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k
@@ -61,7 +65,7 @@ def test_bench_two_ranks_on_one_gpu(extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--small", "--blocks", "2", "--steps", "3",
            "--warmup", "2", "--n-store", "30000", "--gcn-k", "16", "--k", "32", "--tokens-per-sample", "32", "--no-cpu-baseline",
-           *extra]
+           "--settle-s", "0.05", *extra]
     env = dict(os.environ, GNNLM_BENCH_BACKEND="gloo", GNNLM_BENCH_DEVICE="0")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]

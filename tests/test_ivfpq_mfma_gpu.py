@@ -346,6 +346,39 @@ def test_mfma_search_identical_to_f32_scan(dev, small_index):
     _same_search(mixed, f32, many, 1024)
 
 
+def test_empty_list_among_the_threshold_lists(dev, small_index):
+    """A query whose best probes include EMPTY lists: the threshold pass writes no histogram for an empty list, so the tau kernel
+    must not read stale memory there (a too-high tau silently drops true neighbours).  Empty lists are added as scaled-up copies of
+    the centroids (they outrank every real list); the search runs twice with dirtied allocator blocks in between."""
+    from gnnlm_amd.ivfpq import IVFPQIndex
+    from oracle import ivfpq as oivf
+    index, q = small_index
+    extra = 4
+    N = index.ntotal
+    coarse = torch.cat([index.coarse, 1.5 * index.coarse[:extra]]).contiguous()
+    list_off = torch.cat([index.list_off, torch.full((extra,), N, dtype=torch.int64, device=dev)]).contiguous()
+    emp = IVFPQIndex(index.R, coarse, index.pq, list_off, index.list_ids, index.list_codes, nprobe=9)
+    assert emp.tiles is not None and emp.dense_probes == 6
+    f32 = IVFPQIndex(index.R, coarse, index.pq, list_off, index.list_ids, index.list_codes, nprobe=9, scan="f32", dense_probes=6)
+    qd = torch.from_numpy(q).to(dev)
+    cs = (qd @ index.R.t()) @ coarse.t()
+    top = cs.topk(6, dim=1).indices
+    assert bool((top >= index.nlist).any(1).sum() > 5)                       # several queries do have an empty list among their 6 best
+    arrs = [a.cpu().numpy() for a in (index.R, coarse, index.pq, list_off, index.list_ids, index.list_codes)]
+    v_ref, i_ref = oivf.search(q, *arrs, k=1024, nprobe=9)
+    for attempt in range(3):
+        junk = [torch.full((q.shape[0], 6, 1024), 1 << 20, device=dev, dtype=torch.int32) for _ in range(3)]   # what a stale histogram looks like
+        del junk
+        v, i = emp.search_device(qd, 1024)
+        v, i = v.cpu().numpy(), i.cpu().numpy()
+        fin = np.isfinite(v_ref)
+        assert np.array_equal(np.isfinite(v), fin), attempt
+        np.testing.assert_allclose(v[fin], v_ref[fin], rtol=2e-5, atol=2e-5)
+        assert np.mean([len(set(a) & set(b)) / 1024 for a, b in zip(i, i_ref)]) > 0.998
+    vf, if_ = f32.search_device(qd, 1024)
+    _assert_same(v, i, vf.cpu().numpy(), if_.cpu().numpy())
+
+
 def test_search_result_does_not_depend_on_the_grouping(dev, small_index):
     """Which queries of a list share a workgroup, and in which order survivors and candidates are appended, is decided by
     atomics (gnnlm_ivfpq_build_groups, the survivor counters): the RESULT must not depend on it -- repeated searches, the torch

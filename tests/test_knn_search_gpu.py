@@ -492,3 +492,28 @@ def test_ivfpq_one_billion_index_family(dev):
     same = np.mean([len(set(a[a >= 0]) & set(b[b >= 0])) / max(1, (b >= 0).sum()) for a, b in zip(i, i_ref)])
     assert same > 0.998, same
     np.testing.assert_allclose(v[ok], v_ref[ok], rtol=2e-5, atol=2e-4)
+
+
+def test_topk_select_duplicate_ids_among_ties(dev):
+    """Caller-supplied ids that repeat inside a run of values tied at the cut (the select kernel's id cut then admits more than
+    it needs): no strictly better entry may be lost, the row stays sorted, the tail is made of tied entries."""
+    from gnnlm_amd import ops
+    n, ncols, k = 6, 3000, 256
+    rs = np.random.RandomState(17)
+    sc = rs.randn(n, ncols).astype(np.float32)
+    ids = np.stack([rs.permutation(10 * ncols)[:ncols] for _ in range(n)]).astype(np.int64)
+    for r in range(n):
+        order = np.argsort(-sc[r])
+        kth = sc[r, order[k - 40]]
+        tied = order[k - 40:k + 400]                        # 440 entries tied at the cut value ...
+        sc[r, tied] = kth
+        ids[r, tied] = ids[r, tied[0]] if r % 2 else ids[r, tied] % 7      # ... that share one id / seven ids
+    bv = torch.empty(n, k, device=dev)
+    bi = torch.empty(n, k, device=dev, dtype=torch.int64)
+    ops.topk_merge(torch.from_numpy(sc).to(dev), bv, bi, ids=torch.from_numpy(ids).to(dev), largest=True, init=True)
+    bv, bi = bv.cpu().numpy(), bi.cpu().numpy()
+    for r in range(n):
+        want = np.sort(sc[r])[::-1][:k]
+        assert np.array_equal(bv[r], want), r              # every strictly better value present, tail = the tied value
+        better = sc[r] > want[-1]
+        assert set(ids[r, better]) <= set(bi[r]), r

@@ -222,3 +222,119 @@ def test_ivfpq_group_table():
     # without seg: the same table
     a = build_groups(pl, nlist)
     assert np.array_equal(a[0].numpy(), grp_list) and np.array_equal(a[1].numpy(), grp_q) and int(a[2].item()) == ng
+
+
+def test_unsupported_faiss_index_files_are_refused(tmp_path):
+    """IVFPQIndex.from_faiss_file covers what knn/index_builder.py builds (residual codes, the coarse quantizer in the index's
+    metric); files outside that family are refused BEFORE anything touches the device: ``by_residual = False`` and a coarse
+    quantizer of the other metric."""
+    from gnnlm_amd.faiss_io import read_ivfpq_index, write_ivfpq_index
+    from gnnlm_amd.ivfpq import IVFPQIndex
+    rs = np.random.RandomState(2)
+    d, M, nlist = 32, 8, 4
+    coarse, pq = rs.randn(nlist, d).astype(np.float32), rs.randn(M, 256, d // M).astype(np.float32)
+    off = np.array([0, 3, 3, 10, 12], np.int64)
+    ids, codes = np.arange(12, dtype=np.int64), rs.randint(0, 256, (12, M)).astype(np.uint8)
+    f = str(tmp_path / "faiss_store.cosine")
+    write_ivfpq_index(f, None, coarse, pq, off, ids, codes, nprobe=2)
+    raw = bytearray(open(f, "rb").read())
+    at = raw.index(b"IxFI")                                     # the coarse quantizer: IndexFlatIP -> IndexFlatL2 (metric field too)
+    assert read_ivfpq_index(f)["by_residual"]
+    bad = bytearray(raw)
+    bad[at:at + 4] = b"IxF2"
+    struct.pack_into("<i", bad, at + 4 + 29, 1)                 # header: int32 d, int64 x 3, bool, int32 metric
+    open(f, "wb").write(bytes(bad))
+    z = read_ivfpq_index(f)
+    assert z["metric"] == "ip" and z["coarse_metric"] == "l2"
+    with pytest.raises(ValueError, match="residual codes"):
+        IVFPQIndex.from_faiss_file(f, device="cuda")            # raises while still on the host
+    # by_residual = False: the bool in front of code_size, right behind the direct map (int8 type + empty vector)
+    flat_end = at + 4 + 33 + 8 + 4 * nlist * d
+    bad = bytearray(raw)
+    assert bad[flat_end] == 0 and struct.unpack_from("<Q", bad, flat_end + 1) == (0,) and bad[flat_end + 9] == 1
+    bad[flat_end + 9] = 0
+    open(f, "wb").write(bytes(bad))
+    assert not read_ivfpq_index(f)["by_residual"]
+    with pytest.raises(ValueError, match="residual codes"):
+        IVFPQIndex.from_faiss_file(f, device="cuda")
+
+
+def _write_split(tmp_path, n_tok=50, d=8, kg=4, vocab=100, fp16=True):
+    data = tmp_path / "data-bin"
+    rs = np.random.RandomState(0)
+    for split, n in (("train", 200), ("test", n_tok)):
+        p = data / f"{split}_dstore"
+        os.makedirs(p, exist_ok=True)
+        rs.randn(n, d).astype(np.float16).tofile(p / "keys.npy")
+        (4 + rs.randint(0, vocab - 4, n)).astype(np.int16).tofile(p / "vals.npy")
+        json.dump({"dstore_size": n, "hidden_size": d, "vocab_size": vocab, "dstore_fp16": fp16, "val_size": 1}, open(p / "info.json", "w"))
+    rs.randint(0, 200, (n_tok, kg)).astype(np.int64).tofile(data / "test_dstore" / f"neighbors.mmap.{kg}")
+    return data
+
+
+def _write_fairseq_bin(data, split, tokens, sizes, dtype=np.uint16):
+    code = {np.uint8: 1, np.int16: 3, np.int32: 4, np.int64: 5, np.uint16: 8}[dtype]
+    with open(data / f"{split}.idx", "wb") as f:                # MMapIndexedDataset.Index.writer (indexed_dataset.py:354-390)
+        f.write(b"MMIDIDX\x00\x00" + struct.pack("<Q", 1) + struct.pack("<B", code) + struct.pack("<Q", len(sizes)))
+        f.write(np.asarray(sizes, np.int32).tobytes())
+        f.write((np.concatenate([[0], np.cumsum(sizes)[:-1]]) * np.dtype(dtype).itemsize).astype(np.int64).tobytes())
+    np.asarray(tokens, dtype).tofile(data / f"{split}.bin")
+
+
+def test_driver_input_guards(tmp_path):
+    """eval_lm.check_tables: the per-token files of a split must describe the same tokens (sizes against info.json), and when the
+    binarised split is there, vals.npy must BE its token stream (the reference takes targets from fairseq's dataset; the driver
+    takes them from the datastore)."""
+    from gnnlm_amd.eval_lm import check_tables, fairseq_token_stream
+    data = _write_split(tmp_path)
+    args = get_parser().parse_args([str(data), "--path", "x", "--gen-subset", "test", "--gcn-k", "4"])
+    info = json.load(open(data / "test_dstore" / "info.json"))
+    check_tables(args, info, 200)                               # consistent, no .bin: passes
+    assert fairseq_token_stream(str(data), "test") is None
+    vals = np.fromfile(data / "test_dstore" / "vals.npy", dtype=np.int16)
+    _write_fairseq_bin(data, "test", vals, [20, 17, 13])
+    assert np.array_equal(fairseq_token_stream(str(data), "test"), vals)
+    check_tables(args, info, 200)
+    _write_fairseq_bin(data, "test", np.concatenate([vals, [5, 6, 7]]), [20, 17, 16])     # a longer stream (--first): the prefix counts
+    check_tables(args, info, 200)
+    wrong = vals.copy()
+    wrong[31] += 1
+    _write_fairseq_bin(data, "test", wrong, [50], dtype=np.int32)
+    with pytest.raises(ValueError, match="row 31"):
+        check_tables(args, info, 200)
+    _write_fairseq_bin(data, "test", vals[:40], [40])
+    with pytest.raises(ValueError, match="holds 40 tokens"):
+        check_tables(args, info, 200)
+    os.remove(data / "test.bin")
+    os.remove(data / "test.idx")
+    # neighbours written for another k / another split length
+    nb = data / "test_dstore" / "neighbors.mmap.4"
+    raw = open(nb, "rb").read()
+    open(nb, "wb").write(raw[:-32])
+    with pytest.raises(ValueError, match="do not describe the same tokens"):
+        check_tables(args, info, 200)
+    open(nb, "wb").write(raw)
+    open(data / "test_dstore" / "vals.npy", "ab").write(b"\0\0")
+    with pytest.raises(ValueError, match="vals.npy"):
+        check_tables(args, info, 200)
+
+
+def test_quantize_features_sample_and_index_string():
+    """The training sample of knn/quantize_features.py:79-90 (first rows of 100 equal parts, remainder in the last) and the index
+    strings of the recipes (find_knn.sh:32-38 wiki103, one_billion/find_knn.sh:24)."""
+    from gnnlm_amd.quantize_features import parse_index, training_sample
+    keys = np.arange(1000 * 3, dtype=np.float32).reshape(1000, 3)
+    s = training_sample(keys, 1000, 250)                        # 2 rows per part, the last part asks for 250 - 2 * 99 = 52 of its 10
+    want = [p * 10 + i for p in range(99) for i in range(2)] + [990 + i for i in range(10)]
+    assert np.array_equal(s[:, 0] / 3, np.array(want, np.float32))
+    s = training_sample(keys, 1000, 300)                        # the recipe's case: chunk_size % 100 == 0, no remainder
+    assert np.array_equal(s[:, 0] / 3, np.array([p * 10 + i for p in range(100) for i in range(3)], np.float32))
+    s = training_sample(keys, 1000, 5000)                       # chunk_size > store: every part whole = the whole table
+    assert np.array_equal(s, keys)
+    assert parse_index("OPQ128_1024,,PQ128", 1024) == (True, 1024, 128)
+    assert parse_index("OPQ128_512,,PQ128", 1024) == (True, 512, 128)
+    assert parse_index("OPQ64_512,PQ64", 512) == (True, 512, 64)
+    assert parse_index("PQ64", 1024) == (False, 1024, 64)
+    for bad in ("OPQ64_1024,,PQ128", "IVF4096,Flat", "OPQ128_2048,,PQ128", "PQ64x4"):
+        with pytest.raises(ValueError):
+            parse_index(bad, 1024)
