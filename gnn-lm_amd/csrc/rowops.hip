@@ -197,6 +197,15 @@ __global__ void tail_combine_kernel(const float* tail_picked, const float* tail_
     }
 }
 
+// tag of a label (gnnlm_knn_interp_t.vals_tag): the top byte of a multiplicative hash of its low 32 bits
+__device__ __forceinline__ uint32_t label_tag(int64_t v) { return ((uint32_t)v * 2654435761u) >> 24; }
+__global__ __launch_bounds__(256) void label_tags_kernel(const void* vals, int itemsize, int64_t n, uint8_t* tag) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int64_t v = itemsize == 2 ? (int64_t) reinterpret_cast<const int16_t*>(vals)[r] : (int64_t) reinterpret_cast<const int32_t*>(vals)[r];
+    tag[r] = (uint8_t)label_tag(v);
+}
+
 // one wave per token
 __global__ __launch_bounds__(256) void knn_interp_kernel(KnnInterpParams p, float log_1ml, float log_l) {
     const int lane = threadIdx.x & 63;
@@ -267,6 +276,28 @@ __global__ __launch_bounds__(256) void knn_interp_regs_kernel(KnnInterpParams p,
         id[t] = j < p.k ? ids[j] : -1;
         sv[t] = j < p.k ? sims[j] : 0.f;
     }
+    const int64_t tgt = p.targets[i];
+    if (p.vals_tag && !p.knn_vals) {
+        // tag table: k random 1-byte reads; the 4-byte label is read only where the tag equals the target's (rare)
+        const uint32_t ttag = label_tag(tgt);
+        uint32_t tg[JMAX];
+#pragma unroll
+        for (int t = 0; t < JMAX; ++t) {
+            const int j = lane + 64 * t;
+            const int64_t row = (id[t] < 0 ? id[t] + p.n_store : id[t]) - p.row0;
+            tg[t] = 0x100u;                                 // no tag: rows outside the shard / the store never match
+            if (j < p.k && row >= 0 && row < p.n_local) tg[t] = p.vals_tag[row];
+        }
+#pragma unroll
+        for (int t = 0; t < JMAX; ++t) {
+            val[t] = ~tgt;                                  // "no match": equal labels have equal tags
+            if (tg[t] == ttag) {
+                const int64_t row = (id[t] < 0 ? id[t] + p.n_store : id[t]) - p.row0;
+                val[t] = p.vals_itemsize == 2 ? (int64_t) reinterpret_cast<const int16_t*>(p.vals)[row]
+                                              : (int64_t) reinterpret_cast<const int32_t*>(p.vals)[row];
+            }
+        }
+    } else
 #pragma unroll
     for (int t = 0; t < JMAX; ++t) {
         const int j = lane + 64 * t;
@@ -282,7 +313,6 @@ __global__ __launch_bounds__(256) void knn_interp_regs_kernel(KnnInterpParams p,
             }
         }
     }
-    const int64_t tgt = p.targets[i];
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < JMAX; ++t) {
@@ -447,6 +477,15 @@ int knn_interp(const KnnInterpParams& p, hipStream_t stream) {
     if (p.k <= 256) hipLaunchKernelGGL(knn_interp_regs_kernel<4>, grid, block, 0, stream, p, log_1ml, log_l);
     else if (p.k <= 1024) hipLaunchKernelGGL(knn_interp_regs_kernel<16>, grid, block, 0, stream, p, log_1ml, log_l);
     else hipLaunchKernelGGL(knn_interp_kernel, grid, block, 0, stream, p, log_1ml, log_l);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int label_tags(const void* vals, int itemsize, int64_t n, uint8_t* tag, hipStream_t stream) {
+    GNNLM_REQUIRE(vals && tag && n >= 0 && (itemsize == 2 || itemsize == 4), "label_tags: need an int16 / int32 label table");
+    if (n == 0) return OK;
+    GNNLM_REQUIRE(cdiv(n, (int64_t)256) < (1ll << 31), "label_tags: too many rows for one launch");
+    hipLaunchKernelGGL(label_tags_kernel, dim3((unsigned)cdiv(n, (int64_t)256)), dim3(256), 0, stream, vals, itemsize, n, tag);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

@@ -275,7 +275,32 @@ def row_lse_pick(logits, pick=None):
     return lse, picked
 
 
-def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_store=None, row0=0, knn_vals=None):
+_TAG_TABLES = {}                     # id(vals) -> (weakref to vals, version, tag table)
+TAG_TABLE_MIN_ROWS = 1 << 20         # below this the label table sits in the L2 anyway
+
+
+def label_tags(vals, build=True):
+    """The one-byte tag table of a label table (``gnnlm_label_tags``; see ``gnnlm_knn_interp_t.vals_tag``), built once per
+    table and kept while the table lives (keyed on the tensor object and its in-place version counter).  ``build=False``:
+    only what is cached (inside a stream capture nothing may be allocated or launched on the side)."""
+    import weakref
+    for k_ in [k_ for k_, (ref, _, _) in _TAG_TABLES.items() if ref() is None]:
+        del _TAG_TABLES[k_]
+    hit = _TAG_TABLES.get(id(vals))
+    if hit is not None and hit[0]() is vals and hit[1] == vals._version:
+        return hit[2]
+    if not build:
+        return None
+    assert vals.dim() == 1 and vals.is_contiguous() and vals.dtype in (torch.int16, torch.int32)
+    tag = torch.empty(vals.shape[0], dtype=torch.uint8, device=vals.device)
+    call("gnnlm_label_tags", ptr(vals), vals.element_size(), vals.shape[0], ptr(tag), stream())
+    _TAG_TABLES[id(vals)] = (weakref.ref(vals), vals._version, tag)
+    return tag
+
+
+def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_store=None, row0=0, knn_vals=None, vals_tag="auto"):
+    """``vals_tag``: "auto" = gather through the one-byte tag table (built on first use) when the label table is large and
+    k fits the register kernel; True / False force it on / off (tests, A/B)."""
     _dev(lm_logp, sims, ids, targets, vals, knn_vals)
     _f32(lm_logp, sims)
     _dtype(ids, torch.int64, "ids"), _dtype(targets, torch.int64, "targets")
@@ -297,6 +322,11 @@ def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_sto
     if knn_vals is not None:
         assert knn_vals.dtype == torch.int32
         d.knn_vals = knn_vals.data_ptr()
+    elif vals is not None and vals.dim() == 1 and vals.is_contiguous() and k <= 1024 and \
+            (vals_tag is True or (vals_tag == "auto" and vals.shape[0] >= TAG_TABLE_MIN_ROWS)):
+        tag = label_tags(vals, build=not torch.cuda.is_current_stream_capturing())
+        if tag is not None:
+            d.vals_tag = tag.data_ptr()
     d.n, d.k = n, k
     d.temperature, d.lmbda = temperature, lmbda
     d.out_logp, d.out_pknn, d.out_recall = out.data_ptr(), pk.data_ptr(), rec.data_ptr()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNLM_ABI_VERSION 6
+#define GNNLM_ABI_VERSION 7
 #define GNNLM_OK 0
 #define GNNLM_E_INVALID (-22)
 #define GNNLM_E_NOMEM (-12)
@@ -244,8 +244,15 @@ typedef struct gnnlm_knn_interp {
     float* out_logp;           /* [n] */
     float* out_pknn;           /* optional [n] */
     int64_t* out_recall;       /* optional [n] */
+    /* ABI 7, optional: one TAG byte per label row, vals_tag[r] = gnnlm_label_tag(vals[r]) (built once per store by
+     * gnnlm_label_tags).  A neighbour can only match the target when the tags match, so the k gathers of `vals[knns]`
+     * (knn_model.py:198) read this 4x smaller table and the 4-byte label only on a tag match (1 in 256 + the true hits):
+     * same result bit for bit, a quarter of the table behind the random reads. */
+    const uint8_t* vals_tag;
 } gnnlm_knn_interp_t;
 int gnnlm_knn_interp(const gnnlm_knn_interp_t* desc, void* stream);
+/* tag[r] = (uint32(vals[r]) * 2654435761) >> 24 for the n rows of a label table (int16 / int32) */
+int gnnlm_label_tags(const void* vals, int32_t vals_itemsize, int64_t n, uint8_t* tag, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * On-device kNN search, selection half: fold one chunk of scores into a running top-k per query.

@@ -446,9 +446,12 @@ def test_knn_interp_golden(ops, dev, golden, metric_type, t):
         sims = oknn.sims_from_search(g[tag + ".dists"], g[tag + ".ids"], q, metric_type, g["keys"], cosine).float()
         n = sims.shape[0]
         lm = torch.log(torch.linspace(0.01, 0.9, n))
-        out, pk, rec = ops.knn_interp(lm.to(dev), sims.contiguous().to(dev), torch.from_numpy(g[tag + ".ids"]).to(dev),
-                                      torch.from_numpy(g["targets"]).to(dev), t, 0.25,
-                                      vals=torch.from_numpy(g["vals"]).to(dev))
+        vals_d = torch.from_numpy(g["vals"]).to(dev)
+        args_ = (lm.to(dev), sims.contiguous().to(dev), torch.from_numpy(g[tag + ".ids"]).to(dev), torch.from_numpy(g["targets"]).to(dev), t, 0.25)
+        out, pk, rec = ops.knn_interp(*args_, vals=vals_d, vals_tag=False)
+        # the gather through the one-byte tag table (gnnlm_knn_interp_t.vals_tag): the same bits
+        out_t, pk_t, rec_t = ops.knn_interp(*args_, vals=vals_d.reshape(-1).contiguous(), vals_tag=True)
+        assert torch.equal(out, out_t) and torch.equal(pk, pk_t) and torch.equal(rec, rec_t)
         np.testing.assert_allclose(pk.cpu().numpy(), g[tag + ".p"], rtol=2e-5, atol=1e-7)
         assert np.array_equal(rec.cpu().numpy(), g[tag + ".recall"])                    # integer: exact
         ref = oknn.combine_knn_and_vocab_probs(torch.from_numpy(g[tag + ".p"]), lm, 0.25)
@@ -468,8 +471,10 @@ def test_knn_interp_full_size(ops, dev, k):
     for t, lmbda in [(0.01, 0.1), (1.0, 0.25)]:
         p_ref, rec_ref = oknn.knn_target_prob(sims, ids, vals, targets, t)
         ref = oknn.combine_knn_and_vocab_probs(p_ref, torch.from_numpy(lm), lmbda)
-        out, pk, rec = ops.knn_interp(*(torch.from_numpy(a).to(dev) for a in (lm, sims, ids, targets)), t, lmbda,
-                                      vals=torch.from_numpy(vals).to(dev))
+        vals_d = torch.from_numpy(vals).to(dev)
+        out, pk, rec = ops.knn_interp(*(torch.from_numpy(a).to(dev) for a in (lm, sims, ids, targets)), t, lmbda, vals=vals_d, vals_tag=False)
+        out_t, pk_t, rec_t = ops.knn_interp(*(torch.from_numpy(a).to(dev) for a in (lm, sims, ids, targets)), t, lmbda, vals=vals_d, vals_tag=True)
+        assert torch.equal(out, out_t) and torch.equal(pk, pk_t) and torch.equal(rec, rec_t)      # tag table: same bits (k <= 1024)
         assert np.array_equal(rec.cpu().numpy(), rec_ref.numpy())
         np.testing.assert_allclose(pk.cpu().numpy(), p_ref.numpy(), rtol=5e-5, atol=1e-7)
         np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=5e-6)
@@ -582,3 +587,40 @@ def test_gemm_per_row_bias_on_large_tiles(ops, dev):
     ref = 1.25 * (A.double() @ W.double().t()) + (gate.double() * bias.double())[:, None] + R.double()
     scale = 1.25 * (A.abs().double() @ W.abs().double().t()) + R.abs().double() + 1.0
     assert ((out.double() - ref).abs() / scale).max() < 5e-7
+
+
+def test_knn_interp_tag_table(ops, dev):
+    """gnnlm_label_tags + the tag path of knn_interp: int16 and int32 tables, tag collisions (labels that differ from the target
+    but share its tag byte), -1 ids (wrap to the last row), rows outside a shard, an updated table (the cache follows the
+    tensor's version counter)."""
+    rs = np.random.RandomState(21)
+    n, k, N = 64, 300, 70000
+    tag_of = lambda v: ((np.asarray(v).astype(np.int64) & 0xffffffff) * 2654435761 & 0xffffffff) >> 24
+    for dt, V in ((np.int32, 267744), (np.int16, 30000)):
+        vals = rs.randint(0, V, size=N).astype(dt)
+        targets = rs.randint(0, V, size=n).astype(np.int64)
+        ids = rs.randint(0, N, size=(n, k)).astype(np.int64)
+        ids[::3, -2:] = -1
+        # plant true hits and collisions: labels with the target's tag but another value
+        for r in range(n):
+            pool = np.nonzero(tag_of(np.arange(V)) == tag_of(targets[r]))[0]
+            vals[ids[r, 0]] = targets[r]
+            vals[ids[r, 1:6]] = pool[pool != targets[r]][:5]
+        vals_d = torch.from_numpy(vals).to(dev)
+        tags = ops.label_tags(vals_d)
+        assert np.array_equal(tags.cpu().numpy(), tag_of(vals).astype(np.uint8))
+        sims = np.sort(rs.uniform(0.2, 0.9, size=(n, k)).astype(np.float32), axis=1)[:, ::-1].copy()
+        lm = np.log(rs.uniform(1e-4, 1, size=n)).astype(np.float32)
+        a = [torch.from_numpy(x).to(dev) for x in (lm, sims, ids, targets)]
+        for row0, n_store in ((0, N), (1000, N + 5000)):                        # whole table / a shard of a larger store
+            ref = ops.knn_interp(*a, 0.01, 0.25, vals=vals_d, n_store=n_store, row0=row0, vals_tag=False)
+            got = ops.knn_interp(*a, 0.01, 0.25, vals=vals_d, n_store=n_store, row0=row0, vals_tag=True)
+            assert all(torch.equal(x, y) for x, y in zip(ref, got))
+            assert row0 or int(ref[2].sum()) >= n                                # (whole table: every planted hit is found)
+        p_ref, rec_ref = oknn.knn_target_prob(sims, ids, vals, targets, 0.01)
+        got = ops.knn_interp(*a, 0.01, 0.25, vals=vals_d, vals_tag=True)
+        assert np.array_equal(got[2].cpu().numpy(), rec_ref.numpy())
+        vals_d[ids[5, 0]] = int(targets[5]) ^ 1                                 # in-place update: the cached tags are stale, the version says so
+        ref = ops.knn_interp(*a, 0.01, 0.25, vals=vals_d, vals_tag=False)
+        got = ops.knn_interp(*a, 0.01, 0.25, vals=vals_d, vals_tag=True)
+        assert all(torch.equal(x, y) for x, y in zip(ref, got))

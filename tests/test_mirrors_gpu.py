@@ -440,3 +440,90 @@ def test_eval_lm_word_outputs(dev, tmp_path, caplog):
         eval_lm.cli_main(base1 + ["--remove-bpe"])
     with pytest.raises(ValueError):
         eval_lm.cli_main(base1 + ["--output-knn-recall", "--output-word-probs"])
+
+
+def test_quantize_features_producer(dev, tmp_path):
+    """`python -m gnnlm_amd.quantize_features` (knn/quantize_features.py:29-157): strided sample -> OPQ + PQ trained on the GPU ->
+    `quantizer` in faiss's serialisation + `quantized-keys.npy` as a real .npy; the codes are the oracle's encode under the trained
+    codebook, the logged error is the reference's definition, OPQ training beats the untrained rotation, `eval_quantizer` and the
+    eval driver read the outputs."""
+    from gnnlm_amd import eval_quantizer, quantize_features
+    from gnnlm_amd.faiss_io import read_pq_quantizer
+    from gnnlm_amd.pq_wrapper import TorchPQCodec
+    from oracle import pq as opq_
+    rs = np.random.RandomState(11)
+    N, d, M = 41_000, 64, 16
+    # anisotropic, correlated keys: a rotation that balances the sub-spaces matters
+    z = rs.randn(N, d).astype(np.float32) * (np.linspace(3.0, 0.05, d) ** 1)[None, :]
+    mix = np.linalg.qr(rs.randn(d, d))[0].astype(np.float32)
+    keys = (z @ mix + 0.3 * rs.randn(1, d)).astype(np.float16)
+    data = tmp_path / "data-bin"
+    write_dstore(str(data / "train_dstore"), keys, rs.randint(4, 500, N).astype(np.int16), 500)
+    argv = ["--data-dir", str(data), "--subset", "train", "--index", f"OPQ{M}_{d},,PQ{M}", "--code-size", str(M), "--chunk-size", "20000",
+            "--compute-error", "--pq-iters", "12", "--opq-iters", "8", "--encode-rows", "16384"]
+    out = quantize_features.main(quantize_features.get_parser().parse_args(argv))
+    codes = np.load(str(data / "train_dstore" / "quantized-keys.npy"))                    # language_modeling.py:276
+    assert codes.shape == (N, M) and codes.dtype == np.uint8 and out["quantized_keys"].endswith("quantized-keys.npy")
+    q = read_pq_quantizer(str(data / "quantizer"))
+    cen, A, b = q["centroids"], q["A"], q["b"]
+    assert cen.shape == (M, 256, d // M) and A.shape == (d, d) and b.size == 0
+    np.testing.assert_allclose(A @ A.T, np.eye(d), atol=1e-4)                            # an orthonormal rotation
+    x = keys.astype(np.float32)
+    ref = opq_.pq_encode(x, cen, A, b)
+    assert (codes != ref).mean() < 1e-3                                                   # near-ties aside, the oracle's codes
+    dec = opq_.pq_decode(codes, cen, A, b)
+    per_batch = [(((x[s:s + 8192] - dec[s:s + 8192]) ** 2).sum() / (x[s:s + 8192] ** 2).sum()) * len(x[s:s + 8192]) for s in range(0, N, 8192)]
+    assert abs(out["avg_reconstruction_error"] - sum(per_batch) / N) < 1e-4 * out["avg_reconstruction_error"] + 1e-7   # :139-148
+    err = eval_quantizer.main(eval_quantizer.get_parser().parse_args(["--data-dir", str(data)]))
+    per_row = (((x - dec) ** 2).sum(1) / (x ** 2).sum(1)).mean()
+    assert abs(err - per_row) < 1e-4 * per_row + 1e-7                                     # eval_quantizer.py:62-66
+    # the untrained (random) rotation is worse; --pretrained_quantizer re-encodes with the stored quantizer and reproduces the codes
+    out0 = quantize_features.main(quantize_features.get_parser().parse_args([a if a != "8" else "0" for a in argv]))   # --opq-iters 0
+    assert out0["avg_reconstruction_error"] > 1.02 * out["avg_reconstruction_error"]
+    write_q = quantize_features.write_pq_quantizer
+    write_q(str(data / "quantizer"), cen, A, b, metric="l2")
+    quantize_features.main(quantize_features.get_parser().parse_args(argv + ["--pretrained_quantizer"]))
+    assert np.array_equal(np.load(str(data / "train_dstore" / "quantized-keys.npy")), codes)
+    # the codec the hot path builds from the file decodes them like the oracle
+    c = TorchPQCodec.from_file(str(data / "quantizer")).to(dev)
+    got = c.decode(torch.from_numpy(codes[:3000]).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(got, dec[:3000], atol=2e-5, rtol=1e-5)
+    # a reducing block (one_billion/find_knn.sh:24 `OPQ128_512`): A [d_out, d_in] with orthonormal rows
+    argv_r = [a for a in argv]
+    argv_r[argv_r.index(f"OPQ{M}_{d},,PQ{M}")] = f"OPQ{M // 2}_{d // 2},,PQ{M // 2}"
+    argv_r[argv_r.index("--code-size") + 1] = str(M // 2)
+    out_r = quantize_features.main(quantize_features.get_parser().parse_args(argv_r))
+    q_r = read_pq_quantizer(str(data / "quantizer"))
+    assert q_r["A"].shape == (d // 2, d) and q_r["centroids"].shape == (M // 2, 256, d // M)
+    assert np.load(str(data / "train_dstore" / "quantized-keys.npy")).shape == (N, M // 2)
+    np.testing.assert_allclose(q_r["A"] @ q_r["A"].T, np.eye(d // 2), atol=1e-4)
+    assert out_r["avg_reconstruction_error"] < 0.4                              # (8-byte codes of 64-d keys, half the dimensions dropped)
+
+
+def test_eval_lm_reads_the_producers_outputs(dev, tmp_path):
+    """quantize_features -> eval_lm: the driver scores a split over a store whose codes and quantizer file came from the producer
+    (checkpoint without tgt_quantizer buffers, `quantizer_path` override as in the recipe, hgt_lm_wiki103_reproduce.sh:86), and the
+    ppl equals the oracle's over the same codes."""
+    from gnnlm_amd import eval_lm, quantize_features
+    from gnnlm_amd.faiss_io import read_pq_quantizer
+    from oracle import pipeline
+    c = make_data_dir(tmp_path)
+    data, base, model, T, n_test, blk = c["data"], c["base"], c["model"], c["T"], c["n_test"], c["blk"]
+    quantize_features.main(quantize_features.get_parser().parse_args(
+        ["--data-dir", str(data), "--subset", "train", "--index", "OPQ16_64,,PQ16", "--code-size", "16", "--chunk-size", "2000",
+         "--pq-iters", "5", "--opq-iters", "2"]))
+    q = read_pq_quantizer(str(data / "quantizer"))
+    ck = torch.load(str(tmp_path / "ckpt.pt"), weights_only=False)
+    for k_ in [k_ for k_ in ck["model"] if "tgt_quantizer" in k_]:
+        del ck["model"][k_]
+    torch.save(ck, str(tmp_path / "ckpt.pt"))
+    base = list(base)
+    base[base.index("--model-overrides") + 1] = "{'orig_prob_ratio': 0.0, 'quantizer_path': '%s'}" % str(data / "quantizer")
+    res = eval_lm.cli_main(base)
+    model = dict(model, centroids=q["centroids"], A=q["A"], b=q["b"], codes=np.load(str(data / "train_dstore" / "quantized-keys.npy")))
+    total = 0.0
+    for s in range(0, n_test, T):
+        e = min(n_test, s + T)
+        one = {"neighbor_idxs": blk["ids"][s:e], "tgt_feats": blk["tgt_feats"][s:e], "targets": blk["targets"][s:e], "knn_sims": None, "knn_ids": None}
+        total += pipeline.eval_block(one, model, 0.0, 1.0)["lm_logp"].double().sum().item()
+    assert res["count"] == n_test and abs(res["score_sum"] - total) < 1e-4 * n_test
