@@ -217,6 +217,10 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
     const bool dedup = io.group_ids != nullptr;
     GNNLM_REQUIRE(!dedup || (ntgt && !dense0 && !io.fetched_codes && io.group_index && io.n_unique >= 0 && !io.out_ntgt && !io.out_valid),
                   "hgt: group_ids needs group_index, a multi-layer model on a resident store and no ntgt outputs");
+    // ABI 7: centre states kept across calls (io.state_cache): group_ids are the groups the cache lacks, group_index holds slots
+    const bool cached = io.state_cache != nullptr;
+    GNNLM_REQUIRE(!cached || (dedup && io.cache_cap > 0 && (io.group_slot || io.n_unique == 0) && m.n_layers > 1),
+                  "hgt: state_cache needs group_ids / group_index / group_slot, cache_cap > 0 and a multi-layer model");
     const int64_t G = dedup ? io.n_unique : Tt * kg, S = G * n_g;
     GNNLM_REQUIRE(dk % 4 == 0 && d % 4 == 0 && dpq % 4 == 0, "hgt: d_k and the PQ dimension must be multiples of 4");
     GNNLM_REQUIRE(dense0 || m.opq_at || dpq == d, "hgt: without OPQ the PQ dimension must equal d");
@@ -344,10 +348,13 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             a.U = b.U; a.ids = io.ids; a.T = (int)Tt; a.H = H; a.D = din; a.kg = kg;
             a.Z = b.Z; a.has_nb = b.has_nb;
             a.n_store = m.n_store;
-            if (ntgt || dense0) { a.nb_valid = valid; a.nb_valid_stride = n_g; }        // centre slot of each group
+            if (cached) { }                                      // a cached group is a valid one: x_index >= 0 says it all
+            else if (ntgt || dense0) { a.nb_valid = valid; a.nb_valid_stride = n_g; }        // centre slot of each group
             else if (io.fetched_valid) { a.nb_valid = io.fetched_valid; a.nb_valid_stride = io.fetched_centres_only ? 1 : n_g; }
             if (dedup) a.x_index = io.group_index;
-            if (l == 0 && !dense0) {
+            if (cached && l > 0) {
+                a.X = io.state_cache + (int64_t)(l - 1) * io.cache_cap * d; a.ldx = d; a.x_group_stride = 1;
+            } else if (l == 0 && !dense0) {
                 a.codes = io.fetched_codes ? io.fetched_codes : m.codes;
                 if (!io.fetched_codes) a.shards = m.shards;
                 a.codes_direct = io.fetched_codes ? (io.fetched_centres_only ? 1 : n_g) : 0;
@@ -431,6 +438,8 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             }
             hn_cur = hn_out;
             ld_hn = d;
+            // the centre slot (row g * n_g) of every computed group -> its cache slot, for layer l + 1's star edges now and later
+            if (cached && !last) TRY(scatter_rows(hn_out, (int64_t)n_g * d, io.state_cache + (int64_t)l * io.cache_cap * d, d, io.group_slot, G, d, s));
         }
         ht_in = ht_out;
     }

@@ -111,6 +111,8 @@ int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta
               const int32_t* rows_idx = nullptr);                    // only the rows rows_idx[0..rows) (of x, residual, out, valid)
 // idx[g * n_sel + j] = g * n_g + sel[j]
 int group_rows(int32_t* idx, int64_t n_groups, int n_g, const int* sel, int n_sel, hipStream_t stream);
+// dst[slots[g]][0..d) = src[g * ld_src][0..d) for g < n (rows of d floats, d % 4 == 0)
+int scatter_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, const int32_t* slots, int64_t n, int d, hipStream_t stream);
 
 // out = 0.5 * (a + b)
 int mean2(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);

@@ -377,6 +377,24 @@ __global__ __launch_bounds__(256) void group_rows_kernel(int32_t* idx, int64_t n
     const int64_t g = e / n_sel;
     idx[e] = (int32_t)(g * n_g + sel.c[(int)(e - g * n_sel)]);
 }
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, int64_t ld_src, float* __restrict__ dst, int64_t ld_dst,
+                                                           const int32_t* __restrict__ slots, int64_t n, int d4) {
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);         // one wave per row
+    if (g >= n) return;
+    const int64_t slot = slots[g];
+    if (slot < 0) return;
+    const float4* a = reinterpret_cast<const float4*>(src + g * ld_src);
+    float4* o = reinterpret_cast<float4*>(dst + slot * ld_dst);
+    for (int e = threadIdx.x & 63; e < d4; e += 64) o[e] = a[e];
+}
+int scatter_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, const int32_t* slots, int64_t n, int d, hipStream_t stream) {
+    GNNLM_REQUIRE(src && dst && slots && n >= 0 && d > 0 && d % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "scatter_rows: bad arguments");
+    if (n == 0) return OK;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)cdiv(n, (int64_t)4)), dim3(256), 0, stream, src, ld_src, dst, ld_dst, slots, n, d / 4);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
 int group_rows(int32_t* idx, int64_t n_groups, int n_g, const int* sel, int n_sel, hipStream_t stream) {
     GNNLM_REQUIRE(idx && n_sel > 0 && n_sel <= 8 && n_groups * n_g < (1ll << 31), "group_rows: bad arguments");
     if (n_groups == 0) return OK;

@@ -188,6 +188,58 @@ def prepare_hgt_weights(sd: Dict[str, torch.Tensor], n_layers: int, n_heads: int
     return layers, codec
 
 
+class CentreStateCache:
+    """Cross-batch cache of the context groups' centre states (``gnnlm_hgt_io_t.state_cache``).
+
+    The star edges of layer l >= 1 read the centre node of a context group after l ntgt updates; ntgt nodes never receive from
+    tgt nodes (token_block_dataset.py:395-398: only `ntgt -> tgt` and `ntgt <-> ntgt` edges), so that state is a function of
+    the centre's datastore row alone -- the same for every token, block and batch that retrieves the row.  Real neighbour lists
+    repeat rows heavily (the reference's own "todo: merge same nodes", :355, is the within-block half of this).  The cache
+    keeps ``[n_layers - 1, capacity, d]`` float32 states in HBM, a direct row -> slot table (int32 per datastore row: no
+    hashing) and fills slots in arrival order; when it is full it is emptied (the batch that did not fit starts the next
+    generation).  Exact: the states are the ones the un-cached call computes."""
+
+    def __init__(self, n_store, n_layers, d, capacity, device):
+        self.n_store, self.capacity, self.device = n_store, int(capacity), device
+        self.slot_of = torch.full((n_store,), -1, dtype=torch.int32, device=device)
+        self.id_of_slot = torch.empty(self.capacity, dtype=torch.int64, device=device)
+        self.states = torch.empty(n_layers - 1, self.capacity, d, dtype=torch.float32, device=device)
+        self.used = 0
+        self.stream = torch.cuda.current_stream(device).cuda_stream          # slots are reused in stream order: one stream only
+        self.stats = {"lookups": 0, "groups": 0, "computed": 0, "generations": 1}
+
+    def clear(self):
+        if self.used:
+            self.slot_of[self.id_of_slot[:self.used]] = -1
+        self.used = 0
+        self.stats["generations"] += 1
+
+    def assign(self, flat_ids):
+        """flat_ids int64 [n]: neighbour rows (-1 / out of range: none) -> (miss_ids int64 [m] ascending, miss_slots int32 [m],
+        slot int32 [n] with -1 for "not a neighbour"), or None when the batch's new groups alone exceed the capacity.
+        One host sync (the number of new groups), like the within-batch merge it extends."""
+        valid = (flat_ids >= 0) & (flat_ids < self.n_store)
+        key = torch.where(valid, flat_ids, torch.zeros_like(flat_ids))
+        slot = torch.where(valid, self.slot_of[key], torch.full_like(key, -1, dtype=torch.int32))
+        miss = torch.unique(key[valid & (slot < 0)])
+        if self.used + miss.numel() > self.capacity:
+            self.clear()
+            miss = torch.unique(key[valid])
+            if miss.numel() > self.capacity:
+                return None
+        m = miss.numel()
+        new = torch.arange(self.used, self.used + m, dtype=torch.int32, device=self.device)
+        if m:
+            self.slot_of[miss] = new
+            self.id_of_slot[self.used:self.used + m] = miss
+            self.used += m
+            slot = torch.where(valid, self.slot_of[key], torch.full_like(slot, -1))
+        self.stats["lookups"] += 1
+        self.stats["groups"] += int(flat_ids.numel())
+        self.stats["computed"] += m
+        return miss, new, slot.contiguous()
+
+
 class HGT(nn.Module):
     """Drop-in for ``HGT`` of fairseq/models/hgt.py:459-513 (eval forward, non-incremental)."""
 
@@ -216,6 +268,10 @@ class HGT(nn.Module):
         self.gemm_precision = 0     # 0 exact f32 MFMA | 1 bf16x3 | 2 bf16x6 (opt-in split-bf16 emulation)
         self.dedup_groups = os.environ.get("GNNLM_DEDUP", "1") != "0"      # merge equal context groups of a batch (multi-layer models)
         self.last_groups = None                                              # (groups of the last batch, distinct ones)
+        # centre states of context groups kept ACROSS batches (CentreStateCache): HBM budget in GiB, 0 = off
+        self.state_cache_gib = float(os.environ.get("GNNLM_STATE_CACHE_GIB", "16"))
+        self.state_cache_slots = None
+        self.state_cache = None
 
     def _load_from_state_dict(self, *a, **k):
         self._prepared = None
@@ -256,6 +312,27 @@ class HGT(nn.Module):
         self._prepared = {"key": key, "model": m, "layers_arr": arr, "tensors": (layers, codec), "ws": None,
                           "store": store}
         return self._prepared
+
+    def _state_cache_for(self, prep, store, device):
+        """The centre-state cache of (these weights, this store), or None (off, another stream, stale)."""
+        if self.state_cache_gib <= 0 or self.n_layers < 2:
+            return None
+        c = self.state_cache
+        key = (prep["key"], id(store), store.codes.data_ptr(), store.n_store)
+        if c is not None and (getattr(c, "key", None) != key):
+            c = self.state_cache = None                                       # other weights / another store: the states are stale
+        if c is None:
+            per = (self.n_layers - 1) * self.hidden_dim * 4 + 8
+            cap = int(min(store.n_store, max(0, self.state_cache_gib * 2 ** 30 - 4 * store.n_store) // per))
+            if self.state_cache_slots is not None:                            # explicit capacity (tests, tuning)
+                cap = int(min(store.n_store, self.state_cache_slots))
+            if cap < 1:
+                return None
+            c = self.state_cache = CentreStateCache(store.n_store, self.n_layers, self.hidden_dim, cap, device)
+            c.key = key
+        if c.stream != torch.cuda.current_stream(device).cuda_stream:
+            return None
+        return c
 
     @staticmethod
     def _bind_store(m, store):
@@ -327,11 +404,24 @@ class HGT(nn.Module):
                 and not torch.cuda.is_current_stream_capturing()              # (a captured step stays sync-free: no merging)
                 and getattr(st, "shards", None) is None and st.row0 == 0 and st.codes.shape[0] == st.n_store):
             flat = ids.reshape(-1)
-            key = torch.where((flat >= 0) & (flat < st.n_store), flat, torch.full_like(flat, -1))
-            u, inv = torch.unique(torch.cat([key.new_full((1,), -1), key]), return_inverse=True)     # u[0] == -1 always
-            group_ids = u[1:].contiguous()
-            group_index = (inv[1:] - 1).to(torch.int32).contiguous()                                  # -1: not a neighbour
-            io.group_ids, io.n_unique, io.group_index = group_ids.data_ptr(), group_ids.numel(), group_index.data_ptr()
+            hit = None
+            cache = self._state_cache_for(prep, st, tgt.device)
+            if cache is not None:
+                hit = cache.assign(flat)
+            if hit is not None:
+                # across batches: only the groups the cache lacks are computed; every neighbour reads its group's slot
+                group_ids, group_slot, group_index = hit
+                # (an empty tensor has no address, and a null group_ids means "no merging" to the C side: name real memory)
+                io.group_ids = group_ids.data_ptr() if group_ids.numel() else cache.id_of_slot.data_ptr()
+                io.group_slot = group_slot.data_ptr() if group_slot.numel() else cache.slot_of.data_ptr()
+                io.n_unique, io.group_index = group_ids.numel(), group_index.data_ptr()
+                io.state_cache, io.cache_cap = cache.states.data_ptr(), cache.capacity
+            else:
+                key = torch.where((flat >= 0) & (flat < st.n_store), flat, torch.full_like(flat, -1))
+                u, inv = torch.unique(torch.cat([key.new_full((1,), -1), key]), return_inverse=True)     # u[0] == -1 always
+                group_ids = u[1:].contiguous()
+                group_index = (inv[1:] - 1).to(torch.int32).contiguous()                                  # -1: not a neighbour
+                io.group_ids, io.n_unique, io.group_index = group_ids.data_ptr(), group_ids.numel(), group_index.data_ptr()
             self.last_groups = (flat.numel(), group_ids.numel())
         out_tgt = torch.empty_like(tgt)
         io.out_tgt = out_tgt.data_ptr()

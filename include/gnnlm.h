@@ -448,6 +448,14 @@ typedef struct gnnlm_hgt_io {
      * group_ids [n_unique] the distinct valid rows, group_index [n_blocks*T*kg] the group of neighbour (i, j) (-1: not a
      * neighbour).  Results are those of the un-merged graph.  Not with fetched_codes / ntgt_feats / out_ntgt / out_valid. */
     const int64_t* group_ids;  int64_t n_unique;  const int32_t* group_index;
+    /* ABI 7, optional, with group_ids: a CROSS-BATCH cache of the centre states.  The star edges of layer l >= 1 read the
+     * centre slot of a group after l ntgt updates, and that state is a function of the centre row alone (fixed weights and
+     * store) -- so it is kept between calls: state_cache [n_layers - 1][cache_cap][d] f32, owned by the caller, who also owns
+     * the row -> slot map.  Then group_ids / n_unique name only the groups the cache does NOT hold yet (the ntgt pipeline runs
+     * over those and their centre states are written to slots group_slot [n_unique]), and group_index [n_blocks*T*kg] holds
+     * the cache SLOT of neighbour (i, j) (-1: not a neighbour), new and old alike.  Same kernels, same per-row arithmetic:
+     * the result is that of the un-cached call. */
+    float* state_cache;  int64_t cache_cap;  const int32_t* group_slot;
 } gnnlm_hgt_io_t;
 
 /* x = gelu(x) in place, the exact (erf) form of torch.nn.functional.gelu (input adapters of HGT, hgt.py:507) */

@@ -220,3 +220,69 @@ def test_hgt_dedup_context_groups(dev, L):
     assert model.last_groups == (T * kg, 0)
     model.dedup_groups = False
     assert np.array_equal(o1, model(none, features={"tgt": x[:T]})["tgt"].cpu().numpy())
+
+
+@pytest.mark.parametrize("L", [2, 3])
+def test_hgt_centre_state_cache(dev, L):
+    """The cross-batch cache of context groups' centre states (gnnlm_hgt_io_t.state_cache, ABI 7): a sequence of batches with
+    overlapping neighbour rows -- cold, partly cached, fully cached, a generation turnover (cache emptied when full), a batch
+    whose new groups exceed the capacity (falls back to the within-batch merge), new weights (the cache is dropped) -- every
+    output bit-identical to the un-cached call, and equal to the un-merged float64 oracle."""
+    from gnnlm_amd.hgt import HGT, NeighborGraph
+    d, H, M, dsub, T, kg, l, r, nblk = 128, 8, 16, 8, 12, 10, 2, 2, 2
+    rs = np.random.RandomState(70 + L)
+    n_store = 500
+    codes = rs.randint(0, 256, size=(n_store, M)).astype(np.uint8)
+    cen = (rs.randn(M, 256, dsub) * 0.5).astype(np.float32)
+    A = (rs.randn(M * dsub, d) / np.sqrt(M * dsub)).astype(np.float32)
+    b = (rs.randn(M * dsub) * 0.1).astype(np.float32)
+    sd = {k: v.numpy() for k, v in ohgt.init_hgt_weights(L, d, H, seed=6).items()}
+    store = make_store(dev, codes, cen, A, b)
+    model = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=L, n_heads=H)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    plain_model = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=L, n_heads=H)
+    plain_model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    plain_model.state_cache_gib = 0.0                                         # the within-batch merge only (round 3's path)
+    model.state_cache_slots = 60
+
+    def batch(pool_lo, pool_hi, seed):
+        r_ = np.random.RandomState(seed)
+        pool = np.concatenate([[0, n_store - 1], r_.randint(pool_lo, pool_hi, 25)])
+        nb = pool[r_.randint(0, len(pool), size=(nblk * T, kg))].astype(np.int64)
+        nb[r_.rand(*nb.shape) < 0.05] = -1
+        nb[3] = -1
+        nb[4, 1] = n_store + 9
+        return nb, r_.randn(nblk * T, d).astype(np.float16).astype(np.float32)
+
+    def run(mdl, nb, tgt):
+        G = NeighborGraph(ids=torch.from_numpy(nb).to(dev), n_blocks=nblk, T=T, left=l, right=r, store=store)
+        return mdl(G, features={"tgt": torch.from_numpy(tgt).to(dev)})["tgt"].cpu().numpy()
+
+    a, b_, c = batch(0, 200, 1), batch(100, 300, 2), batch(300, 500, 3)
+    seq = [a, b_, a, c, a, b_]                                                # 60 slots: c (or the a after it) turns the generation over
+    computed = []
+    for i, (nb, tgt) in enumerate(seq):
+        got = run(model, nb, tgt)
+        assert model.state_cache is not None
+        computed.append(model.last_groups[1])
+        assert np.array_equal(got, run(plain_model, nb, tgt)), i              # same kernels, same per-row arithmetic: same bits
+    st = model.state_cache.stats
+    assert computed[1] < plain_model.last_groups[1] and computed[2] == 0      # b: only its new rows; a again: nothing to compute
+    assert st["generations"] >= 2 and st["computed"] == sum(computed)
+    nb, tgt = a
+    nbo = np.where(nb >= n_store, -1, nb)
+    ref = np.concatenate([oracle_hgt(sd, L, H, tgt[i * T:(i + 1) * T], nbo[i * T:(i + 1) * T], codes, cen, A, b, n_store, l, r)["tgt"].numpy()
+                          for i in range(nblk)])
+    assert np.abs(run(model, nb, tgt) - ref).max() < 1e-4
+    # a capacity below one batch's distinct groups: the call falls back to the within-batch merge
+    model.state_cache_slots, model.state_cache = 5, None
+    assert np.array_equal(run(model, *a), run(plain_model, *a)) and model.state_cache.used == 0
+    # new weights: cached states are stale and dropped
+    model.state_cache_slots, model.state_cache = 400, None
+    run(model, *a)
+    old_cache = model.state_cache
+    assert old_cache.used > 0
+    sd2 = {k: v.numpy() for k, v in ohgt.init_hgt_weights(L, d, H, seed=9).items()}
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd2.items()}, strict=True)
+    plain_model.load_state_dict({k: torch.as_tensor(v) for k, v in sd2.items()}, strict=True)
+    assert np.array_equal(run(model, *a), run(plain_model, *a)) and model.state_cache is not old_cache
