@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-extras", dest="extras", action="store_false",
                     help="skip the recipe_L3 and driver_path sub-benchmarks (run after the timed region, N = 1 only)")
     ap.add_argument("--cpu-tokens", type=int, default=384)
+    ap.add_argument("--l3-blocks", type=int, default=16, help="blocks per step of the 3-layer recipe sub-benchmark (recipe_L3)")
+    ap.add_argument("--l3-steps", type=int, default=20)
+    ap.add_argument("--l3-cache-gib", type=float, default=16.0, help="HBM budget of the cross-batch centre-state cache in recipe_L3")
     ap.add_argument("--search-check", type=int, default=32,
                     help="queries of the kNN-search sub-benchmark checked against the float64 oracle before it is timed (0: skip)")
     ap.add_argument("--small", action="store_true", help="tiny shapes (plumbing check only)")
@@ -276,11 +279,47 @@ def verify_block(eng, batch, args, cpu_model, n_tok):
     return res
 
 
+def searched_neighbour_ids(args, dev, n_tokens, T, n_keys=1_000_000, d_c=256, n_clusters=4000, noise=0.9, stay=0.7, seed=7):
+    """Neighbour ids as the pipeline's own producer makes them: an exact cosine kNN search (the `ExactIndex` behind
+    `python -m gnnlm_amd.find_knn`, knn/find_knn.py:55-70) of a token stream over a CLUSTERED synthetic corpus -- `n_keys` keys
+    around `n_clusters` centres; a block's tokens walk through the clusters (a token stays in its predecessor's cluster with
+    probability `stay`: topical text), each token = its centre + noise.  Returns ids [n_tokens, k_g] as STORE rows (key i lives
+    in row i * (n_store // n_keys), so context rows are distinct rows) and a description.  The overlap of the lists is a
+    property of the search result, not of this function."""
+    from gnnlm_amd.knn_model import ExactIndex
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    centres = torch.randn(n_clusters, d_c, generator=g, device=dev)
+    which = torch.randint(0, n_clusters, (n_keys,), generator=g, device=dev)
+    keys = (centres[which] + noise * torch.randn(n_keys, d_c, generator=g, device=dev)).to(torch.float16)
+    index = ExactIndex(keys, metric="ip", cosine=True, device=dev)
+    # the token stream: cluster of token t = cluster of t - 1 with probability `stay` (never across a block boundary)
+    fresh = torch.randint(0, n_clusters, (n_tokens,), generator=g, device=dev)
+    keep = torch.rand(n_tokens, generator=g, device=dev) < stay
+    keep[::T] = False
+    seg = torch.cumsum((~keep).to(torch.int64), 0) - 1                     # tokens of one stay-run share the run's first draw
+    cl = fresh[(~keep).nonzero().reshape(-1)][seg]
+    q = centres[cl] + noise * torch.randn(n_tokens, d_c, generator=g, device=dev)
+    t0 = time.perf_counter()
+    _, ids = index.search_device(q, args.gcn_k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stride = max(1, args.n_store // n_keys)
+    rows = torch.where(ids >= 0, ids * stride, ids)
+    desc = {"producer": "ExactIndex.search_device (what gnnlm_amd.find_knn runs), cosine", "corpus_keys": n_keys, "corpus_dim": d_c,
+            "clusters": n_clusters, "noise": noise, "p_stay_in_cluster": stay, "search_seconds": round(dt, 2),
+            "row_of_key": f"key i -> store row {stride} i"}
+    del index, keys
+    return rows.contiguous(), desc
+
+
 def recipe_l3(args, eng1, batches, dev):
-    """The shipped recipe (`--graph_layer 3`, hgt_lm_wiki103_reproduce.sh:56) on the same store: 4 blocks per step.  Two
-    neighbour-id distributions: i.i.d. uniform over the store (no two context groups of a batch coincide: the worst case),
-    and lists that OVERLAP between neighbouring tokens as real kNN lists do (each token keeps ~60 % of its predecessor's
-    ids) -- equal context groups of a batch are computed once (exact: token_block_dataset.py:355 'merge same nodes')."""
+    """The shipped recipe (`--graph_layer 3`, hgt_lm_wiki103_reproduce.sh:56: the model the published 14.8 ppl belongs to) on
+    the same store, as a measured configuration of its own: `--l3-blocks` blocks per step (blocks are independent), >= 20
+    timed steps after a settle phase, per-kernel list, roofline of the dominant kernel with its PMC traffic, executed and
+    un-elided FLOP per token.  Neighbour ids: (1) i.i.d. uniform over the store -- no two context groups coincide: the worst
+    case, nothing to merge or cache; (2) SEARCHED neighbours over a clustered corpus (`searched_neighbour_ids`) -- equal groups
+    of a batch are computed once and the centre states are cached across batches (exact: token_block_dataset.py:355)."""
     from gnnlm_amd import _lib, ops
     from gnnlm_amd.engine import BlockBatch, GnnLmEngine
     from gnnlm_amd.hgt import HGT
@@ -289,50 +328,173 @@ def recipe_l3(args, eng1, batches, dev):
     hgt = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=3, n_heads=H)
     hgt.gemm_precision = eng1.hgt.gemm_precision
     eng = GnnLmEngine(hgt, eng1.asm, eng1.store, eng1.left, eng1.right)
-    nb, T = 4, args.tokens_per_sample
-    b0 = batches[0]
-    cut = lambda t: t[: nb * T].contiguous()
-    ids_u = cut(b0.ids)
-    # overlapping lists: token t keeps a random ~60 % of token t - 1's ids (same columns), the rest are fresh rows
-    g = torch.Generator(device=dev)
-    g.manual_seed(99)
-    keep = torch.rand(ids_u.shape, generator=g, device=dev) < 0.6
-    ids_o = ids_u.clone()
-    for t in range(1, ids_o.shape[0]):
-        if t % T:                                                            # lists do not carry over a block boundary
-            ids_o[t] = torch.where(keep[t], ids_o[t - 1], ids_o[t])
+    nb, T = args.l3_blocks, args.tokens_per_sample
+    n = nb * T
+    pool_feats = torch.cat([b_.tgt_feats for b_ in batches])
+    pool_tg, pool_sims, pool_kids = (torch.cat([getattr(b_, a) for b_ in batches]) for a in ("targets", "knn_sims", "knn_ids"))
+    pool_ids = torch.cat([b_.ids for b_ in batches])
+    assert pool_feats.shape[0] >= n, "--l3-blocks larger than the input pool (--pool x --blocks)"
+    n_pool = pool_feats.shape[0] // n                                     # distinct L3 batches in the pool
 
-    def run(ids):
-        batch = BlockBatch(ids=ids, tgt_feats=cut(b0.tgt_feats), targets=cut(b0.targets), n_blocks=nb, T=T,
-                           knn_sims=cut(b0.knn_sims), knn_ids=cut(b0.knn_ids))
-        acc = torch.zeros(1, device=dev, dtype=torch.float64)
-        step = lambda: ops.masked_sum_f64(eng.score(batch, args.lmbda, args.temperature)["logp"], None, acc)
-        step()
+    def batch_at(i, ids):
+        sl = slice((i % n_pool) * n, (i % n_pool + 1) * n)
+        return BlockBatch(ids=ids[sl] if ids.shape[0] >= (i % n_pool + 1) * n else ids[:n], tgt_feats=pool_feats[sl], targets=pool_tg[sl],
+                          n_blocks=nb, T=T, knn_sims=pool_sims[sl], knn_ids=pool_kids[sl])
+
+    acc = torch.zeros(1, device=dev, dtype=torch.float64)
+    step = lambda b_: ops.masked_sum_f64(eng.score(b_, args.lmbda, args.temperature)["logp"], None, acc)
+    steps = max(20, args.l3_steps)
+
+    def timed(bs, cache_gib, settle_s=0.6):
+        """`steps` timed steps over the batch list `bs` (cycled), after one profiled step and a settle phase."""
+        hgt.state_cache_gib, hgt.state_cache = cache_gib, None
+        step(bs[0])
         torch.cuda.synchronize()
         _lib.profile_begin()
-        step()
+        step(bs[1 % len(bs)])
         torch.cuda.synchronize()
         kern = _lib.profile_end()
+        t_s, i = 0.0, 2
+        while t_s < settle_s:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step(bs[i % len(bs)])
+            torch.cuda.synchronize()
+            t_s += time.perf_counter() - t0
+            i += 1
         dominant = max(kern, key=lambda k_: kern[k_]["total_ms"])
-        steps = 5
+        names = [_lib.lib().gnnlm_kernel_name(j).decode() for j in range(12)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        groups = []
         torch.cuda.synchronize()
+        _lib.profile_begin(1 << names.index(dominant))
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        marks[0].record()
+        for j in range(steps):
+            step(bs[(i + j) % len(bs)])
+            groups.append(hgt.last_groups[1] if hgt.last_groups else n * args.gcn_k)
+            marks[j + 1].record()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        e = kern[dominant]
-        grp = hgt.last_groups or (ids.numel(), ids.numel())
-        return {"hgt_layers": 3, "blocks_per_step": nb, "steps": steps, "tokens_per_s": round(steps * nb * T / dt, 1),
-                "ms_per_step": round(dt / steps * 1e3, 3), "context_groups": grp[0], "distinct_context_groups": grp[1],
-                "dominant_kernel": dominant,
-                "dominant_share_of_step": round(e["total_ms"] / sum(v["total_ms"] for v in kern.values()), 3),
-                "dominant_TFLOPs": round(e["flops"] / (e["total_ms"] / 1e3) / 1e12, 2) if e["flops"] else None,
-                "dominant_frac_of_f32_mfma_peak": round(e["flops"] / (e["total_ms"] / 1e3) / 1e12 / PEAK["mfma_f32_tflops"], 4) if e["flops"] else None}
+        prof = _lib.profile_end()[dominant]
+        per = sorted(marks[j].elapsed_time(marks[j + 1]) for j in range(steps))
+        r = roofline_entry(dominant, prof, args.precision)
+        r["traffic"], r["traffic_source"] = pmc_traffic("L3:" + dominant)
+        r["launches_per_step"] = prof["launches"] / steps
+        flop_exec = sum(v["flops"] for v in kern.values()) / n
+        return {"tokens_per_s": round(steps * n / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_step_median": round(per[len(per) // 2], 3),
+                "ms_per_step_min": round(per[0], 3), "ms_per_step_max": round(per[-1], 3), "steps": steps,
+                "context_groups_per_step": n * args.gcn_k, "groups_computed_per_step_mean": round(sum(groups) / len(groups), 1),
+                "roofline": r, "kernels": [roofline_entry(k_, v, args.precision) for k_, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"])],
+                "dominant_share_of_step": round(kern[dominant]["total_ms"] / sum(v["total_ms"] for v in kern.values()), 3),
+                "flop_per_token_executed": round(flop_exec), "executed_TFLOPs_whole_step": round(flop_exec * steps * n / dt / 1e12, 2)}
 
-    out = run(ids_u)
-    out["neighbour_ids"] = "i.i.d. uniform (no equal context groups: worst case)"
-    out["overlapping_neighbour_lists"] = dict(run(ids_o), neighbour_ids="each token keeps ~60 % of its predecessor's ids")
+    out = {"hgt_layers": 3, "blocks_per_step": nb, "tokens_per_step": n,
+           "flop_per_token_unelided_survey_8d": round(unelided_flop_per_token(3, d=d, H=H, kg=args.gcn_k, T=T)),
+           "flop_note": "`flop_per_token_executed` = what the kernels of a step compute (dead work elided, star edges absorbed: DESIGN.md 2); "
+                        "the un-elided figure is the reference's forward as written (SURVEY.md 8d), the same result"}
+    uni = [batch_at(i, pool_ids) for i in range(n_pool)]
+    out["uniform_ids"] = dict(timed(uni, 0.0), neighbour_ids="i.i.d. uniform over the store (no equal context groups: the worst case; state cache off -- it could only miss)")
+    out["uniform_ids"]["unelided_equivalent_TFLOPs"] = round(out["flop_per_token_unelided_survey_8d"] * out["uniform_ids"]["tokens_per_s"] / 1e12, 1)
+    # searched neighbours: one id table for the whole pool
+    n_srch = n_pool * n
+    ids_s, desc = searched_neighbour_ids(args, dev, n_srch, T)
+    srch = [batch_at(i, ids_s) for i in range(n_pool)]
+    flat = ids_s.reshape(n_pool, -1)
+    per_batch = [int(torch.unique(flat[i][flat[i] >= 0]).numel()) for i in range(n_pool)]
+    merged = timed(srch, 0.0)                                             # within-batch merge only (round 3's path)
+    # with the cross-batch cache: a COLD pass over the pool (what an eval run over new text does), then the steady state
+    hgt.state_cache_gib, hgt.state_cache = float(args.l3_cache_gib), None
+    colds = []
+    for rep in range(3):                                                  # pass 0 allocates (cache, workspace); passes 1, 2 are timed, each from an EMPTY cache
+        if hgt.state_cache is not None:
+            hgt.state_cache.clear()
+            hgt.state_cache.stats.update(lookups=0, groups=0, computed=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b_ in srch:
+            step(b_)
+        torch.cuda.synchronize()
+        colds.append(time.perf_counter() - t0)
+    cold = min(colds[1:])
+    st = dict(hgt.state_cache.stats) if hgt.state_cache is not None else None
+    # and the steady state of a long run over text whose rows the cache already holds (every group a hit)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b_ in srch:
+        step(b_)
+    torch.cuda.synchronize()
+    warm = time.perf_counter() - t0
+    out["searched_neighbours"] = {
+        "corpus": desc, "batches_in_pool": n_pool, "distinct_context_groups_per_batch": per_batch,
+        "distinct_context_groups_whole_pool": int(torch.unique(flat[flat >= 0]).numel()), "context_groups_per_batch": n * args.gcn_k,
+        "within_batch_merge": {k_: merged[k_] for k_ in ("tokens_per_s", "ms_per_step", "ms_per_step_median", "groups_computed_per_step_mean", "dominant_share_of_step")},
+        "with_state_cache_cold_pass": {"tokens": n_srch, "tokens_per_s": round(n_srch / cold, 1), "seconds": round(cold, 3), "cache_gib": args.l3_cache_gib,
+                                       "seconds_runs": [round(c_, 3) for c_ in colds[1:]],
+                                       "groups_computed": None if st is None else st["computed"], "groups_looked_up": None if st is None else st["groups"]},
+        "with_state_cache_all_hits": {"tokens": n_srch, "tokens_per_s": round(n_srch / warm, 1), "seconds": round(warm, 3),
+                                      "what": "the same pool again with every group's states cached: the floor of the cached path (tgt side + cache reads only)"},
+        "note": "cold pass = every batch of the pool once from an empty cache (an eval run over new text); a group's centre states are "
+                "computed the first time its row is retrieved and read from HBM afterwards (exact)"}
+    hgt.state_cache = None
+    torch.cuda.empty_cache()
+    out["through_eval_lm"] = {"what": "eval_lm.main -> SequenceScorer.generate, the recipe's command line (--max-tokens 256: one-block batches, "
+                                      "16 per launch for a multi-layer model), the reference's own timer (fairseq_cli/eval_lm.py:214-219) and the wall clock of main",
+                              "uniform_ids": driver_path_l3(args, eng1, batches, dev),
+                              "searched_neighbours": driver_path_l3(args, eng1, batches, dev, ids=ids_s, label="searched")}
+    return out
+
+
+def driver_path_l3(args, eng1, batches, dev, ids=None, label="uniform"):
+    """`eval_lm.main` -> `SequenceScorer.generate` with the 3-layer model, the recipe's command line as it stands (one-block
+    batches, `--batch-blocks` at its default: 16 per launch for a multi-layer model), over the whole input pool."""
+    import contextlib
+    import io
+    from gnnlm_amd import eval_lm, ops
+    from gnnlm_amd.hgt import HGT
+    from gnnlm_amd.model import GnnLmModel
+    torch.manual_seed(4321)
+    d, H = eng1.hgt.hidden_dim, eng1.hgt.n_heads
+    hgt = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=3, n_heads=H)
+    st = eng1.store
+    T = args.tokens_per_sample
+    cat = lambda a: torch.cat([getattr(b_, a) for b_ in batches])
+    feats, targets, nbrs, sims, kids = cat("tgt_feats"), cat("targets"), (ids if ids is not None else cat("ids")), cat("knn_sims"), cat("knn_ids")
+    n = min(feats.shape[0], nbrs.shape[0])
+    model = GnnLmModel(hgt, eng1.asm, None)
+    model.make_store = lambda codes, n_store, device: st
+
+    class Knn:
+        pos = 0
+
+        def interpolate(self, queries, targets_, lm_logp, t, lmbda, k=0):
+            m = queries.shape[0]
+            sl = slice(self.pos, self.pos + m)
+            self.pos = (self.pos + m) % n
+            return ops.knn_interp(lm_logp.contiguous(), sims[sl].contiguous(), kids[sl].contiguous(), targets_.long().contiguous(), t, lmbda,
+                                  vals=st.vals, n_store=st.n_store)
+    tabs = {"n_tok": n, "d": d, "vocab": None, "n_store": st.n_store, "feats": feats[:n], "targets": targets[:n].clamp(min=4),
+            "nbrs": nbrs[:n], "codes": st.codes, "no_pad": True}
+    a = eval_lm.get_parser().parse_args(
+        ["-", "--path", "-", "--graph", "--use-precompute-feat", "--neighbor-context", "2", "--gcn-k", str(args.gcn_k),
+         "--tokens-per-sample", str(T), "--max-tokens", str(T), "--knnlm", "--k", str(args.k), "--lmbda", str(args.lmbda),
+         "--temperature", str(args.temperature), "--knn-keytype", "gcn_feat", "--softmax-batch", str(64 * T + 1), "--device", str(dev)])
+    out = {}
+    for name, gib in (("state_cache_off", 0.0), ("state_cache_on_cold", float(args.l3_cache_gib))):
+        hgt.state_cache_gib, hgt.state_cache = gib, None
+        with contextlib.redirect_stdout(io.StringIO()):
+            a.knn_model = Knn()
+            eval_lm.main(a, tables=tabs, model=model)                          # warm-up (allocations)
+            if hgt.state_cache is not None:
+                hgt.state_cache.clear()
+            a.knn_model = Knn()
+            r = eval_lm.main(a, tables=tabs, model=model)
+        out[name] = {"tokens": r["tokens"], "tokens_per_s_generate_timer": round(r["tokens"] / r["seconds"], 1),
+                     "tokens_per_s_wall": round(r["tokens"] / r["wall_seconds"], 1), "blocks_per_batch": a.batch_blocks}
+        if label == "uniform":
+            break                                                             # (i.i.d. ids: the cache could only miss)
+    hgt.state_cache = None
+    torch.cuda.empty_cache()
     return out
 
 
@@ -485,6 +647,17 @@ def knn_search(args, eng, batches, dev, step_ms):
     torch.cuda.synchronize()
     step2 = (time.perf_counter() - t1) / 10
     knn_prof = _lib.profile_end().get("knn_interp_kernel", {"launches": 1, "total_ms": 0.0})
+    # the search of a 16-block batch (the 3-layer recipe's step: recipe_L3.*.tokens_per_s_with_search)
+    qh = q[: min(n, 4096)].contiguous()
+    idx.search_device(qh, args.k, return_vals=True)
+    torch.cuda.synchronize()
+    th = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        idx.search_device(qh, args.k, return_vals=True)
+        torch.cuda.synchronize()
+        th.append(time.perf_counter() - t0)
+    ms_4096 = sorted(th)[1] * 1e3
     scan_name = "int8-MFMA filter + exact float32 re-score" if idx.tiles is not None else "float32"
     thr_lists, cap_now = idx.dense_probes, idx.cand_cap
     # roofline of the search's dominant kernel, the int8-MFMA filter: one table byte per (query, key, sub-quantizer) goes
@@ -568,7 +741,7 @@ def knn_search(args, eng, batches, dev, step_ms):
         torch.cuda.empty_cache()
     return {"index": "synthetic OPQ64_1024,IVF4096,PQ64", "keys": args.n_store, "nprobe": 32, "k": args.k, "queries": n,
             "skewed_lists": skewed, "driver_with_search": drv,
-            "scan": scan_name, "threshold_lists": thr_lists, "cand_cap": cap_now,
+            "scan": scan_name, "threshold_lists": thr_lists, "cand_cap": cap_now, "ms_per_4096_queries": round(ms_4096, 3),
             "ms_per_batch": round(dt * 1e3, 2), "ms_per_batch_runs": [round(t_ * 1e3, 2) for t_ in times], "queries_per_s": round(n / dt, 1),
             "pairs_per_query": round(st["pairs"] / n), "survivors_per_query": round(st["survivors"] / n), "candidates_per_query": round(st["candidates"] / n), "queries_searched_again": st.get("requeried", 0),
             "kernels_ms": {k_: round(v_["total_ms"], 3) for k_, v_ in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
@@ -576,6 +749,36 @@ def knn_search(args, eng, batches, dev, step_ms):
             "step_with_search_labels_ms": round(step2 * 1e3, 4),
             "knn_interp_with_labels_us": round(knn_prof["total_ms"] * 1e3 / max(1, knn_prof["launches"]), 1),
             "tokens_per_s_step_plus_search": round(n / (dt + step2), 1)}
+
+
+def roofline_entry(name, e, precision="f32"):
+    """One kernel's roofline line from its event-timed profile entry (launches, total_ms, algorithmic flops / bytes)."""
+    bound = KERNEL_BOUND.get(name, "hbm")
+    sec = max(e["total_ms"], 1e-9) / 1e3
+    if bound == "mfma" and precision != "f32":                    # priced in the bf16 MFMA flops actually issued
+        a, p, unit = SPLIT_PRODUCTS[precision] * e["flops"] / sec / 1e12, PEAK["mfma_bf16_tflops"], "TFLOP/s"
+    elif bound == "mfma":
+        a, p, unit = e["flops"] / sec / 1e12, PEAK["mfma_f32_tflops"], "TFLOP/s"
+    else:
+        a, p, unit = e["bytes"] / sec / 1e9, PEAK["hbm_gbs"], "GB/s"
+    out = {"kernel": name, "bound": bound, "achieved": round(a, 2), "peak": p, "unit": unit,
+           "frac": round(a / p, 4), "launches": e["launches"], "avg_us": round(e["total_ms"] * 1e3 / max(1, e["launches"]), 2)}
+    # both rates for the kernels that gather AND contract (star attention: code-row gather + f32-MFMA attention)
+    if e["flops"] > 0 and e["bytes"] > 0:
+        out["algorithmic_GBps"] = round(e["bytes"] / sec / 1e9, 1)
+        out["algorithmic_TFLOPs"] = round(e["flops"] / sec / 1e12, 2)
+        out["mfma_f32_frac"] = round(e["flops"] / sec / 1e12 / PEAK["mfma_f32_tflops"], 4)
+    return out
+
+
+def unelided_flop_per_token(L, d=1024, H=8, kg=128, l=2, r=2, T=256, M=128, dsub=8, head=20002, tails=((256, 40000), (64, 207744))):
+    """the work of the reference's forward AS WRITTEN per evaluated token -- every ntgt node projected in every
+    layer, the OPQ rotation of every decoded row, the dense head; what `flop_per_token_executed` is to be read against."""
+    n, dk = kg * (1 + l + r), d // H
+    layer = 8 * d * d * n + 8 * d * d + 8 * d * dk * n + 4 * d * dk + 4 * d * (kg + kg * (1 + 3 * (l + r)) + (T + 1) / 2)
+    decode = 2 * (M * dsub) * d * n
+    softmax = 2 * d * head                                        # + the target's tail band, a few MFLOP
+    return L * layer + decode + softmax
 
 
 def read_sclk(device_index, sysfs_only=False):
@@ -901,6 +1104,13 @@ def main():
         drv = driver_path(args, eng, batches, dev)
         if args.precision == "f32":
             search = knn_search(args, eng, batches, dev, dt / args.steps * 1e3)
+    if recipe is not None and search is not None and recipe["tokens_per_step"] == 4096:
+        # step + on-device search of the step's own queries (what the reference's timer spans), for the recipe's lines
+        for key in ("uniform_ids",):
+            e = recipe[key]
+            e["tokens_per_s_with_search"] = round(recipe["tokens_per_step"] / ((e["ms_per_step"] + search["ms_per_4096_queries"]) / 1e3), 1)
+        w = recipe["searched_neighbours"]["within_batch_merge"]
+        w["tokens_per_s_with_search"] = round(recipe["tokens_per_step"] / ((w["ms_per_step"] + search["ms_per_4096_queries"]) / 1e3), 1)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         all_reduce(tt, dist.ReduceOp.MAX)
@@ -909,24 +1119,7 @@ def main():
     tokens = args.steps * args.blocks * args.tokens_per_sample * world
     score_sum = acc.item()
 
-    def roof(name, e):
-        bound = KERNEL_BOUND.get(name, "hbm")
-        sec = e["total_ms"] / 1e3
-        if bound == "mfma" and args.precision != "f32":           # priced in the bf16 MFMA flops actually issued
-            a, p, unit = SPLIT_PRODUCTS[args.precision] * e["flops"] / sec / 1e12, PEAK["mfma_bf16_tflops"], "TFLOP/s"
-        elif bound == "mfma":
-            a, p, unit = e["flops"] / sec / 1e12, PEAK["mfma_f32_tflops"], "TFLOP/s"
-        else:
-            a, p, unit = e["bytes"] / sec / 1e9, PEAK["hbm_gbs"], "GB/s"
-        out = {"kernel": name, "bound": bound, "achieved": round(a, 2), "peak": p, "unit": unit,
-               "frac": round(a / p, 4), "launches": e["launches"], "avg_us": round(e["total_ms"] * 1e3 / e["launches"], 2)}
-        # both rates for the kernels that gather AND contract (star attention: code-row gather + f32-MFMA attention)
-        if e["flops"] > 0 and e["bytes"] > 0:
-            out["algorithmic_GBps"] = round(e["bytes"] / sec / 1e9, 1)
-            out["algorithmic_TFLOPs"] = round(e["flops"] / sec / 1e12, 2)
-            out["mfma_f32_frac"] = round(e["flops"] / sec / 1e12 / PEAK["mfma_f32_tflops"], 4)
-        return out
-
+    roof = lambda name, e: roofline_entry(name, e, args.precision)
     if rank == 0:
         r = roof(dominant, prof)
         r["traffic"], r["traffic_source"] = pmc_traffic(dominant)

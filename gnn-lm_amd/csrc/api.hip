@@ -186,6 +186,41 @@ int linear_rows(const float* A, int64_t lda, const float* W, const float* bias, 
         if (_rc != OK) return _rc; \
     } while (0)
 
+// The ntgt projections of a multi-layer step run over [groups x slots] rows of a few KB each: from ~1 M rows on, the operand
+// spans more than 2^32 bytes and the GEMM kernel with 32-bit row offsets (gemm_f32_sched.hip, the fastest one for these
+// shapes: 133-136 against 123-128 TFLOP/s, tools/gemm_bigm_bench.py) is no longer eligible.  Rows are independent, so the
+// launches walk the groups in WINDOWS whose rows fit 32-bit byte offsets: same kernels per row as a 4-block step, same bits.
+struct GroupWindows {
+    int64_t G, per;       // groups, groups per window (a multiple of 128)
+    int n_g;
+    GroupWindows(int64_t G_, int n_g_, int64_t row_bytes) : G(G_), n_g(n_g_) {
+        const int64_t max_rows = ((1ll << 32) - 1) / std::max<int64_t>(row_bytes, 1);
+        const int64_t max_groups = std::max<int64_t>(128, max_rows / n_g / 128 * 128);
+        const int64_t n_win = std::max<int64_t>(1, cdiv(G, max_groups));
+        per = std::min<int64_t>(max_groups, cdiv(cdiv(G, n_win), (int64_t)128) * 128);
+    }
+};
+// every slot row of every group
+int linear_windows(const GroupWindows& w, const float* A, int64_t lda, const float* W, const float* bias, float* C, int N, int K, hipStream_t s) {
+    for (int64_t g0 = 0; g0 < w.G; g0 += w.per) {
+        const int64_t g1 = std::min(w.G, g0 + w.per), r0 = g0 * w.n_g;
+        const int rc = linear(A + r0 * lda, lda, W, bias, C + r0 * N, (g1 - g0) * w.n_g, N, K, nullptr, 1.f, s);
+        if (rc != OK) return rc;
+    }
+    return OK;
+}
+// a subset of the slots of every group: `rows` = group_rows(n_sel slots of G groups) is group-major with indices g * n_g + slot,
+// so its PREFIX is the row map of any window once the operands are based at the window's first row
+int linear_rows_windows(const GroupWindows& w, const float* A, int64_t lda, const float* W, const float* bias, float* C, int64_t ldc,
+                        const int32_t* rows, int n_sel, int N, int K, hipStream_t s) {
+    for (int64_t g0 = 0; g0 < w.G; g0 += w.per) {
+        const int64_t g1 = std::min(w.G, g0 + w.per), r0 = g0 * w.n_g;
+        const int rc = linear_rows(A + r0 * lda, lda, W, bias, C + r0 * ldc, ldc, rows, (g1 - g0) * n_sel, N, K, 1.f, s, (g1 - g0) * w.n_g);
+        if (rc != OK) return rc;
+    }
+    return OK;
+}
+
 int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, size_t ws_bytes, hipStream_t s) {
     GNNLM_REQUIRE(m.layers && m.n_layers >= 1, "hgt: no layers");
     GNNLM_REQUIRE(m.gemm_precision >= 0 && m.gemm_precision <= 2, "hgt: gemm_precision must be 0, 1 or 2");
@@ -402,17 +437,18 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             const int kin = f0 ? dpq : d;
             const float *Wq = f0 ? w.wq_n0 : w.wq_n, *Bq = f0 ? w.bq_n0 : w.bq_n, *Wk = f0 ? w.wk_n0 : w.wk_n,
                         *Bk = f0 ? w.bk_n0 : w.bk_n, *Wv = f0 ? w.wv_n0 : w.wv_n, *Bv = f0 ? w.bv_n0 : w.bv_n;
+            const GroupWindows win(G, n_g, 4 * (int64_t)std::max<int64_t>(std::max<int64_t>(ld_pin, ld_hn), std::max(d, dpq)));
             if (all_slots) {
-                if (f0) TRY(linear(b.hn[1], dpq, m.opq_at, m.opq_nba, b.hn[0], S, d, dpq, nullptr, 1.f, s));      // residual of every row
-                TRY(linear(pin, ld_pin, Wq, Bq, b.nq, S, d, kin, nullptr, 1.f, s));
-                TRY(linear(pin, ld_pin, Wk, Bk, b.nk, S, d, kin, nullptr, 1.f, s));
-                TRY(linear(pin, ld_pin, Wv, Bv, b.nv, S, d, kin, nullptr, 1.f, s));
+                if (f0) TRY(linear_windows(win, b.hn[1], dpq, m.opq_at, m.opq_nba, b.hn[0], d, dpq, s));      // residual of every row
+                TRY(linear_windows(win, pin, ld_pin, Wq, Bq, b.nq, d, kin, s));
+                TRY(linear_windows(win, pin, ld_pin, Wk, Bk, b.nk, d, kin, s));
+                TRY(linear_windows(win, pin, ld_pin, Wv, Bv, b.nv, d, kin, s));
                 ChainAttnParams ca{};
                 ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
                 ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
                 ca.out = b.nq; ca.ldo = d;      // in place over Q: a (group, head) task loads before it stores
                 TRY(chain_attn(ca, s));
-                TRY(linear(b.nq, d, w.wa_n, w.ba_n, b.nk, S, d, d, nullptr, 1.f, s));
+                TRY(linear_windows(win, b.nq, d, w.wa_n, w.ba_n, b.nk, d, d, s));
                 TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, S, d, m.ln_eps, valid, s, hn_cur, ld_hn));
             } else {
                 // slot of the position `o` relative to the centre: centre first, then o - left .. o - 1, then o + 1 .. o + right
@@ -422,18 +458,18 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
                 for (int o = -std::min(rad + 1, m.left); o <= std::min(rad + 1, m.right); ++o) sel_kv[n_kv++] = slot(o);
                 TRY(group_rows(b.rows_out, G, n_g, sel_out, n_out, s));
                 TRY(group_rows(b.rows_kv, G, n_g, sel_kv, n_kv, s));
-                const int64_t R_out = G * n_out, R_kv = G * n_kv;
-                if (f0) TRY(linear_rows(b.hn[1], dpq, m.opq_at, m.opq_nba, b.hn[0], d, b.rows_out, R_out, d, dpq, 1.f, s, S));   // residual rows only
-                TRY(linear_rows(pin, ld_pin, Wq, Bq, b.nq, d, b.rows_out, R_out, d, kin, 1.f, s, S));
-                TRY(linear_rows(pin, ld_pin, Wk, Bk, b.nk, d, b.rows_kv, R_kv, d, kin, 1.f, s, S));
-                TRY(linear_rows(pin, ld_pin, Wv, Bv, b.nv, d, b.rows_kv, R_kv, d, kin, 1.f, s, S));
+                const int64_t R_out = G * n_out;
+                if (f0) TRY(linear_rows_windows(win, b.hn[1], dpq, m.opq_at, m.opq_nba, b.hn[0], d, b.rows_out, n_out, d, dpq, s));   // residual rows only
+                TRY(linear_rows_windows(win, pin, ld_pin, Wq, Bq, b.nq, d, b.rows_out, n_out, d, kin, s));
+                TRY(linear_rows_windows(win, pin, ld_pin, Wk, Bk, b.nk, d, b.rows_kv, n_kv, d, kin, s));
+                TRY(linear_rows_windows(win, pin, ld_pin, Wv, Bv, b.nv, d, b.rows_kv, n_kv, d, kin, s));
                 ChainAttnParams ca{};
                 ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
                 ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
                 ca.out = b.nq; ca.ldo = d;
                 ca.radius_p1 = rad + 1;
                 TRY(chain_attn(ca, s));
-                TRY(linear_rows(b.nq, d, w.wa_n, w.ba_n, b.nk, d, b.rows_out, R_out, d, d, 1.f, s, S));
+                TRY(linear_rows_windows(win, b.nq, d, w.wa_n, w.ba_n, b.nk, d, b.rows_out, n_out, d, d, s));
                 TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, R_out, d, m.ln_eps, valid, s, hn_cur, ld_hn, b.rows_out));
             }
             hn_cur = hn_out;

@@ -438,7 +438,10 @@ class HGT(nn.Module):
             prep["ws"] = {}
         ws = prep["ws"].get(key)
         if ws is None or ws.numel() < need or ws.device != tgt.device:
-            ws = prep["ws"][key] = torch.empty(need, device=tgt.device, dtype=torch.uint8)
+            # with merged / cached groups the need varies from batch to batch: grow in steps of 1/8 (+ 64 MiB), not by the few
+            # rows the next batch happens to add -- a fresh multi-GB allocation stalls the step for a second
+            prep["ws"][key] = ws = None
+            ws = prep["ws"][key] = torch.empty(need + need // 8 + (64 << 20) if io.group_ids else need, device=tgt.device, dtype=torch.uint8)
         _lib.check(L.gnnlm_hgt_forward(ctypes.byref(m), ctypes.byref(io), _lib.ptr(ws), ws.numel(),
                                        _lib.stream()), "gnnlm_hgt_forward")
         out = {"tgt": out_tgt}

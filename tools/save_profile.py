@@ -50,6 +50,28 @@ if os.path.exists(stxt):
         e["hbm_bytes_per_launch"] = 2 * e["fetch_size_bytes_raw"] + e["write_size_bytes_raw"]
         t[k] = e
     json.dump(t, open(pj, "w"), indent=1, sort_keys=True)
+# the 3-layer recipe's own passes (tools/profile_bench.sh writes prof_<tag>_L3): kernels under "L3:<name>" in pmc_traffic.json
+src3 = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_L3")
+st3 = glob.glob(os.path.join(src3, "stats", "**", "*_kernel_stats.csv"), recursive=True)
+if st3:
+    import json
+    with open(st3[0]) as f, open(os.path.join(ROOT, "profiles", f"{tag}_L3_kernel_stats.csv"), "w", newline="") as g:
+        w = csv.writer(g, quoting=csv.QUOTE_MINIMAL)
+        for row in csv.reader(f):
+            row[0] = row[0][:160]
+            w.writerow(row)
+    py3 = [sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f"FETCH_SIZE={src3}/fetch", f"WRITE_SIZE={src3}/write"]
+    open(os.path.join(ROOT, "profiles", f"{tag}_L3_pmc_traffic.csv"), "w").write(subprocess.run(py3, capture_output=True, text=True, check=True).stdout)
+    t3 = json.loads(subprocess.run(py3 + ["--json", f"--profile={tag}"], capture_output=True, text=True, check=True).stdout)
+    pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    t = json.load(open(pj))
+    for k, e in t3.items():
+        if k != "_meta":
+            t["L3:" + k] = e
+    json.dump(t, open(pj, "w"), indent=1, sort_keys=True)
+    l3 = [l for l in open(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_L3.bench.json")) if l.startswith("{")]
+    if l3:
+        open(os.path.join(ROOT, "profiles", f"{tag}_L3_bench_under_rocprof.json"), "w").write(l3[0])
 line = [l for l in open(os.path.join(ROOT, "gpurun_out", f"prof_{tag}.bench.json")) if l.startswith("{")][0]
 open(os.path.join(ROOT, "profiles", f"{tag}_bench_under_rocprof.json"), "w").write(line)
 print("saved profiles/", tag)
