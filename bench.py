@@ -789,13 +789,15 @@ def read_sclk(device_index, sysfs_only=False):
     import re
     import subprocess
     try:
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        if cards:
-            txt = open(cards[min(device_index, len(cards) - 1)]).read()
-            m = re.search(r"(\d+)\s*M[Hh]z\s*\*", txt)
-            if m:
-                return int(m.group(1))
-    except OSError:
+        # the node's sysfs lists every GPU of the host; ours is the one at the PCI address the runtime reports
+        pr = torch.cuda.get_device_properties(device_index)
+        addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            if addr in os.path.realpath(os.path.dirname(f)):
+                m = re.search(r"(\d+)\s*M[Hh]z\s*\*", open(f).read())
+                if m:
+                    return int(m.group(1))
+    except (OSError, AttributeError, RuntimeError):
         pass
     if sysfs_only:
         return None

@@ -121,11 +121,13 @@ def lib():
         L.gnnlm_ivfpq_pack_tiles.argtypes = [vp, i64, i32, vp, vp]
         L.gnnlm_ivfpq_quantize_lut.argtypes = [vp, i64, i64, i32, vp, vp, vp]
         L.gnnlm_ivfpq_build_groups.argtypes = [vp, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp]
+        L.gnnlm_label_tags.argtypes = [vp, i32, i64, vp, vp]
+        L.gnnlm_ivfpq_split_payload.argtypes = [vp, i64, i32, i32, vp, vp]
         L.gnnlm_hgt_workspace_bytes.argtypes = [vp, vp]
         L.gnnlm_hgt_forward.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
         for nm in ("gnnlm_gemm_nt", "gnnlm_pq_gather_decode", "gnnlm_star_attn", "gnnlm_chain_attn",
                    "gnnlm_knn_interp", "gnnlm_topk_merge", "gnnlm_ivfpq_scan", "gnnlm_gather_rows_peer",
-                   "gnnlm_ivfpq_scan8", "gnnlm_ivfpq_rescore", "gnnlm_ivfpq_tau"):
+                   "gnnlm_ivfpq_scan8", "gnnlm_ivfpq_rescore", "gnnlm_ivfpq_tau", "gnnlm_ivfpq_refine"):
             getattr(L, nm).argtypes = [vp, vp]
         if L.gnnlm_target_arch() != b"gfx950" or L.gnnlm_abi_version() != ABI_VERSION:
             raise GnnlmError(f"libgnnlm_hip.so is not the gfx950 / ABI-{ABI_VERSION} build")

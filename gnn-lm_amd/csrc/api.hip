@@ -582,7 +582,7 @@ size_t gnnlm_sizeof(const char* name) {
 #define GNNLM_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
     GNNLM_SZ(gnnlm_gemm_t) GNNLM_SZ(gnnlm_gather_t) GNNLM_SZ(gnnlm_star_attn_t) GNNLM_SZ(gnnlm_chain_attn_t)
     GNNLM_SZ(gnnlm_adaptive_softmax_t) GNNLM_SZ(gnnlm_knn_interp_t) GNNLM_SZ(gnnlm_hgt_layer_t)
-    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t) GNNLM_SZ(gnnlm_ivfpq_scan8_t) GNNLM_SZ(gnnlm_ivfpq_rescore_t) GNNLM_SZ(gnnlm_ivfpq_tau_t) GNNLM_SZ(gnnlm_peer_gather_t) GNNLM_SZ(gnnlm_shards_t)
+    GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t) GNNLM_SZ(gnnlm_ivfpq_scan8_t) GNNLM_SZ(gnnlm_ivfpq_rescore_t) GNNLM_SZ(gnnlm_ivfpq_tau_t) GNNLM_SZ(gnnlm_ivfpq_refine_t) GNNLM_SZ(gnnlm_peer_gather_t) GNNLM_SZ(gnnlm_shards_t)
 #undef GNNLM_SZ
     return 0;
 }
@@ -677,6 +677,8 @@ int gnnlm_ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int32_
 int gnnlm_ivfpq_scan8(const gnnlm_ivfpq_scan8_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_scan8(*d, (hipStream_t)stream); }
 int gnnlm_ivfpq_rescore(const gnnlm_ivfpq_rescore_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_rescore(*d, (hipStream_t)stream); }
 int gnnlm_ivfpq_tau(const gnnlm_ivfpq_tau_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_tau(*d, (hipStream_t)stream); }
+int gnnlm_ivfpq_refine(const gnnlm_ivfpq_refine_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_refine(*d, (hipStream_t)stream); }
+int gnnlm_ivfpq_split_payload(int64_t* idx, int64_t n, int32_t label_bits, int32_t val_last, int32_t* out_vals, void* stream) { return ivfpq_split_payload(idx, n, label_bits, val_last, out_vals, (hipStream_t)stream); }
 int gnnlm_masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, void* stream) {
     return masked_sum_f64(x, mask, n, out, (hipStream_t)stream);
 }

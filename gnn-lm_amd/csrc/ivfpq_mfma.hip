@@ -41,6 +41,9 @@ constexpr int HIST_BINS = 1024, HIST_SHIFT = 4;         // threshold pass: sum_u
 constexpr int SUMS_LDS = TAB_BYTES + QG * HIST_BINS * 4;  // = 160 KiB: the whole LDS of a CU
 constexpr int SURV_CNT_STRIDE = 16;                     // survivor counters one per 64-byte line: they are hammered by atomics
 constexpr int QLUT_BYTES = 64 * 256;                    // one query's quantised table
+// a survivor record is {row, list | sum_u << 18}: the key's integer sum (14 bits; SURV_SUM_BIG = "at least threshold + 1023": the
+// wave's LDS staging entry only has 10 bits for the distance to the threshold) above an 18-bit list
+constexpr int SURV_ROW_BITS = 19, SURV_LIST_BITS = 18, SURV_EXCESS_MAX = 1023, SURV_SUM_BIG = 16383;
 
 // codes [N, 64] row-major -> tiles of 16 rows, [tile][g 0..3][i 0..15][p 0..15] = code[16 tile + i][16 g + (i + p) % 16];
 // rows beyond N are zero.  One thread per (row, g).
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
 #pragma unroll
         for (int sl = 0; sl < QG; ++sl) {
             const int base = __builtin_amdgcn_readlane(basev, sl), qsl = __builtin_amdgcn_readlane(qs_lane, sl);
+            const int Tsl = __builtin_amdgcn_readlane(T, sl);                  // lane sl holds query slot sl's integer threshold (j = lane)
             if (qsl < 0) continue;
             int run = 0;
 #pragma unroll
@@ -387,7 +391,13 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
                 if (m == 0ull) continue;
                 if (mine) {
                     const int64_t at = (int64_t)base + run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (at < p.cap) surv[(int64_t)qsl * p.cap + at] = uint2{(uint32_t)(lo + (ent[x] >> 3)), (uint32_t)list};
+                    if (at < p.cap) {
+                        // the key's integer sum sum_u = excess + T + 128 * 64 (0 .. 16320); SURV_SUM_BIG: more than the entry could hold
+                        const int ex = (int)(ent[x] >> (SURV_ROW_BITS + 3));
+                        const int su = ex >= SURV_EXCESS_MAX ? SURV_SUM_BIG : min(SURV_SUM_BIG - 1, max(0, ex + Tsl + 128 * 64));
+                        surv[(int64_t)qsl * p.cap + at] = uint2{(uint32_t)(lo + ((ent[x] >> 3) & ((1u << SURV_ROW_BITS) - 1u))),
+                                                                (uint32_t)list | (uint32_t)su << SURV_LIST_BITS};
+                    }
                 }
                 run += __builtin_popcountll(m);
             }
@@ -403,11 +413,14 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         if (lane < QG && mytot > 0 && qs_lane >= 0) basev = atomicAdd(&p.surv_cnt[(int64_t)qs_lane * SURV_CNT_STRIDE], mytot);
         write_entries(basev);
     };
-    auto append = [&](uint64_t m, bool mine, int local_row) {                // m: the wave's mask, mine: this lane's bit
+    // entry = excess << 22 | local row << 3 | query slot: `excess` = how far the key's integer sum lies above the query's integer
+    // threshold (clamped to 1023) -- ivfpq_refine_kernel turns it into a lower bound of the key's score (SURV_ROW_BITS = 19: lists
+    // of up to 524,287 rows; the launcher checks)
+    auto append = [&](uint64_t m, bool mine, int local_row, int sum) {       // m: the wave's mask, mine: this lane's bit
         if (m == 0ull) return;
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 #if !(GNNLM_IVF8_EXP & 64)
-        if (mine) wbuf[wcnt + rank] = (uint32_t)local_row << 3 | (uint32_t)(j & 7);
+        if (mine) wbuf[wcnt + rank] = (uint32_t)min(sum - T, SURV_EXCESS_MAX) << (SURV_ROW_BITS + 3) | (uint32_t)local_row << 3 | (uint32_t)(j & 7);
 #endif
         wcnt = __builtin_amdgcn_readfirstlane(wcnt + __builtin_popcountll(m));   // (scalar: the compiler's divergence analysis gives up on it)
 #if GNNLM_IVF8_EXP & 128
@@ -474,16 +487,16 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool sr = acc[r] >= T && (unsigned)(rb + r) < (unsigned)len;
-                    append(__builtin_amdgcn_ballot_w64(sr), sr, rb + r);
+                    append(__builtin_amdgcn_ballot_w64(sr), sr, rb + r, acc[r]);
                 }
             } else {
                 const uint64_t m0 = __builtin_amdgcn_ballot_w64(acc[0] >= T), m1 = __builtin_amdgcn_ballot_w64(acc[1] >= T),
                                m2 = __builtin_amdgcn_ballot_w64(acc[2] >= T), m3 = __builtin_amdgcn_ballot_w64(acc[3] >= T);
                 if ((m0 | m1 | m2 | m3) != 0ull) {
-                    append(m0, acc[0] >= T, rb + 0);
-                    append(m1, acc[1] >= T, rb + 1);
-                    append(m2, acc[2] >= T, rb + 2);
-                    append(m3, acc[3] >= T, rb + 3);
+                    append(m0, acc[0] >= T, rb + 0, acc[0]);
+                    append(m1, acc[1] >= T, rb + 1, acc[1]);
+                    append(m2, acc[2] >= T, rb + 2, acc[2]);
+                    append(m3, acc[3] >= T, rb + 3, acc[3]);
                 }
             }
         }
@@ -609,6 +622,174 @@ __global__ __launch_bounds__(1024) void ivfpq_tau_kernel(gnnlm_ivfpq_tau_t p) {
     }
 }
 
+// A TIGHTER threshold from the survivors themselves, then the survivors that can still beat it (round 4).  The threshold pass's
+// tau is a lower bound of the k-th best score from the first D lists, histogrammed in bins of 16: the filter lets ~6 x k keys
+// through and ~4 x k of them score above tau.  Every survivor carries its integer sum (as the excess over its query's integer
+// threshold), i.e. a lower bound LB(x) = bias_l + sum_lo + sum_u(x) delta' - eps <= score(x) over ALL probed lists, un-binned:
+// the k-th largest LB is a valid and much tighter threshold tau1 (at least k keys score >= it), and only the survivors whose
+// UPPER bound exceeds tau1 (the filter's own integer test, with tau1) need an exact score.  One workgroup per query:
+// (1) the k-th largest LB to the resolution of a 2048-bin histogram over [tau, max LB] (one pass: a lower edge is a valid threshold too),
+// (2) compaction of the records in place, count in `out_cnt` (surv_cnt keeps the filter's count: the overflow check reads it),
+// tau[q] = max(tau, tau1).  The search result is unchanged: candidates stay a superset of the true k best.
+template <int EPT>
+__global__ __launch_bounds__(1024) void ivfpq_refine_kernel(gnnlm_ivfpq_refine_t p) {
+    constexpr int NT = 1024, NB = 2048, NWV = NT / 64;
+    __shared__ int hist[NB];
+    __shared__ int wtot[NWV];
+    __shared__ int dig_s, base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q = blockIdx.x;
+    const int n = min(p.surv_cnt[q * SURV_CNT_STRIDE], p.cap);
+    uint2* surv = reinterpret_cast<uint2*>(p.surv) + q * p.cap;
+    const float tau0 = p.tau[q];
+    if (n < p.k || !(tau0 > -INFINITY)) {                                    // fewer survivors than k, or no threshold at all (the sums say nothing)
+        if (tid == 0) p.out_cnt[q * SURV_CNT_STRIDE] = n;
+        return;
+    }
+    const float delta = p.qmeta[q * 4], sum_lo = p.qmeta[q * 4 + 1], amax = p.qmeta[q * 4 + 2];
+    const float dlo = delta * (1.f - 6.1035156e-5f);                         // delta (1 - 2^-14) < 1 / inv (ivfpq_tau_kernel)
+    const float* coarse = p.coarse + q * p.ld_coarse;
+    // LB of a record: bias_l + sum_lo + sum_u delta' - eps (eps: the float32 rounding of the score chain), strictly below the score
+    auto lower_bound = [&](const uint2& rec) -> float {
+        const int list = (int)(rec.y & ((1u << SURV_LIST_BITS) - 1u));
+        int su = (int)(rec.y >> SURV_LIST_BITS);
+        const float bias = coarse[list];
+        if (su >= SURV_SUM_BIG) su = min(16320, max(0, filter_threshold(p.qmeta, q, bias, tau0) + SURV_EXCESS_MAX + 128 * 64));   // (rare: the very best keys)
+        const float eps = 66.f * 2.3841858e-7f * (64.f * amax + fabsf(bias));
+        const float lb = (bias + sum_lo) + (float)su * dlo - eps;
+        return lb - (fabsf(lb) * 2.3841858e-7f + 1e-30f);                    // candidates are score > tau
+    };
+    // the first EPT * 1024 records live in registers (one memory round trip); longer lists (a doubled capacity) re-read the rest
+    constexpr int C0 = EPT * NT;
+    uint2 rrec[EPT];
+    float rlb[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) rrec[e] = surv[min(tid + e * NT, n - 1)];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        rlb[e] = tid + e * NT < n ? lower_bound(rrec[e]) : -INFINITY;
+        mx = fmaxf(mx, rlb[e]);
+    }
+    for (int c = C0 + tid; c < n; c += NT) mx = fmaxf(mx, lower_bound(surv[c]));
+    // ---- (1) the k-th largest LB, to the resolution of 2048 bins over [tau0, max LB] (far finer than the 64-delta slack of the
+    // bounds; a float radix select of the exact value serialises on LDS atomics: the bounds of a query share their leading bits)
+    __shared__ float wmax[NWV];
+    mx = wave_max(mx);
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    mx = wmax[0];
+    for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, wmax[w]);
+    const float span = mx - tau0;
+    float tau1 = tau0;
+    if (span > 0.f) {                                                        // (else no bound above the old threshold: nothing to gain)
+        const float inv_w = (float)NB / span * (1.f - 1e-6f);
+        for (int e = tid; e < NB; e += NT) hist[e] = 0;
+        __syncthreads();
+        auto bin_of = [&](float lb) -> int { return lb >= tau0 ? min(NB - 1, (int)((lb - tau0) * inv_w)) : -1; };
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int bn = bin_of(rlb[e]);
+            if (bn >= 0) atomicAdd(&hist[bn], 1);
+        }
+        for (int c = C0 + tid; c < n; c += NT) {
+            const int bn = bin_of(lower_bound(surv[c]));
+            if (bn >= 0) atomicAdd(&hist[bn], 1);
+        }
+        __syncthreads();
+        // the highest bin whose suffix count reaches k (thread t owns bins 2 t, 2 t + 1; suffix sums by shuffles, then over the waves)
+        constexpr int BPT = NB / NT;
+        int own[BPT], mine = 0;
+#pragma unroll
+        for (int bb = 0; bb < BPT; ++bb) { own[bb] = hist[BPT * tid + bb]; mine += own[bb]; }
+        int suf = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_down(suf, d, 64);
+            if (lane + d < 64) suf += o;
+        }
+        if (lane == 0) wtot[wave] = suf;
+        if (tid == 0) dig_s = -1;
+        __syncthreads();
+        for (int w = wave + 1; w < NWV; ++w) suf += wtot[w];
+        if (suf >= p.k && suf - mine < p.k) {
+            int acc_ = suf - mine;
+#pragma unroll
+            for (int bb = BPT - 1; bb >= 0; --bb) {
+                if (acc_ + own[bb] >= p.k) { dig_s = BPT * tid + bb; break; }
+                acc_ += own[bb];
+            }
+        }
+        __syncthreads();
+        if (dig_s > 0) {
+            // every bound of bins >= dig_s is >= tau0 + dig_s / inv_w: at least k keys score above it (two roundings of slack)
+            const float t = tau0 + (float)dig_s / inv_w * (1.f - 2e-6f);
+            tau1 = fmaxf(tau0, t - fabsf(t) * 4.7683716e-7f);
+        }
+    }
+    // ---- (2) keep the records whose upper bound exceeds tau1.  A record is dropped only if its UPPER bound (bias + sum_lo +
+    // (sum_u + 64) delta + eps, the filter's) lies below tau1 with a margin of 0.1 % of the sum term + 2 delta for this formula's
+    // own rounding: a slightly weaker test than the filter's integer one
+    auto keep_rec = [&](const uint2& rec) -> bool {
+        const int list = (int)(rec.y & ((1u << SURV_LIST_BITS) - 1u)), su = (int)(rec.y >> SURV_LIST_BITS);
+        if (su >= SURV_SUM_BIG) return true;
+        const float bias = coarse[list];
+        const float eps = 66.f * 2.3841858e-7f * (64.f * amax + fabsf(bias) + fabsf(tau1));
+        const float ub = (bias + sum_lo) + (float)(su + 66) * delta * 1.001f + eps;
+        return !(ub < tau1);
+    };
+    // the register-resident records: every thread counts what it keeps, one exclusive scan over the threads, then the writes
+    // (all reads happened long ago: in place is safe)
+    int kept = 0;
+    uint32_t kmask = 0u;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (tid + e * NT < n && keep_rec(rrec[e])) { kmask |= 1u << e; ++kept; }
+    int incl = kept;                                                         // inclusive prefix over the lanes of the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();                                                         // (wtot is free again)
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int at = incl - kept;
+    for (int w = 0; w < wave; ++w) at += wtot[w];
+    int total = 0;
+    for (int w = 0; w < NWV; ++w) total += wtot[w];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (kmask >> e & 1u) surv[at++] = rrec[e];
+    // the rest of a longer list, chunk by chunk behind what has been written (write index <= read index)
+    if (n > C0) {
+        if (tid == 0) base_s = total;
+        __syncthreads();
+        for (int c0 = C0; c0 < n; c0 += NT) {
+            const int c = c0 + tid;
+            uint2 rec = uint2{0u, 0u};
+            bool keep = false;
+            if (c < n) { rec = surv[c]; keep = keep_rec(rec); }
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            __syncthreads();
+            if (lane == 0) wtot[wave] = __builtin_popcountll(m);
+            __syncthreads();                                                 // (every read of the chunk is done: the writes stay behind them)
+            int before = base_s;
+            for (int w = 0; w < wave; ++w) before += wtot[w];
+            if (keep) surv[before + rank] = rec;
+            __syncthreads();
+            if (tid == 0) { int tot = 0; for (int w = 0; w < NWV; ++w) tot += wtot[w]; base_s += tot; }
+            __syncthreads();
+        }
+        total = base_s;
+    }
+    if (tid == 0) {
+        p.out_cnt[q * SURV_CNT_STRIDE] = total;
+        p.tau[q] = tau1;
+    }
+}
+
 // Exact float32 scores of the survivors, in the summation order of the f32 scan (ivfpq.hip scan_rot: look-up s of half h
 // goes to sub-quantizer 32 h + (row + s) % 32, even look-ups into one chain, odd ones into the other, halves in order,
 // score = bias + (chain0 + chain1)).  One workgroup per query, its table in LDS.
@@ -632,7 +813,7 @@ __global__ __launch_bounds__(1024) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore
     const int last = max(n - 1, 0);
     auto record = [&](int e, uint2& rec) __attribute__((always_inline)) { rec = surv[min(e, last)]; };
     auto rowload = [&](const uint2& rec, v4u (&cr)[M / 16], float& bias) __attribute__((always_inline)) {
-        bias = p.coarse[q * p.ld_coarse + rec.y];                           // (first: the youngest loads of a step are the row's)
+        bias = p.coarse[q * p.ld_coarse + (rec.y & ((1u << SURV_LIST_BITS) - 1u))];   // (first: the youngest loads of a step are the row's)
         const v4u* crow = reinterpret_cast<const v4u*>(p.codes + (int64_t)rec.x * M);
 #pragma unroll
         for (int c16 = 0; c16 < M / 16; ++c16) cr[c16] = crow[c16];
@@ -781,6 +962,35 @@ int ivfpq_tau(const gnnlm_ivfpq_tau_t& d, hipStream_t stream) {
     GNNLM_REQUIRE(d.hist && d.probe_list && d.probe_bias && d.qmeta && d.tau && d.ld_probe >= d.D, "ivfpq_tau: null operand");
     ProfScope prof(K_TAU, stream, 0.0, 4.0 * (double)d.n * d.D * HIST_BINS);
     hipLaunchKernelGGL(ivfpq_tau_kernel, dim3((unsigned)d.n), dim3(1024), 0, stream, d);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+// the search's results: payload (id << label_bits | label, -1 = none) -> id in place, label to out_vals (none: `val_last`, what
+// numpy's vals[-1] reads for the reference, knn/knn_model.py:198)
+__global__ __launch_bounds__(256) void split_payload_kernel(int64_t* __restrict__ idx, int64_t n, int label_bits, int32_t val_last, int32_t* __restrict__ out_vals) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int64_t v = idx[e];
+    idx[e] = v < 0 ? v : v >> label_bits;
+    if (out_vals) out_vals[e] = v < 0 ? val_last : (int32_t)(v & ((1ll << label_bits) - 1));
+}
+int ivfpq_split_payload(int64_t* idx, int64_t n, int label_bits, int32_t val_last, int32_t* out_vals, hipStream_t stream) {
+    GNNLM_REQUIRE(idx && n >= 0 && label_bits > 0 && label_bits < 32, "ivfpq_split_payload: bad arguments");
+    if (n == 0) return OK;
+    hipLaunchKernelGGL(split_payload_kernel, dim3((unsigned)cdiv(n, (int64_t)256)), dim3(256), 0, stream, idx, n, label_bits, val_last, out_vals);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
+
+int ivfpq_refine(const gnnlm_ivfpq_refine_t& d, hipStream_t stream) {
+    GNNLM_REQUIRE(d.n >= 0 && d.n < (1ll << 31) && d.k > 0 && d.cap > 0, "ivfpq_refine: bad shape");
+    if (d.n == 0) return OK;
+    GNNLM_REQUIRE(d.surv && d.surv_cnt && d.out_cnt && d.tau && d.qmeta && d.coarse, "ivfpq_refine: null operand");
+    ProfScope prof(K_TAU, stream, 0.0, 16.0 * (double)d.n * d.k);
+    // records in registers: 8 per thread cover 8192 (the usual ~6 k survivors of k = 1024 never need more), 16 the default capacity
+    if (d.cap <= 8192) hipLaunchKernelGGL(ivfpq_refine_kernel<8>, dim3((unsigned)d.n), dim3(1024), 0, stream, d);
+    else hipLaunchKernelGGL(ivfpq_refine_kernel<16>, dim3((unsigned)d.n), dim3(1024), 0, stream, d);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

@@ -22,6 +22,8 @@ int ivfpq_build_groups(const int64_t* pl, int64_t ld, int64_t n, int P, int nlis
 int ivfpq_quantize_lut(const float* lut, int64_t ld_lut, int64_t n, int M, uint8_t* qlut, float* qmeta, hipStream_t stream);
 int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream);
 int ivfpq_rescore(const gnnlm_ivfpq_rescore_t& d, hipStream_t stream);
+int ivfpq_refine(const gnnlm_ivfpq_refine_t& d, hipStream_t stream);
+int ivfpq_split_payload(int64_t* idx, int64_t n, int label_bits, int32_t val_last, int32_t* out_vals, hipStream_t stream);
 int ivfpq_tau(const gnnlm_ivfpq_tau_t& d, hipStream_t stream);
 
 int gemm_nt(const GemmParams& p, hipStream_t stream);

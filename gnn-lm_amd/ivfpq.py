@@ -166,7 +166,8 @@ class IVFPQIndex:
             scan = "rowmajor"
         if scan == "rowmajor":
             pass                                                             # the row-major kernels (one table per (query, list) task)
-        elif self.M == 64 and self.ntotal and self.ntotal < (1 << 32) and scan != "f32":
+        elif self.M == 64 and self.ntotal and self.ntotal < (1 << 32) and scan != "f32" and self.max_list < (1 << 19) and self.nlist <= (1 << 18):
+            # (a survivor record packs the row inside its list into 19 bits and the list into 18: longer / more lists take the float32 scan)
             self.tiles = ops.ivfpq_pack_tiles(self.list_codes)
         elif self.M in (32, 64) and self.ntotal:
             self.packed_codes = torch.empty(-(-self.ntotal // 64) * 64 * self.M, dtype=torch.uint8, device=self.device)
@@ -175,6 +176,7 @@ class IVFPQIndex:
         # bound a little loose, 6 lists give the tighter threshold (fewer survivors to re-score) for less time
         if self.dense_probes is None:
             self.dense_probes = 6 if self.tiles is not None else 2
+        self.refine_tau = os.environ.get("GNNLM_IVF_REFINE", "1") != "0"     # gnnlm_ivfpq_refine between the filter and the re-score (A/B: 0)
         self.stats = {}                                                      # device-side work counters of the last search (bench.py)
 
     def attach_vals(self, vals):
@@ -353,11 +355,10 @@ class IVFPQIndex:
             val = -val                                                        # scores are -distance: squared distances, ascending, +inf padded
         if not self.has_vals:
             return (val, idx, None) if return_vals else (val, idx)
-        ids = idx >> self.LABEL_BITS                                          # -1 stays -1
-        if not return_vals:
-            return val, ids
-        vals = torch.where(idx < 0, torch.full_like(idx, self.val_last), idx & ((1 << self.LABEL_BITS) - 1)).to(torch.int32)
-        return val, ids, vals
+        # payload -> (id in place, label): one pass (gnnlm_ivfpq_split_payload) instead of five elementwise torch kernels over [n, k]
+        vals = torch.empty(idx.shape, dtype=torch.int32, device=idx.device) if return_vals else None
+        _lib.call("gnnlm_ivfpq_split_payload", _lib.ptr(idx), idx.numel(), self.LABEL_BITS, self.val_last, _lib.ptr(vals), _lib.stream())
+        return (val, idx, vals) if return_vals else (val, idx)
 
     def _search_once(self, q, k, query_block, dense_probes, cap):
         n, dev = q.shape[0], self.device
@@ -459,10 +460,19 @@ class IVFPQIndex:
         self.stats["groups"] = self.stats.get("groups", 0) + g2[2][0]
         self._scan8(qlut, qmeta, cs, g2, tau=tau, surv=(surv, sc16))
         sc = sc16[:, 0]
+        # a tighter threshold from the survivors' own integer sums (all lists, un-binned), and only the survivors that can beat it
+        rc16 = sc16
+        if self.refine_tau:
+            rc16 = torch.empty_like(sc16)
+            f = _lib.gnnlm_ivfpq_refine_t()
+            f.surv, f.surv_cnt, f.out_cnt, f.cap = surv.data_ptr(), sc16.data_ptr(), rc16.data_ptr(), cap
+            f.tau, f.qmeta, f.coarse, f.ld_coarse, f.n, f.k = tau.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0), nq, k
+            _lib.call_desc("gnnlm_ivfpq_refine", f)
+            self.stats["rescored"] = self.stats.get("rescored", 0) + rc16[:, 0].sum()
         r = _lib.gnnlm_ivfpq_rescore_t()
         r.codes, r.payload, r.M = self.list_codes.data_ptr(), self.payload.data_ptr(), self.M
         r.lut, r.ld_lut, r.coarse, r.ld_coarse, r.tau = lut.data_ptr(), lut.stride(0), cs.data_ptr(), cs.stride(0), tau.data_ptr()
-        r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), sc16.data_ptr(), cap, nq
+        r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), rc16.data_ptr(), cap, nq
         r.cand_val, r.cand_id, r.cand_cnt, r.cand_cap = cv.data_ptr(), ci.data_ptr(), cc.data_ptr(), cap
         _lib.call_desc("gnnlm_ivfpq_rescore", r)
         self.stats["survivors"] += sc.sum()

@@ -349,7 +349,7 @@ typedef struct gnnlm_ivfpq_scan8 {
     const float* tau;                                 /* [n] */
     const int32_t* grp_list;  const int32_t* grp_q;   /* [max_groups] list (-1: none), [max_groups, 8] queries (-1: none), sorted by list */
     const int32_t* n_groups;  int32_t max_groups;     /* DEVICE count of groups in use (no host round trip), capacity of the arrays */
-    uint32_t* surv;  int32_t* surv_cnt;  int32_t cap; /* [n, cap, 2] {row, list}; surv_cnt [n, 16] int32 (one 64-byte line per query: the
+    uint32_t* surv;  int32_t* surv_cnt;  int32_t cap; /* [n, cap, 2] {row, list | sum_u << 18}; surv_cnt [n, 16] int32 (one 64-byte line per query: the
                                                        * counters are hammered by atomics), column 0 counts ALL survivors (overflow check) */
     /* threshold pass (out_hist != NULL; tau / surv unused): the integer sums sum_m u (0 .. 255 * 64) of a list's keys are
      * histogrammed per query (1024 bins of 16) and written to out_hist[grp_out[group * 8 + j] .. + 1024) for query j of the group
@@ -372,6 +372,21 @@ typedef struct gnnlm_ivfpq_tau {
     float* tau;
 } gnnlm_ivfpq_tau_t;
 int gnnlm_ivfpq_tau(const gnnlm_ivfpq_tau_t* desc, void* stream);
+/* ABI 7.  Between the filter and the re-score: a tighter threshold from the survivors themselves.  A survivor record is
+ * {row, list | sum_u << 18} with sum_u the key's integer sum (16383: more than the filter's staging could hold): a lower bound of
+ * the key's score over ALL probed lists.  tau[q] <- max(tau[q], the k-th largest lower bound of query q's survivors) (at
+ * least k keys score above it), the records whose upper bound cannot exceed it are dropped (compacted in place), out_cnt
+ * [n, 16] int32 (column 0) = records left; surv_cnt stays what the filter counted.  The search result does not change. */
+typedef struct gnnlm_ivfpq_refine {
+    uint32_t* surv;  const int32_t* surv_cnt;  int32_t* out_cnt;  int32_t cap;
+    float* tau;  const float* qmeta;
+    const float* coarse;  int64_t ld_coarse;
+    int64_t n;  int32_t k;
+} gnnlm_ivfpq_refine_t;
+int gnnlm_ivfpq_refine(const gnnlm_ivfpq_refine_t* desc, void* stream);
+/* ABI 7.  Results of a search over an index that carries labels (payload = id << label_bits | label, -1 = no result): idx [n]
+ * -> the ids in place, out_vals [n] (optional) the labels, `val_last` where there is no result (numpy's vals[-1], knn_model.py:198) */
+int gnnlm_ivfpq_split_payload(int64_t* idx, int64_t n, int32_t label_bits, int32_t val_last, int32_t* out_vals, void* stream);
 typedef struct gnnlm_ivfpq_rescore {
     const uint8_t* codes;  const int64_t* payload;    /* [N, M] list-ordered codes, [N] what a candidate carries (key id, or id << 24 | label) */
     int32_t M;

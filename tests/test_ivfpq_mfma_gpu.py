@@ -192,6 +192,8 @@ def test_filter_is_superset_with_bounded_excess(dev, small_index):
     cap = 4096
     cs_, pi_, lut_, qmeta, surv, sc, _ = _run_filter(index, qd, torch.from_numpy(tau).to(dev), p_lo, dev, cap)
     qmeta = qmeta.cpu().numpy()
+    from gnnlm_amd import ops
+    u_tab = ops.ivfpq_quantize_lut(lut_, 64)[0].cpu().numpy().astype(np.int64) ^ 0x80     # [nq, 2, 256, 32]: the byte tables
     assert sc[0] == len(exact[0][0]) and sc[0] > cap                         # tau = -inf: everything, counted beyond the capacity
     assert sc[1] == 0
     list_of_row = np.searchsorted(arr["list_off"], np.arange(index.ntotal), side="right") - 1
@@ -201,7 +203,11 @@ def test_filter_is_superset_with_bounded_excess(dev, small_index):
         got = surv[r, :sc[r]]
         got_rows = got[:, 0].astype(np.int64) & 0xffffffff
         assert len(np.unique(got_rows)) == len(got_rows)                     # no key twice
-        assert np.array_equal(list_of_row[got_rows], got[:, 1])              # {row, list} pairs
+        assert np.array_equal(list_of_row[got_rows], got[:, 1].astype(np.int64) & 0x3ffff)   # {row, list | sum_u << 18} records
+        su = (got[:, 1].astype(np.int64) & 0xffffffff) >> 18                 # ... whose sum_u is the key's exact integer sum
+        exact_su = sum(u_tab[r, m // 32, arr["list_codes"][got_rows, m].astype(np.int64), m % 32] for m in range(64))
+        small = su < 16383                                                   # (16383: beyond what the filter's staging entry holds)
+        assert np.array_equal(su[small], exact_su[small]) and small.mean() > 0.9
         must = rows[s64 > tau[r] - 1e-6]                                     # (1e-6: float32 vs float64 scores at the threshold)
         assert np.isin(must, got_rows).all(), r                              # superset
         band = 66.0 * qmeta[r, 0] + 1e-4
@@ -494,3 +500,29 @@ def test_reference_shape_search_vs_oracle(dev, reference_shape_index, tmp_path):
     np.testing.assert_allclose(p.cpu().numpy(), p_ref.numpy(), rtol=2e-3, atol=1e-6)
     assert np.abs(rec.cpu().numpy() - rec_ref.numpy()).max() <= 2            # near-ties at the k-th place may swap a neighbour
     assert rec.min().item() >= 1
+
+
+def test_refine_tightens_the_threshold_and_keeps_the_result(dev, small_index):
+    """gnnlm_ivfpq_refine (ABI 7): the k-th largest LOWER bound among a query's survivors is a valid threshold (at least k keys of
+    the probed lists score above it), never below the threshold pass's, the records dropped cannot beat it, and the search result is
+    the one without the step -- bit for bit."""
+    from gnnlm_amd.ivfpq import IVFPQIndex
+    index, q = small_index
+    args = (index.R, index.coarse, index.pq, index.list_off, index.list_ids, index.list_codes)
+    a, b = IVFPQIndex(*args, nprobe=9), IVFPQIndex(*args, nprobe=9)
+    b.refine_tau = False
+    a.keep_candidates = b.keep_candidates = True
+    qd = torch.from_numpy(np.concatenate([q, q[::-1]])).to(dev)
+    for k in (1024, 64, 2000):
+        va, ia = a.search_device(qd, k)
+        tau_a, cnt_a = a.last_candidates[3].cpu().numpy(), a.last_candidates[2].cpu().numpy()
+        vb, ib = b.search_device(qd, k)
+        tau_b, cnt_b = b.last_candidates[3].cpu().numpy(), b.last_candidates[2].cpu().numpy()
+        assert torch.equal(va, vb) and torch.equal(ia, ib), k
+        assert (tau_a >= tau_b).all() and (cnt_a <= cnt_b).all()
+        assert (cnt_a >= np.minimum(k, cnt_b)).all()                          # still at least k candidates wherever there were k
+        if k == 1024:
+            assert cnt_a.sum() < 0.9 * cnt_b.sum(), (k, cnt_a.sum(), cnt_b.sum())   # and fewer of them to score and select from (6 of this
+                                                                                    # index's 9 probed lists are threshold lists: little is lost to begin with)
+        sa, sb = float(a.stats["rescored"]), float(b.stats["survivors"])
+        assert sa <= sb and float(a.stats["survivors"]) == sb
