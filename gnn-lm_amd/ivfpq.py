@@ -37,6 +37,36 @@ import torch
 from . import _lib, ops
 
 
+class _LazyStats(dict):
+    """Work counters of a search whose device-side terms are only reduced when somebody reads them: a search enqueues no
+    bookkeeping kernels for numbers that only bench.py and the tests look at (``add`` keeps the tensors and a thunk)."""
+
+    def add(self, key, thunk):
+        dict.setdefault(self, key, 0)
+        self.__dict__.setdefault("_pending", {}).setdefault(key, []).append(thunk)
+
+    def _resolve(self, key):
+        pend = self.__dict__.get("_pending", {}).pop(key, None)
+        if pend:
+            dict.__setitem__(self, key, dict.__getitem__(self, key) + sum(t() for t in pend))
+
+    def __getitem__(self, key):
+        self._resolve(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in list(self.keys())]
+
+    def clone(self):
+        out = _LazyStats()
+        for k, v in self.items():
+            dict.__setitem__(out, k, v.clone() if torch.is_tensor(v) else v)
+        return out
+
+
 def _kmeans(x, k, iters, gen, spherical=False, init=None):
     """Lloyd's algorithm (squared L2) on the device; empty clusters are re-seeded from random points.  ``spherical``: the
     centroids are L2-normalised after every update (faiss ClusteringParameters.spherical, set by index_factory for
@@ -323,11 +353,10 @@ class IVFPQIndex:
         threshold) are searched again on their own with every probed list scored in full; if many overflow, the capacity is
         doubled for good and the call repeated."""
         q = q.to(self.device, torch.float32).contiguous()
-        zero = lambda: torch.zeros((), device=self.device, dtype=torch.float64)
         while True:
-            # work counters of this call (device side; bench.py reads them): (query, key) pairs of the probed lists, survivors
-            # of the filter, candidates after the exact re-score, queries searched a second time because their survivors overflowed
-            self.stats = {"pairs": zero(), "survivors": zero(), "candidates": zero(), "queries": q.shape[0], "M": self.M, "requeried": 0}
+            # work counters of this call (device side, reduced lazily; bench.py reads them): (query, key) pairs of the probed lists,
+            # survivors of the filter, candidates after the exact re-score, queries searched a second time because their survivors overflowed
+            self.stats = _LazyStats(pairs=0, survivors=0, candidates=0, queries=q.shape[0], M=self.M, requeried=0)
             val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
             if over is None:
                 break
@@ -338,7 +367,7 @@ class IVFPQIndex:
                 self.cand_cap *= 2
                 continue
             sub, cap2 = q[bad].contiguous(), self.cand_cap
-            main = {k_: (v_.clone() if torch.is_tensor(v_) else v_) for k_, v_ in self.stats.items()}
+            main = self.stats.clone()
             while True:                                                       # every probed list in the threshold / dense round
                 v2, i2, o2 = self._search_once(sub, k, query_block, self.nprobe, cap2)
                 if o2 is None or int(o2.max().item()) <= cap2:
@@ -348,7 +377,8 @@ class IVFPQIndex:
                                      f"capacity ({cap2}); lower k / nprobe or search this index with scan='f32'")
                 cap2 *= 2
             val[bad], idx[bad] = v2, i2
-            self.stats = dict(main, requeried=int(bad.numel()))               # (the counters describe the main pass)
+            dict.__setitem__(main, "requeried", int(bad.numel()))             # (the counters describe the main pass)
+            self.stats = main
             break
         self._overflow = None
         if self.metric == "l2":
@@ -389,8 +419,7 @@ class IVFPQIndex:
             pv = (2.0 * pv - (qr ** 2).sum(1, keepdim=True)).contiguous()      # the list's bias: -|q' - c_l|^2
         else:
             ops.topk_merge(cs, pv, pi, largest=True, init=True)                 # the nprobe best lists, best first
-        lens = self.list_off[1:] - self.list_off[:-1]
-        self.stats["pairs"] += lens[pi.clamp(min=0)].masked_fill(pi < 0, 0).sum()
+        self.stats.add("pairs", lambda pi=pi: (self.list_off[1:] - self.list_off[:-1])[pi.clamp(min=0)].masked_fill(pi < 0, 0).sum().double())
         lut = torch.empty(nq, self.M * 256, device=dev, dtype=torch.float32)    # lut[q][m][c] = <q'_m, p_mc>: M small GEMMs
         g = _lib.gnnlm_gemm_t()
         g.A, g.lda, g.W, g.ldw, g.C, g.ldc = qr.data_ptr(), qr.stride(0), self.pq.data_ptr(), self.dsub, lut.data_ptr(), self.M * 256
@@ -419,7 +448,7 @@ class IVFPQIndex:
         # round 2: the other lists only emit scores above the query's k-th best so far
         tau = torch.where(bi[:, k - 1] >= 0, bv[:, k - 1], torch.full_like(bv[:, k - 1], float("-inf"))).contiguous()
         self._scan(lut_s, pv, pi, dense, nprobe, tau=tau, cand=(cv, ci, cc), cap=cap)
-        self.stats["candidates"] += cc.sum()
+        self.stats.add("candidates", lambda cc=cc: cc.sum().double())
         if getattr(self, "keep_candidates", False):                          # tests / debugging: the round-2 candidates of the last block
             self.last_candidates = (cv, ci, cc, tau)
         ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=False, row_ncols=cc.clamp(max=cap))
@@ -457,7 +486,7 @@ class IVFPQIndex:
         surv = torch.empty(nq, cap, 2, device=dev, dtype=torch.int32)
         sc16 = torch.zeros(nq, 16, device=dev, dtype=torch.int32)              # one 64-byte line per counter (column 0)
         g2 = self._groups(pi)
-        self.stats["groups"] = self.stats.get("groups", 0) + g2[2][0]
+        self.stats.add("groups", lambda g=g2[2]: g[0].double())
         self._scan8(qlut, qmeta, cs, g2, tau=tau, surv=(surv, sc16))
         sc = sc16[:, 0]
         # a tighter threshold from the survivors' own integer sums (all lists, un-binned), and only the survivors that can beat it
@@ -468,15 +497,15 @@ class IVFPQIndex:
             f.surv, f.surv_cnt, f.out_cnt, f.cap = surv.data_ptr(), sc16.data_ptr(), rc16.data_ptr(), cap
             f.tau, f.qmeta, f.coarse, f.ld_coarse, f.n, f.k = tau.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0), nq, k
             _lib.call_desc("gnnlm_ivfpq_refine", f)
-            self.stats["rescored"] = self.stats.get("rescored", 0) + rc16[:, 0].sum()
+            self.stats.add("rescored", lambda rc=rc16: rc[:, 0].sum().double())
         r = _lib.gnnlm_ivfpq_rescore_t()
         r.codes, r.payload, r.M = self.list_codes.data_ptr(), self.payload.data_ptr(), self.M
         r.lut, r.ld_lut, r.coarse, r.ld_coarse, r.tau = lut.data_ptr(), lut.stride(0), cs.data_ptr(), cs.stride(0), tau.data_ptr()
         r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), rc16.data_ptr(), cap, nq
         r.cand_val, r.cand_id, r.cand_cnt, r.cand_cap = cv.data_ptr(), ci.data_ptr(), cc.data_ptr(), cap
         _lib.call_desc("gnnlm_ivfpq_rescore", r)
-        self.stats["survivors"] += sc.sum()
-        self.stats["candidates"] += cc.sum()
+        self.stats.add("survivors", lambda sc=sc: sc.sum().double())
+        self.stats.add("candidates", lambda cc=cc: cc.sum().double())
         if getattr(self, "keep_candidates", False):
             self.last_candidates = (cv, ci, cc, tau)
         ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=True, row_ncols=cc.clamp(max=cap))
