@@ -1121,7 +1121,17 @@ def main():
     tokens = args.steps * args.blocks * args.tokens_per_sample * world
     score_sum = acc.item()
 
-    roof = lambda name, e: roofline_entry(name, e, args.precision)
+    def roof(name, e):
+        r_ = roofline_entry(name, e, args.precision)
+        if name == "knn_interp_kernel" and batches[0].knn_vals is None:
+            # ids-only search results: k random 4-byte label reads per token.  What bounds them is the REQUEST rate of the memory
+            # system, not bytes: ~48 G requests/s for anything up to 128 B (tools/probes/fetch_calib.hip: random 4-B words, and
+            # cooperatively fetched 64-B and 128-B rows, all saturate there; FETCH_SIZE counts exactly these requests)
+            n_tok = args.blocks * args.tokens_per_sample
+            req = e["launches"] * (n_tok * args.k + n_tok * args.k * 12 / 128.0)          # label gathers + the id / sim stream in 128-B requests
+            r_["requests_per_s_G"] = round(req / (e["total_ms"] / 1e3) / 1e9, 1)
+            r_["frac_of_measured_request_ceiling_48G"] = round(req / (e["total_ms"] / 1e3) / 48e9, 3)
+        return r_
     if rank == 0:
         r = roof(dominant, prof)
         r["traffic"], r["traffic_source"] = pmc_traffic(dominant)

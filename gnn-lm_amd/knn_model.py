@@ -114,6 +114,9 @@ class KNNModel(object):
         self.k, self.metric_type, self.sim_func, self.cuda = k, metric_type, sim_func, cuda
         assert self.metric_type in ["do_not_recomp_l2", "do_not_recomp_ip", "l2", "ip"]
         self.device = torch.device(device if device is not None else "cuda")
+        # `ip` / `l2` recompute similarities from the keys: the table goes to HBM when it fits (and is smaller than this bound),
+        # else its rows are gathered from the host per query block (`host_gather_bytes` of float32 rows per block)
+        self.max_hbm_key_bytes, self.host_gather_bytes = float("inf"), 1 << 30
         self.index = index if index is not None else self.setup_faiss()
         self._vals_dev = None
         # an IVF-PQ index searched on the device carries the labels next to the key ids (one payload per key): the search
@@ -178,9 +181,8 @@ class KNNModel(object):
             return self.keys
         need = self.dstore_size * self.hidden_size * (2 if self.dstore_fp16 else 4)
         free = torch.cuda.mem_get_info(self.device)[0]
-        if need > 0.9 * free:
-            raise MemoryError(f"--knn-sim-func {self.metric_type} recomputes similarities from the keys: {need / 2**30:.0f} GiB "
-                              f"do not fit in the {free / 2**30:.0f} GiB of free HBM; use do_not_recomp_* or shard the store")
+        if need > min(0.9 * free, self.max_hbm_key_bytes):
+            return None                               # the key table stays where the reference keeps it: _sims gathers rows from the host
         return self.data_store.keys_to_device(self.device)
 
     def vals_device(self):
@@ -215,16 +217,33 @@ class KNNModel(object):
         # the recomputed similarities gather key rows: from HBM (the exact index's table, or the store's keys uploaded
         # once -- the reference's per-query np.memmap gather on the host, :163,170, is what this replaces); numpy's
         # negative-index wrap of the -1 padding is kept (row N - 1)
+        if fn not in ("l2", "ip"):
+            raise ValueError("Invalid knn similarity function!")
         keys_dev = self._keys_device()
-        idx = torch.where(knns < 0, knns + keys_dev.shape[0], knns)
-        vecs = keys_dev[idx].float()
-        if fn == "l2":
-            return -1 * torch.sum((queries[:, None, :] - vecs) ** 2, dim=2)
-        if fn == "ip":
+
+        def sims_of(vecs, q):
+            if fn == "l2":
+                return -1 * torch.sum((q[:, None, :] - vecs) ** 2, dim=2)
             if self.cosine:
                 vecs = vecs / (vecs ** 2).sum(-1, keepdims=True).sqrt()
-            return (vecs * queries[:, None, :]).sum(dim=-1)
-        raise ValueError("Invalid knn similarity function!")
+            return (vecs * q[:, None, :]).sum(dim=-1)
+
+        if keys_dev is not None:
+            idx = torch.where(knns < 0, knns + keys_dev.shape[0], knns)
+            return sims_of(keys_dev[idx].float(), queries)
+        # A key table larger than the free HBM (WikiText-103 train: 211 GB of fp16 keys next to everything else): the k rows of
+        # every query are gathered from the host table exactly as the reference does (`self.keys[knns]` on the np.memmap,
+        # :163,170) -- in blocks of queries, through pinned memory -- and the arithmetic runs on the device.  Slow by
+        # construction (n k random 2-KB host reads: the recipes use do_not_recomp_ip for that reason); same numbers.
+        n, k = knns.shape
+        host_idx = torch.where(knns < 0, knns + self.dstore_size, knns).cpu().numpy()
+        rows_per_block = max(1, self.host_gather_bytes // max(1, k * self.hidden_size * 4))
+        out = torch.empty(n, k, device=queries.device, dtype=torch.float32)
+        for r0 in range(0, n, rows_per_block):
+            blk = host_idx[r0:r0 + rows_per_block]
+            vecs = torch.from_numpy(np.ascontiguousarray(self.keys[blk.reshape(-1)])).to(queries.device).float()
+            out[r0:r0 + blk.shape[0]] = sims_of(vecs.reshape(blk.shape[0], k, self.hidden_size), queries[r0:r0 + blk.shape[0]])
+        return out
 
     def search_sims(self, queries, k=0, with_vals=False):
         """queries [n, d] (device) -> (sims [n,k] f32, knns [n,k] i64[, knn_vals [n,k] i32 or None]), before the -1 masking."""

@@ -527,3 +527,31 @@ def test_eval_lm_reads_the_producers_outputs(dev, tmp_path):
         one = {"neighbor_idxs": blk["ids"][s:e], "tgt_feats": blk["tgt_feats"][s:e], "targets": blk["targets"][s:e], "knn_sims": None, "knn_ids": None}
         total += pipeline.eval_block(one, model, 0.0, 1.0)["lm_logp"].double().sum().item()
     assert res["count"] == n_test and abs(res["score_sum"] - total) < 1e-4 * n_test
+
+
+@pytest.mark.parametrize("metric_type", ["ip", "l2"])
+def test_knn_model_recompute_from_host_keys(dev, golden, tmp_path, metric_type):
+    """`--knn-sim-func ip | l2` with a key table that does not go to HBM (knn_model.py:163,170 gather `self.keys[knns]` from the
+    np.memmap): rows gathered from the host per query block, arithmetic on the device -- the numbers of the in-HBM path and the
+    reference's own (golden `knn.npz`)."""
+    from gnnlm_amd.knn_model import KNNModel
+    g = golden("knn")
+    d = str(tmp_path / "train_dstore")
+    write_dstore(d, g["keys"], g["vals"].astype(np.int16), 50)
+    q = torch.from_numpy(g["queries"]).to(dev)
+    tg = torch.from_numpy(g["targets"]).to(dev)
+    for cosine in (False, True):
+        tag = f"{metric_type}.{'cos' if cosine else 'raw'}.t1.0"
+        idx_file = "faiss_store.cosine" if cosine else "faiss_store.ip"
+        outs = []
+        for bound, blk in ((float("inf"), 1 << 30), (0, 1 << 30), (0, 3 * 8 * g["keys"].shape[1] * 4)):     # in HBM / host gather / tiny blocks
+            m = KNNModel(idx_file, d, metric_type=metric_type, k=8, index=FixedIndex(g[tag + ".dists"], g[tag + ".ids"]), device=dev)
+            m.max_hbm_key_bytes, m.host_gather_bytes = bound, blk
+            p, rec = m.get_knn_prob(q, t=1.0, targets=tg, return_recall=True)
+            assert (m._keys_device() is None) == (bound == 0)
+            outs.append((p.cpu().numpy(), rec.cpu().numpy()))
+        for p_, r_ in outs[1:]:
+            np.testing.assert_allclose(p_, outs[0][0], rtol=1e-6, atol=1e-9)
+            assert np.array_equal(r_, outs[0][1])
+        assert np.array_equal(outs[0][1], g[tag + ".recall"])
+        np.testing.assert_allclose(outs[1][0], g[tag + ".p"], rtol=3e-5, atol=1e-7)
