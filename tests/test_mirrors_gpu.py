@@ -555,3 +555,71 @@ def test_knn_model_recompute_from_host_keys(dev, golden, tmp_path, metric_type):
             assert np.array_equal(r_, outs[0][1])
         assert np.array_equal(outs[0][1], g[tag + ".recall"])
         np.testing.assert_allclose(outs[1][0], g[tag + ".p"], rtol=3e-5, atol=1e-7)
+
+
+def test_pipeline_from_raw_keys(dev, tmp_path):
+    """The whole pipeline of the recipes from nothing but raw key tables, every producer this repo's own (no faiss):
+    quantize_features (find_knn.sh:32-38) -> run_index_build (find_knn.sh:8-13) -> find_knn (:17-22) -> eval_lm --graph --knnlm
+    (hgt_lm_wiki103_reproduce.sh:140-150).  The driver's score equals the oracle's over the SAME produced files (codes, quantizer,
+    neighbour ids, index arrays)."""
+    from gnnlm_amd import eval_lm, find_knn, quantize_features, run_index_build
+    from gnnlm_amd.faiss_io import read_pq_quantizer
+    from gnnlm_amd.synthetic import make_problem
+    from oracle import ivfpq as oivf, knn as oknn_, pipeline
+    d, H, M, dsub, V, kg, T, L, k = 64, 4, 16, 4, 600, 6, 16, 2, 32
+    n_train, n_test = 6000, 41
+    prob = make_problem(n_store=n_train, d=d, n_heads=H, M=M, dsub=dsub, vocab=V, cutoff=[100, 300], T=n_test, kg=kg,
+                        left=2, right=2, n_layers=L, k=8, seed=5)
+    rs = np.random.RandomState(9)
+    centres = rs.randn(30, d).astype(np.float32)
+    train_keys = (centres[rs.randint(0, 30, n_train)] + 0.5 * rs.randn(n_train, d)).astype(np.float16)
+    test_keys = (centres[rs.randint(0, 30, n_test)] + 0.5 * rs.randn(n_test, d)).astype(np.float16)
+    targets = np.maximum(prob["block"]["targets"], 4)
+    data = tmp_path / "data-bin"
+    write_dstore(str(data / "train_dstore"), train_keys, prob["vals"].astype(np.int16), V)
+    write_dstore(str(data / "test_dstore"), test_keys, targets.astype(np.int16), V)
+    # 1. the quantizer and the code table
+    quantize_features.main(quantize_features.get_parser().parse_args(
+        ["--data-dir", str(data), "--subset", "train", "--index", f"OPQ{M}_{d},,PQ{M}", "--code-size", str(M), "--chunk-size", "6000",
+         "--pq-iters", "6", "--opq-iters", "3"]))
+    # 2. the kNN index over the train keys, 3. the graph neighbours of the test split (searched over that index)
+    run_index_build.main(run_index_build.get_parser().parse_args(
+        ["--dstore-dir", str(data / "train_dstore"), "--index-type", f"OPQ{M}_{d},IVF32,PQ{M}", "--metric", "cosine", "--nprobe", "8"]))
+    find_knn.main(find_knn.get_parser().parse_args(["--data-dir", str(data), "--subset", "test", "--k", str(kg), "--nprobe", "8"]))
+    nbrs = np.array(np.memmap(str(data / "test_dstore" / f"neighbors.mmap.{kg}"), dtype=np.int64, mode="r", shape=(n_test, kg)))
+    assert nbrs.min() >= 0 and nbrs.max() < n_train
+    # 4. the driver, with a checkpoint that carries no quantizer (the recipe's `quantizer_path` override)
+    sd = {"decoder.hgt_decoder." + k_: v for k_, v in prob["sd"].items()}
+    w = prob["asm"]
+    for i, e in enumerate(w["emb"]):
+        sd[f"decoder.embed_tokens.embeddings.{i}.0.weight"] = e
+        if i:
+            sd[f"decoder.embed_tokens.embeddings.{i}.1.weight"] = w["proj"][i]
+    sd["decoder.adaptive_softmax.head.class_proj.weight"] = w["class_proj"]
+    margs = Namespace(decoder_embed_dim=d, decoder_attention_heads=H, graph_layer=L, decoder_gcn_dim=d,
+                      adaptive_softmax_cutoff="100,300", orig_prob_ratio=0.0, short_cut=False, quantizer_path="")
+    torch.save({"args": margs, "model": sd}, str(tmp_path / "ckpt.pt"))
+    lam, temp = 0.25, 1.0
+    res = eval_lm.cli_main(
+        [str(data), "--path", str(tmp_path / "ckpt.pt"), "--gen-subset", "test", "--graph", "--neighbor-context", "2", "--gcn-k", str(kg),
+         "--use-precompute-feat", "--sample-break-mode", "none", "--max-tokens", str(T), "--tokens-per-sample", str(T),
+         "--gcn-context-window", "0", "--knn-keytype", "gcn_feat", "--model-overrides",
+         "{'orig_prob_ratio': 0.0, 'quantizer_path': '%s'}" % str(data / "quantizer"),
+         "--knnlm", "--k", str(k), "--lmbda", str(lam), "--dstore-dir", str(data / "train_dstore"),
+         "--index-file", str(data / "train_dstore" / "faiss_store.cosine"), "--temperature", str(temp), "--knn-sim-func", "do_not_recomp_ip", "--probe", "8"])
+    # the oracle over the produced files
+    q = read_pq_quantizer(str(data / "quantizer"))
+    z = np.load(str(data / "train_dstore" / "faiss_store.cosine.gnnlm.npz"))
+    model = {"sd": prob["sd"], "n_layers": L, "n_heads": H, "centroids": q["centroids"], "A": q["A"], "b": q["b"],
+             "codes": np.load(str(data / "train_dstore" / "quantized-keys.npy")), "vals": prob["vals"], "n_store": n_train,
+             "left": 2, "right": 2, "asm": w}
+    total = 0.0
+    for s in range(0, n_test, T):
+        e = min(n_test, s + T)
+        one = {"neighbor_idxs": nbrs[s:e], "tgt_feats": test_keys[s:e], "targets": targets[s:e], "knn_sims": None, "knn_ids": None}
+        o = pipeline.eval_block(one, model, 0.0, 1.0)
+        qn = oknn_.normalize_queries(o["gcn_feat"].float(), True).numpy()
+        dd, ii = oivf.search(qn, z["R"], z["coarse"], z["pq"], z["list_off"], z["list_ids"], z["list_codes"], k=k, nprobe=8)
+        p, _ = oknn_.knn_target_prob(dd.astype(np.float32), ii, prob["vals"], targets[s:e], temp)
+        total += oknn_.combine_knn_and_vocab_probs(p, o["lm_logp"], lam).double().sum().item()
+    assert res["count"] == n_test and abs(res["score_sum"] - total) < 5e-4 * n_test
