@@ -195,45 +195,67 @@ class CentreStateCache:
     tgt nodes (token_block_dataset.py:395-398: only `ntgt -> tgt` and `ntgt <-> ntgt` edges), so that state is a function of
     the centre's datastore row alone -- the same for every token, block and batch that retrieves the row.  Real neighbour lists
     repeat rows heavily (the reference's own "todo: merge same nodes", :355, is the within-block half of this).  The cache
-    keeps ``[n_layers - 1, capacity, d]`` float32 states in HBM, a direct row -> slot table (int32 per datastore row: no
-    hashing) and fills slots in arrival order; when it is full it is emptied (the batch that did not fit starts the next
-    generation).  Exact: the states are the ones the un-cached call computes."""
+    keeps ``[n_layers - 1, capacity, d]`` float32 states in HBM and a direct row -> slot table (int32 per datastore row: no
+    hashing).  Slots are filled in arrival order in TWO GENERATIONS (the halves of the table): when the current half is full
+    the other one is emptied and refilled, so the more recent half of what was computed always survives.  Exact: the states
+    are the ones the un-cached call computes."""
 
     def __init__(self, n_store, n_layers, d, capacity, device):
         self.n_store, self.capacity, self.device = n_store, int(capacity), device
+        self.half = max(1, self.capacity // 2)
         self.slot_of = torch.full((n_store,), -1, dtype=torch.int32, device=device)
         self.id_of_slot = torch.empty(self.capacity, dtype=torch.int64, device=device)
         self.states = torch.empty(n_layers - 1, self.capacity, d, dtype=torch.float32, device=device)
-        self.used = 0
+        self.gen, self.fill = 0, [0, 0]                                       # the half being filled, entries in each half
         self.stream = torch.cuda.current_stream(device).cuda_stream          # slots are reused in stream order: one stream only
         self.stats = {"lookups": 0, "groups": 0, "computed": 0, "generations": 1}
 
+    @property
+    def used(self):
+        return self.fill[0] + self.fill[1]
+
+    def _drop(self, g):
+        if self.fill[g]:
+            lo = g * self.half
+            self.slot_of[self.id_of_slot[lo:lo + self.fill[g]]] = -1
+        self.fill[g] = 0
+
     def clear(self):
-        if self.used:
-            self.slot_of[self.id_of_slot[:self.used]] = -1
-        self.used = 0
+        self._drop(0)
+        self._drop(1)
+        self.gen = 0
         self.stats["generations"] += 1
+
+    def _room(self, g):
+        return (self.half if g == 0 else self.capacity - self.half) - self.fill[g]
 
     def assign(self, flat_ids):
         """flat_ids int64 [n]: neighbour rows (-1 / out of range: none) -> (miss_ids int64 [m] ascending, miss_slots int32 [m],
-        slot int32 [n] with -1 for "not a neighbour"), or None when the batch's new groups alone exceed the capacity.
+        slot int32 [n] with -1 for "not a neighbour"), or None when the batch's new groups alone exceed a generation.
         One host sync (the number of new groups), like the within-batch merge it extends."""
         valid = (flat_ids >= 0) & (flat_ids < self.n_store)
         key = torch.where(valid, flat_ids, torch.zeros_like(flat_ids))
-        slot = torch.where(valid, self.slot_of[key], torch.full_like(key, -1, dtype=torch.int32))
+        none = torch.full_like(key, -1, dtype=torch.int32)
+        slot = torch.where(valid, self.slot_of[key], none)
         miss = torch.unique(key[valid & (slot < 0)])
-        if self.used + miss.numel() > self.capacity:
-            self.clear()
-            miss = torch.unique(key[valid])
-            if miss.numel() > self.capacity:
+        if miss.numel() > self._room(self.gen):
+            # the current generation is full: the OTHER (older) half is emptied and becomes the one being filled; what this batch
+            # found there has to be computed again
+            self.gen ^= 1
+            self._drop(self.gen)
+            self.stats["generations"] += 1
+            slot = torch.where(valid, self.slot_of[key], none)
+            miss = torch.unique(key[valid & (slot < 0)])
+            if miss.numel() > self._room(self.gen):
                 return None
         m = miss.numel()
-        new = torch.arange(self.used, self.used + m, dtype=torch.int32, device=self.device)
+        lo = self.gen * self.half + self.fill[self.gen]
+        new = torch.arange(lo, lo + m, dtype=torch.int32, device=self.device)
         if m:
             self.slot_of[miss] = new
-            self.id_of_slot[self.used:self.used + m] = miss
-            self.used += m
-            slot = torch.where(valid, self.slot_of[key], torch.full_like(slot, -1))
+            self.id_of_slot[lo:lo + m] = miss
+            self.fill[self.gen] += m
+            slot = torch.where(valid, self.slot_of[key], none)
         self.stats["lookups"] += 1
         self.stats["groups"] += int(flat_ids.numel())
         self.stats["computed"] += m
@@ -269,7 +291,7 @@ class HGT(nn.Module):
         self.dedup_groups = os.environ.get("GNNLM_DEDUP", "1") != "0"      # merge equal context groups of a batch (multi-layer models)
         self.last_groups = None                                              # (groups of the last batch, distinct ones)
         # centre states of context groups kept ACROSS batches (CentreStateCache): HBM budget in GiB, 0 = off
-        self.state_cache_gib = float(os.environ.get("GNNLM_STATE_CACHE_GIB", "16"))
+        self.state_cache_gib = float(os.environ.get("GNNLM_STATE_CACHE_GIB", "32"))
         self.state_cache_slots = None
         self.state_cache = None
 
