@@ -286,3 +286,38 @@ def test_hgt_centre_state_cache(dev, L):
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd2.items()}, strict=True)
     plain_model.load_state_dict({k: torch.as_tensor(v) for k, v in sd2.items()}, strict=True)
     assert np.array_equal(run(model, *a), run(plain_model, *a)) and model.state_cache is not old_cache
+
+
+def test_state_cache_bits_at_recipe_shapes(dev):
+    """The cached call computes a DIFFERENT number of rows per launch than the un-cached one (a few new groups instead of all of
+    them), i.e. its GEMMs may take another kernel (64x64 tiles instead of the hand-scheduled 128x128 loop): the recipe's shapes
+    (d = 1024, H = 8, PQ 128x8 + OPQ, k_g = 128, l = r = 2, L = 3, one 256-token block = 32 k groups) with 0 / 90 / 99.7 / 100 % of the
+    neighbour rows already cached -- bit-identical to the un-cached call every time."""
+    from gnnlm_amd.hgt import HGT, CodeStore, NeighborGraph
+    d, H, M, dsub, T, kg, L, N = 1024, 8, 128, 8, 256, 128, 3, 1_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    codes = torch.randint(0, 256, (N, M), generator=g, device=dev, dtype=torch.uint8)
+    cen = torch.randn(M, 256, dsub, generator=g, device=dev) * 0.5
+    A = torch.linalg.qr(torch.randn(d, d, generator=g, device=dev))[0].contiguous()
+    b = torch.randn(d, generator=g, device=dev) * 0.1
+    store = CodeStore(codes=codes, centroids=cen, n_store=N, vals=None, A=A, b=b)
+    torch.manual_seed(1)
+    cached = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=L, n_heads=H)
+    plain = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=L, n_heads=H)
+    plain.load_state_dict(cached.state_dict())
+    plain.state_cache_gib, cached.state_cache_slots = 0.0, 200000
+    ids_a = torch.randint(0, N, (T, kg), generator=g, device=dev)
+    x = torch.randn(T, d, generator=g, device=dev)
+    run = lambda m, ids: m(NeighborGraph(ids=ids, n_blocks=1, T=T, left=2, right=2, store=store), features={"tgt": x})["tgt"]
+    computed = []
+    for frac in (0.0, 0.9, 0.997, 1.0):
+        ids_b = ids_a.clone()
+        fresh = torch.rand(T, kg, generator=g, device=dev) >= frac
+        ids_b[fresh] = torch.randint(0, N, (int(fresh.sum()),), generator=g, device=dev)
+        cached.state_cache = None
+        run(cached, ids_a)                                                    # fills the cache
+        got = run(cached, ids_b)
+        computed.append(cached.last_groups[1])
+        assert torch.equal(got, run(plain, ids_b)), frac
+    assert computed[0] > 30000 and 2000 < computed[1] < 5000 and 0 < computed[2] < 300 and computed[3] == 0
