@@ -694,13 +694,19 @@ def knn_search(args, eng, batches, dev, step_ms):
         model = GnnLmModel(eng.hgt, eng.asm, None)
         model.make_store = lambda codes, n_store, device: st_
 
-        class SearchKnn:                          # KNNModel.interpolate over the device index (cosine: knn_model.py:181-184)
-            def interpolate(self, queries, targets, lm_logp, t, lmbda, k=0):
+        class SearchKnn:                          # KNNModel.interpolate_begin / _finish over the device index (cosine: knn_model.py:181-184)
+            def interpolate_begin(self, queries, k=0):
                 qn = queries.float()
                 qn = qn / (qn ** 2).sum(-1, keepdims=True).sqrt()
-                sims_, ids_, vals_ = idx.search_device(qn.contiguous(), args.k, return_vals=True)
+                return idx.search_begin(qn.contiguous(), args.k, return_vals=True)
+
+            def interpolate_finish(self, h, targets, lm_logp, t, lmbda):
+                sims_, ids_, vals_ = h.result()
                 return ops.knn_interp(lm_logp.contiguous(), sims_.contiguous(), ids_.contiguous(), targets.long().contiguous(), t, lmbda,
                                       n_store=st_.n_store, knn_vals=vals_.contiguous())
+
+            def interpolate(self, queries, targets, lm_logp, t, lmbda, k=0):
+                return self.interpolate_finish(self.interpolate_begin(queries), targets, lm_logp, t, lmbda)
         n_tok = nb * len(batches)
         tabs = {"n_tok": n_tok, "d": eng.hgt.hidden_dim, "vocab": None, "n_store": st_.n_store, "feats": pool[0], "targets": pool[1].clamp(min=4),
                 "nbrs": pool[2], "codes": st_.codes, "no_pad": True}

@@ -67,6 +67,20 @@ class _LazyStats(dict):
         return out
 
 
+class _PendingSearch:
+    """Handle of ``IVFPQIndex.search_begin``."""
+
+    def __init__(self, index, q, k, query_block, return_vals, val, idx, over, worst, ev):
+        self.index, self.q, self.k, self.query_block, self.return_vals = index, q, k, query_block, return_vals
+        self.val, self.idx, self.over, self.worst, self.ev = val, idx, over, worst, ev
+        self._out = None
+
+    def result(self):
+        if self._out is None:
+            self._out = self.index._finish(self)
+        return self._out
+
+
 def _kmeans(x, k, iters, gen, spherical=False, init=None):
     """Lloyd's algorithm (squared L2) on the device; empty clusters are re-seeded from random points.  ``spherical``: the
     centroids are L2-normalised after every update (faiss ClusteringParameters.spherical, set by index_factory for
@@ -352,19 +366,42 @@ class IVFPQIndex:
         back once per call (the only host sync).  Queries with more (a query whose dense lists hold fewer than k keys has no
         threshold) are searched again on their own with every probed list scored in full; if many overflow, the capacity is
         doubled for good and the call repeated."""
+        return self.search_begin(q, k, query_block, return_vals).result()
+
+    def search_begin(self, q, k, query_block=None, return_vals=False):
+        """Enqueue the search and return a handle; ``handle.result()`` waits for the SEARCH only (an event behind its last kernel, the
+        worst survivor count on its way to pinned memory) and returns what ``search_device`` returns.  Work enqueued between the two
+        calls (the language model's softmax, which does not depend on the neighbours) keeps the device busy while the host looks at
+        the count and enqueues what follows: no pipeline bubble behind the search's one host round trip."""
         q = q.to(self.device, torch.float32).contiguous()
-        while True:
-            # work counters of this call (device side, reduced lazily; bench.py reads them): (query, key) pairs of the probed lists,
-            # survivors of the filter, candidates after the exact re-score, queries searched a second time because their survivors overflowed
-            self.stats = _LazyStats(pairs=0, survivors=0, candidates=0, queries=q.shape[0], M=self.M, requeried=0)
-            val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
-            if over is None:
-                break
+        self.stats = _LazyStats(pairs=0, survivors=0, candidates=0, queries=q.shape[0], M=self.M, requeried=0)
+        val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
+        worst = ev = None
+        if over is not None:
+            if getattr(self, "_worst_host", None) is None:
+                self._worst_host = torch.empty(1, dtype=torch.int32).pin_memory()
+            worst = self._worst_host
+            worst.copy_(over.max().reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return _PendingSearch(self, q, k, query_block, return_vals, val, idx, over, worst, ev)
+
+    def _finish(self, h):
+        q, k, query_block = h.q, h.k, h.query_block
+        val, idx, over = h.val, h.idx, h.over
+        while over is not None:
+            if h.ev is not None:
+                h.ev.synchronize()
+                if int(h.worst[0]) <= self.cand_cap:
+                    break
+                h.ev = None
             bad = (over > self.cand_cap).nonzero().reshape(-1)                # host sync
             if bad.numel() == 0:
                 break
             if bad.numel() * 8 > q.shape[0] and self.cand_cap < (1 << 18):
                 self.cand_cap *= 2
+                self.stats = _LazyStats(pairs=0, survivors=0, candidates=0, queries=q.shape[0], M=self.M, requeried=0)
+                val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
                 continue
             sub, cap2 = q[bad].contiguous(), self.cand_cap
             main = self.stats.clone()
@@ -374,7 +411,7 @@ class IVFPQIndex:
                     break
                 if cap2 >= (1 << 22):                                         # survivors beyond the capacity would be dropped silently
                     raise _lib.GnnlmError(f"ivfpq search: {int(o2.max().item())} survivors of one query exceed the largest candidate "
-                                     f"capacity ({cap2}); lower k / nprobe or search this index with scan='f32'")
+                                          f"capacity ({cap2}); lower k / nprobe or search this index with scan='f32'")
                 cap2 *= 2
             val[bad], idx[bad] = v2, i2
             dict.__setitem__(main, "requeried", int(bad.numel()))             # (the counters describe the main pass)
@@ -384,11 +421,11 @@ class IVFPQIndex:
         if self.metric == "l2":
             val = -val                                                        # scores are -distance: squared distances, ascending, +inf padded
         if not self.has_vals:
-            return (val, idx, None) if return_vals else (val, idx)
+            return (val, idx, None) if h.return_vals else (val, idx)
         # payload -> (id in place, label): one pass (gnnlm_ivfpq_split_payload) instead of five elementwise torch kernels over [n, k]
-        vals = torch.empty(idx.shape, dtype=torch.int32, device=idx.device) if return_vals else None
+        vals = torch.empty(idx.shape, dtype=torch.int32, device=idx.device) if h.return_vals else None
         _lib.call("gnnlm_ivfpq_split_payload", _lib.ptr(idx), idx.numel(), self.LABEL_BITS, self.val_last, _lib.ptr(vals), _lib.stream())
-        return (val, idx, vals) if return_vals else (val, idx)
+        return (val, idx, vals) if h.return_vals else (val, idx)
 
     def _search_once(self, q, k, query_block, dense_probes, cap):
         n, dev = q.shape[0], self.device

@@ -278,6 +278,27 @@ class KNNModel(object):
                                       vals=vals if kvals is None else None, n_store=self.dstore_size, knn_vals=kvals)
         return (p, recall) if return_recall else p
 
+    def interpolate_begin(self, queries, k=0):
+        """Start the search for ``interpolate`` and return a handle for ``interpolate_finish``: the scorer enqueues the language
+        model's softmax in between, so the device has work while the host waits for the search's survivor count (an index without
+        ``search_begin`` is searched here and now)."""
+        k = k or self.k
+        q = queries.float()
+        if self.cosine:                                                                 # :181-184
+            q = q / (q ** 2).sum(-1, keepdims=True).sqrt()
+        if getattr(self.index, "has_vals", False) and hasattr(self.index, "search_begin") and self.metric_type.startswith("do_not_recomp"):
+            return ("pending", q, self.index.search_begin(q.contiguous(), k, return_vals=True))
+        dists, knns, kvals = self._search(q, k)
+        return ("done", q, (dists, knns, kvals))
+
+    def interpolate_finish(self, handle, targets, lm_logp, t, lmbda):
+        kind, q, h = handle
+        dists, knns, kvals = h.result() if kind == "pending" else h
+        sims = self._sims(dists, knns, q).contiguous()
+        return ops.knn_interp(lm_logp.contiguous(), sims, knns.contiguous(), targets.long().contiguous(), t, lmbda,
+                              vals=self.vals_device() if kvals is None else None, n_store=self.dstore_size,
+                              knn_vals=None if kvals is None else kvals.contiguous())
+
     def interpolate(self, queries, targets, lm_logp, t, lmbda, k=0):
         """Fused hot-path form: search -> (interpolated log-prob [n], p_knn [n], recall [n])."""
         sims, knns, kvals = self.search_sims(queries, k, with_vals=True)

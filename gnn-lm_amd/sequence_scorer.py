@@ -40,23 +40,33 @@ class SequenceScorer(object):
         orig_target = sample["target"]
         decoder_out = model(**net_input)
         bsz, tsz = orig_target.shape
-        probs = model.target_log_probs(decoder_out, orig_target.clamp(min=0))
-        recall = None
         lmbda = getattr(self.args, "lmbda", 0.0)
-        if "knn_dstore" in kwargs and lmbda > 0.0:
+        use_knn = "knn_dstore" in kwargs and lmbda > 0.0
+        pending = None
+        if use_knn:
             assert bsz * tsz < self.softmax_batch, "kNN scoring needs B*T < --softmax-batch (sequence_scorer.py:105)"
             knn_model = kwargs["knn_dstore"]
             extra = decoder_out[1]
             kt = getattr(self.args, "knn_keytype", None)
             queries = extra[kt] if kt in extra else extra["inner_states"][-1]          # [T, B, C]  (:105)
             seq_len, b2, hidden = queries.shape
+            # the search only needs the features: it is enqueued BEFORE the softmax (which does not need the neighbours), and its
+            # one host round trip (survivor counts) is waited for AFTER -- the device works through the softmax meanwhile
+            if hasattr(knn_model, "interpolate_begin"):
+                pending = knn_model.interpolate_begin(queries.contiguous().view(-1, hidden))
+        probs = model.target_log_probs(decoder_out, orig_target.clamp(min=0))
+        recall = None
+        if use_knn:
             # as written (:117): targets in [B, T] order against queries in [T, B] order -- only right for B = 1, the recipe.
             # The driver's --batch-blocks (several of the recipe's one-block batches per launch) asks for the pairing those
             # one-block batches have: targets in the queries' order.
             tq = (orig_target.transpose(0, 1) if sample.get("blockwise_knn") else orig_target.permute(0, 1)).reshape(seq_len * b2)
             lm_flat = probs.transpose(0, 1).reshape(-1)                                 # [T*B] like the queries
-            mixed, _, rec = knn_model.interpolate(queries.contiguous().view(-1, hidden), tq.clamp(min=0),
-                                                  lm_flat, temperature, lmbda)
+            if pending is not None:
+                mixed, _, rec = knn_model.interpolate_finish(pending, tq.clamp(min=0), lm_flat, temperature, lmbda)
+            else:
+                mixed, _, rec = knn_model.interpolate(queries.contiguous().view(-1, hidden), tq.clamp(min=0),
+                                                      lm_flat, temperature, lmbda)
             probs = mixed.view(seq_len, b2).transpose(0, 1)
             recall = rec.view(seq_len, b2).transpose(0, 1)
         start_idxs = sample["start_indices"] if "start_indices" in sample else [0] * bsz
