@@ -378,9 +378,10 @@ class IVFPQIndex:
         val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
         worst = ev = None
         if over is not None:
-            if getattr(self, "_worst_host", None) is None:
-                self._worst_host = torch.empty(1, dtype=torch.int32).pin_memory()
-            worst = self._worst_host
+            if getattr(self, "_worst_host", None) is None:                    # pinned landing slots, one per search in flight (a ring of 8)
+                self._worst_host, self._worst_next = torch.empty(8, dtype=torch.int32).pin_memory(), 0
+            worst = self._worst_host[self._worst_next:self._worst_next + 1]
+            self._worst_next = (self._worst_next + 1) % 8
             worst.copy_(over.max().reshape(1), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
