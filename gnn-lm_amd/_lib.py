@@ -122,6 +122,8 @@ def lib():
         L.gnnlm_ivfpq_quantize_lut.argtypes = [vp, i64, i64, i32, vp, vp, vp]
         L.gnnlm_ivfpq_build_groups.argtypes = [vp, i64, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp]
         L.gnnlm_label_tags.argtypes = [vp, i32, i64, vp, vp]
+        L.gnnlm_knn_interp_scratch_bytes.argtypes = [i64, i32, i64]
+        L.gnnlm_knn_interp_scratch_bytes.restype = ctypes.c_size_t
         L.gnnlm_ivfpq_split_payload.argtypes = [vp, i64, i32, i32, vp, vp]
         L.gnnlm_hgt_workspace_bytes.argtypes = [vp, vp]
         L.gnnlm_hgt_forward.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]

@@ -655,6 +655,7 @@ int gnnlm_adaptive_target_logp(const gnnlm_adaptive_softmax_t* w, const float* x
     return adaptive_impl(*w, x, ldx, target, n, lm_logp, workspace, workspace_bytes, (hipStream_t)stream);
 }
 int gnnlm_knn_interp(const gnnlm_knn_interp_t* d, void* stream) { GNNLM_DESC(d); return knn_interp(*d, (hipStream_t)stream); }
+size_t gnnlm_knn_interp_scratch_bytes(int64_t n, int32_t k, int64_t n_local) { return knn_interp_scratch_bytes(n, k, n_local); }
 int gnnlm_label_tags(const void* vals, int32_t vals_itemsize, int64_t n, uint8_t* tag, void* stream) { return label_tags(vals, vals_itemsize, n, tag, (hipStream_t)stream); }
 int gnnlm_topk_merge(const gnnlm_topk_t* d, void* stream) { GNNLM_DESC(d); return topk_merge(*d, (hipStream_t)stream); }
 int gnnlm_ivfpq_scan(const gnnlm_ivfpq_scan_t* d, void* stream) { GNNLM_DESC(d); return ivfpq_scan(*d, (hipStream_t)stream); }

@@ -151,6 +151,9 @@ int tail_combine(const float* tail_picked, const float* tail_lse, const int32_t*
 
 int knn_interp(const KnnInterpParams& p, hipStream_t stream);
 int label_tags(const void* vals, int itemsize, int64_t n, uint8_t* tag, hipStream_t stream);
+size_t knn_interp_scratch_bytes(int64_t n, int k, int64_t n_local);
+bool knn_interp_bucketed_eligible(const KnnInterpParams& p);
+int knn_interp_bucketed(const KnnInterpParams& p, float log_1ml, float log_l, hipStream_t stream);
 
 // sum of x[start[b] : ] per ... simple masked sum in double: out[0] += sum(x[i] * (mask?mask[i]:1))
 int masked_sum_f64(const float* x, const uint8_t* mask, int64_t n, double* out, hipStream_t stream);

@@ -491,6 +491,7 @@ int knn_interp(const KnnInterpParams& p, hipStream_t stream) {
     // coefficients are float32 roundings of the float64 logs, as in coeffs[0] = np.log(1 - coeff)
     ProfScope prof(K_KNN, stream, 0.0, (double)p.n * p.k * (12.0 + (p.knn_vals ? 4.0 : p.vals_itemsize)) + 16.0 * p.n);
     const float log_1ml = (float)log(1.0 - p.lmbda), log_l = (float)log(p.lmbda);
+    if (knn_interp_bucketed_eligible(p)) return knn_interp_bucketed(p, log_1ml, log_l, stream);      // routed look-ups (knn_bucket.hip)
     const dim3 grid((unsigned)cdiv(p.n, 4)), block(256);
     if (p.k <= 256) hipLaunchKernelGGL(knn_interp_regs_kernel<4>, grid, block, 0, stream, p, log_1ml, log_l);
     else if (p.k <= 1024) hipLaunchKernelGGL(knn_interp_regs_kernel<16>, grid, block, 0, stream, p, log_1ml, log_l);

@@ -298,9 +298,15 @@ def label_tags(vals, build=True):
     return tag
 
 
-def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_store=None, row0=0, knn_vals=None, vals_tag="auto"):
+_KNN_SCRATCH = {}                    # (device, stream) -> scratch of the routed look-ups (knn_bucket.hip)
+KNN_BUCKET_MIN_LOOKUPS = 1 << 20     # below this the one-pass kernel is as fast (three launches against one)
+
+
+def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_store=None, row0=0, knn_vals=None, vals_tag="auto",
+               bucketed="auto"):
     """``vals_tag``: "auto" = gather through the one-byte tag table (built on first use) when the label table is large and
-    k fits the register kernel; True / False force it on / off (tests, A/B)."""
+    k fits the register kernel; True / False force it on / off (tests, A/B).  ``bucketed``: "auto" = with the tag table and at
+    least 2^20 look-ups, route the look-ups region by region through the L2 (gnnlm_knn_interp_t.scratch); True / False force."""
     _dev(lm_logp, sims, ids, targets, vals, knn_vals)
     _f32(lm_logp, sims)
     _dtype(ids, torch.int64, "ids"), _dtype(targets, torch.int64, "targets")
@@ -324,9 +330,18 @@ def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_sto
         d.knn_vals = knn_vals.data_ptr()
     elif vals is not None and vals.dim() == 1 and vals.is_contiguous() and k <= 1024 and \
             (vals_tag is True or (vals_tag == "auto" and vals.shape[0] >= TAG_TABLE_MIN_ROWS)):
-        tag = label_tags(vals, build=not torch.cuda.is_current_stream_capturing())
+        capturing = torch.cuda.is_current_stream_capturing()
+        tag = label_tags(vals, build=not capturing)
         if tag is not None:
             d.vals_tag = tag.data_ptr()
+            if bucketed is True or (bucketed == "auto" and n * k >= KNN_BUCKET_MIN_LOOKUPS):
+                need = _lib.lib().gnnlm_knn_interp_scratch_bytes(n, k, vals.shape[0])
+                key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+                sc = _KNN_SCRATCH.get(key)
+                if (sc is None or sc.numel() < need) and not capturing and n <= (1 << 16) and vals.shape[0] <= (1 << 27):
+                    sc = _KNN_SCRATCH[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+                if sc is not None and sc.numel() >= need:
+                    d.scratch, d.scratch_bytes = sc.data_ptr(), sc.numel()
     d.n, d.k = n, k
     d.temperature, d.lmbda = temperature, lmbda
     d.out_logp, d.out_pknn, d.out_recall = out.data_ptr(), pk.data_ptr(), rec.data_ptr()

@@ -249,8 +249,15 @@ typedef struct gnnlm_knn_interp {
      * (knn_model.py:198) read this 4x smaller table and the 4-byte label only on a tag match (1 in 256 + the true hits):
      * same result bit for bit, a quarter of the table behind the random reads. */
     const uint8_t* vals_tag;
+    /* ABI 7, optional, with vals_tag: scratch of at least gnnlm_knn_interp_scratch_bytes(n, k, n_local) bytes (16-byte aligned,
+     * contents irrelevant).  The k look-ups of every token are then ROUTED: sorted by region of the tag table (<= 128 KB each) and
+     * looked up by one workgroup per region against the region's slice held in LDS, instead of costing one memory request each
+     * (the memory system serves ~48 G requests/s whatever their size: 8192 x 1024 one-by-one look-ups take 176 us).  Same result
+     * bit for bit (csrc/knn_bucket.hip).  Needs k <= 1024, n <= 2^16, n_local <= 2^27 (else the one-pass kernel runs). */
+    void* scratch;  size_t scratch_bytes;
 } gnnlm_knn_interp_t;
 int gnnlm_knn_interp(const gnnlm_knn_interp_t* desc, void* stream);
+size_t gnnlm_knn_interp_scratch_bytes(int64_t n, int32_t k, int64_t n_local);
 /* tag[r] = (uint32(vals[r]) * 2654435761) >> 24 for the n rows of a label table (int16 / int32) */
 int gnnlm_label_tags(const void* vals, int32_t vals_itemsize, int64_t n, uint8_t* tag, void* stream);
 

@@ -624,3 +624,49 @@ def test_knn_interp_tag_table(ops, dev):
         ref = ops.knn_interp(*a, 0.01, 0.25, vals=vals_d, vals_tag=False)
         got = ops.knn_interp(*a, 0.01, 0.25, vals=vals_d, vals_tag=True)
         assert all(torch.equal(x, y) for x, y in zip(ref, got))
+
+
+@pytest.mark.parametrize("case", ["uniform", "skewed", "shard_int16", "small_k"])
+def test_knn_interp_bucketed_lookups(ops, dev, case):
+    """The ROUTED label look-ups (csrc/knn_bucket.hip: sorted by region of the tag table, looked up per XCD through its L2, hit masks,
+    then the one-pass kernel's arithmetic) == the one-pass kernel, bit for bit: uniform ids, ids concentrated on a few rows and
+    regions (lists overflow their capacity: the overflow is looked up on the spot), a shard of a larger store with int16 labels,
+    k < 1024 with a ragged token count, -1 ids and rows outside the table."""
+    rs = np.random.RandomState({"uniform": 1, "skewed": 2, "shard_int16": 3, "small_k": 4}[case])
+    n, k, N, V, row0, n_store, dt = 1500, 1024, 3_000_000, 267744, 0, None, np.int32
+    if case == "shard_int16":
+        N, V, row0, n_store, dt = 2_500_000, 30000, 700_000, 4_000_000, np.int16
+    if case == "small_k":
+        n, k = 1031, 200
+    vals = rs.randint(0, V, size=N).astype(dt)
+    hi = n_store or N
+    if case == "skewed":                                                 # half of the look-ups go to 3000 rows of two regions
+        hot = np.concatenate([rs.randint(0, 2000, 1500), rs.randint(N - 2000, N, 1500)])
+        ids = np.where(rs.rand(n, k) < 0.5, hot[rs.randint(0, len(hot), size=(n, k))], rs.randint(0, N, size=(n, k))).astype(np.int64)
+    else:
+        ids = rs.randint(0, hi, size=(n, k)).astype(np.int64)
+    ids[::5, -3:] = -1
+    ids[7, 5] = hi + 12                                                  # not a row of the store
+    local = (np.where(ids < 0, ids + hi, ids) - row0)
+    inside = (local >= 0) & (local < N)
+    targets = rs.randint(0, V, size=n).astype(np.int64)
+    pick = np.where(inside.any(1), np.argmax(inside, 1), 0)
+    plant = rs.rand(n) < 0.6
+    for r in np.nonzero(plant & inside.any(1))[0]:
+        targets[r] = vals[local[r, pick[r]]]
+    sims = np.sort(rs.uniform(0.2, 0.9, size=(n, k)).astype(np.float32), axis=1)[:, ::-1].copy()
+    lm = np.log(rs.uniform(1e-4, 1, size=n)).astype(np.float32)
+    a = [torch.from_numpy(x).to(dev) for x in (lm, sims, ids, targets)]
+    vals_d = torch.from_numpy(vals).to(dev)
+    kw = dict(vals=vals_d, n_store=n_store, row0=row0)
+    for t, lmbda in ((0.01, 0.25), (1.0, 0.1)):
+        ref = ops.knn_interp(*a, t, lmbda, vals_tag=False, **kw)
+        got = ops.knn_interp(*a, t, lmbda, vals_tag=True, bucketed=True, **kw)
+        for x, y in zip(ref, got):
+            assert torch.equal(x, y), (case, t)
+        assert int(ref[2].sum()) > n // 4
+    # the oracle too (recall is an integer: exact)
+    if case == "uniform":
+        p_ref, rec_ref = oknn.knn_target_prob(sims, np.where(ids >= N, 0, ids), vals, targets, 1.0)
+        keep = (ids < N).all(1)
+        assert np.array_equal(got[2].cpu().numpy()[keep], rec_ref.numpy()[keep])

@@ -47,11 +47,14 @@ def main():
         return ts[len(ts) // 2], ts[0]
 
     ref = ops.knn_interp(lm, sims, ids, tg, 0.01, 0.25, vals=vals, vals_tag=False)
-    tag = ops.knn_interp(lm, sims, ids, tg, 0.01, 0.25, vals=vals, vals_tag=True)
+    tag = ops.knn_interp(lm, sims, ids, tg, 0.01, 0.25, vals=vals, vals_tag=True, bucketed=False)
     assert all(torch.equal(x, y) for x, y in zip(ref, tag)), "tag path differs"
+    rt = ops.knn_interp(lm, sims, ids, tg, 0.01, 0.25, vals=vals, vals_tag=True, bucketed=True)
+    assert all(torch.equal(x, y) for x, y in zip(ref, rt)), "routed path differs"
     for flush in (True, False):
         for name, f in (("4-byte label gather", lambda: ops.knn_interp(lm, sims, ids, tg, 0.01, 0.25, vals=vals, vals_tag=False)),
-                        ("1-byte tag gather  ", lambda: ops.knn_interp(lm, sims, ids, tg, 0.01, 0.25, vals=vals, vals_tag=True)),
+                        ("1-byte tag gather  ", lambda: ops.knn_interp(lm, sims, ids, tg, 0.01, 0.25, vals=vals, vals_tag=True, bucketed=False)),
+                        ("routed look-ups    ", lambda: ops.knn_interp(lm, sims, ids, tg, 0.01, 0.25, vals=vals, vals_tag=True, bucketed=True)),
                         ("labels delivered   ", lambda: ops.knn_interp(lm, sims, ids, tg, 0.01, 0.25, knn_vals=kv))):
             med, mn = timeit(f, flush)
             print(f"{name} caches {'flushed' if flush else 'warm   '}: median {med:7.1f} us  min {mn:7.1f} us   "
