@@ -1,3 +1,5 @@
+"""The routed label look-ups of the ids-only kNN interpolation (csrc/knn_bucket.hip) at the bench's shape, per call, by the library's own event
+profiler; `GNNLM_LIB=<variant>.so` times an A/B build (tools/build_variant.sh kbN knn_bucket.hip -DGNNLM_KB_EXP=N / -DGNNLM_KB_TILE=T)."""
 import sys, os, csv, glob
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
