@@ -11,9 +11,12 @@
 //     so that   score(q, x) = bias + sum_m L[m][code_m(x)]  <  bias + sum_lo + (sum_m u + M) delta + eps  =: UB(x);
 //   * EIGHT queries that probe the same list share a workgroup; the LDS table entry of (sub-quantizer, code) is the 8
 //     queries' bytes, so one ds_read_b64 serves 8 (query, key) pairs (LDS: 128 KiB of tables);
-//   * the sums over the 64 sub-quantizers are taken by v_mfma_i32_16x16x64_i8: a lane's two look-ups ARE its 16-byte A
-//     operand (row = key, k = (look-up, query)), B is the constant selector B[(look-up, query)][j] = [query == j]: one MFMA
-//     adds 16 keys x 8 sub-quantizers x 8 queries -- the integer sums are exact, the matrix core is the adder;
+//   * the sums over the 64 sub-quantizers are taken by the matrix core: a lane's four look-ups ARE the 32-byte dense operand
+//     of v_smfmac_i32_16x16x128_i8 (column = key, k = (look-up, query)), the other operand is the constant selector
+//     S[query m][(look-up, query')] = [query' == m] -- two non-zeros in every four along k at most, i.e. exactly what the
+//     2:4-SPARSE operand format holds: one instruction adds 16 keys x 16 sub-quantizers x 8 queries in the 16 busy cycles
+//     the dense v_mfma_i32_16x16x64_i8 of round 3 took for half of that (PMC: SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA = 16.0
+//     for both).  The integer sums are exact, the matrix core is the adder;
 //   * a key survives for query j iff its integer sum reaches T_j = the integer image of the query's threshold tau (its
 //     k-th best exact score after the dense round): UB(x) <= tau  =>  score(x) <= tau, so no key of the exact
 //     one-pass scan (score > tau) is lost; survivors (row, list) are staged in LDS and appended to the query's list;
@@ -31,11 +34,15 @@ namespace gnnlm {
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr int QG = 8;                                   // queries per workgroup
 constexpr int TAB_BYTES = 2 * 256 * 32 * QG;            // [half][code][slot][query]: 128 KiB
-constexpr int WAVE_CAP = 320;                           // survivors a wave stages per task (all 8 queries of its group)
+#ifndef GNNLM_IVF8_WAVE_CAP
+#define GNNLM_IVF8_WAVE_CAP 320
+#endif
+constexpr int WAVE_CAP = GNNLM_IVF8_WAVE_CAP;                           // survivors a wave stages per task (all 8 queries of its group)
 constexpr int SCAN_LDS = TAB_BYTES + 512 + 16 * WAVE_CAP * 4;
 constexpr int HIST_BINS = 1024, HIST_SHIFT = 4;         // threshold pass: sum_u (0 .. 16320) >> 4
 constexpr int SUMS_LDS = TAB_BYTES + QG * HIST_BINS * 4;  // = 160 KiB: the whole LDS of a CU
@@ -188,15 +195,18 @@ __global__ __launch_bounds__(256) void groups_scatter_kernel(const int64_t* __re
 #define GNNLM_IVF8_NW 16         // waves per workgroup of the scan (A/B: 8)
 #endif
 constexpr int NW = GNNLM_IVF8_NW, NTH = 64 * NW;
-#ifndef GNNLM_IVF8_ORDER
-#define GNNLM_IVF8_ORDER 1      // 1: the next tile's look-ups interleaved with this tile's MFMAs (8.8 ms); 0: look-ups first (11.0 ms)
-#endif
 #ifndef GNNLM_IVF8_PF
-#define GNNLM_IVF8_PF 3         // tiles of code bytes in flight per wave (A/B: 4)
+#define GNNLM_IVF8_PF 3         // tiles of code bytes in flight per wave of the filter = steps per block of the loop (every register name is static).
+                                // A/B with exact waits, medians of 7 searches: 3: 8.17 ms, 4: 9.06, 6: 8.82, 8: 9.21 -- depth buys nothing, the steps past
+                                // the end of a list (up to PF - 1 per wave and group) cost
+#endif
+#ifndef GNNLM_IVF8_PF_SUMS
+#define GNNLM_IVF8_PF_SUMS 3    // ... of the threshold pass
 #endif
 #ifndef GNNLM_IVF8_EXP
-#define GNNLM_IVF8_EXP 0        // ablation builds (no survivors): 1 no code loads, 2 no table fill, 4 no look-ups, 8 no MFMAs, 16 nothing else
-#endif
+#define GNNLM_IVF8_EXP 0        // ablation / instrumented builds: 1 no code loads, 2 no table fill, 4 no look-ups, 8 no matrix instructions, 32 nothing survives,
+#endif                          // 64 no staging writes, 128 the staging count stays 0, 256 always the same four tiles; 512 phase times, 1024 the waves' exit times
+                                // (into the spare words of work_ctr: tools/ivf8_phases.py, tools/ivf8_waves.py)
 
 // SUMS = false: the filter (survivors of the integer threshold).  SUMS = true: the threshold pass -- the integer sums sum_u of a
 // list's keys are HISTOGRAMMED per query in LDS (bins of 16, atomics without return) and the (query, list) histogram is written
@@ -217,11 +227,25 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     bool first = true;
     int gi = (int)(blockIdx.x >> 3);
     int* next_s = reinterpret_cast<int*>(smem + TAB_BYTES);                   // (free between two groups)
+#if GNNLM_IVF8_EXP & 512
+    // instrumented build: thread 0's time per phase (group set-up + table fill | tile loop | end of the group) into the spare words of work_ctr
+    long long stamp = clock64();
+    const long long k0 = stamp, w0 = wall_clock64();
+    auto phase = [&](int ph) { const long long t = clock64(); if (tid == 0 && p.work_ctr) atomicAdd(&p.work_ctr[(blockIdx.x & 7) * 16 + 1 + ph], (int)(t - stamp)); stamp = t; };
+    // ... and inside the steps of wave 8 (the third of its SIMD): accumulated in registers, added at the end of the group
+    long long st2 = 0; int acc_t[4] = {0, 0, 0, 0};
+    auto tick = [&](int ph) { if (wave == 8) { const long long t = clock64(); if (ph >= 0) acc_t[ph] += (int)(t - st2); st2 = t; } };
+#else
+    auto phase = [&](int) {};
+    auto tick = [&](int) {};
+#endif
+    int nxt = 0;                                                             // (thread 0) the counter's value for the group after this one
     for (;;) {
+    phase(2);
     if (!first) {
         __syncthreads();                                                     // the previous group's tables, totals and histograms are done with
         if (p.work_ctr) {
-            if (tid == 0) *next_s = (int)(gridDim.x >> 3) + atomicAdd(&p.work_ctr[(blockIdx.x & 7) * 16], 1);
+            if (tid == 0) *next_s = (int)(gridDim.x >> 3) + nxt;
             __syncthreads();
             gi = *next_s;
             __syncthreads();
@@ -231,6 +255,9 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     if (gi >= per_xcd) break;
     const int grp = (int)(blockIdx.x & 7) * per_xcd + gi;
     if (grp >= n_groups) break;
+    // the NEXT group's index is asked for now and read at the end of this group: the atomic's round trip (and nothing but it) used to
+    // stand between two groups, 135 times per workgroup
+    if (tid == 0 && p.work_ctr) nxt = atomicAdd(&p.work_ctr[(blockIdx.x & 7) * 16], 1);
     const int list = p.grp_list[grp];
     if (list < 0) continue;
     const int64_t lo = p.list_off[list], hi = p.list_off[list + 1];
@@ -285,26 +312,43 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         }
     }
 #endif
-    // ---- integer thresholds: lane column j = lane % 16 (the D layout of the MFMA: D[key 4 g + r][query j])
     const int j = lane & 15, g = lane >> 4;
-    int T = 0x7fffffff;
-    const int qj = j < QG ? gq[j] : -1;                                   // (a register array may not be indexed by the lane)
     const int qs_lane = lane < QG ? gq[lane] : -1;                           // lanes 0..7: the query of slot `lane` (flush of the survivors)
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem + TAB_BYTES);          // SUMS: [8 queries][HIST_BINS] counters
-    uint32_t* hist_j = nullptr;                                              // this lane's query (lanes j < 8 of a live query)
+    if (SUMS) for (int e = tid; e < QG * HIST_BINS; e += NTH) hist[e] = 0u;
+    // ---- the D layout of the sparse instruction: D[query 4 g + r][key j] in register r of lane (g, j) -- lanes 0..31 hold the 8 queries
+    // of the group for the 16 keys of a tile, lanes 32..63 the unused rows 8..15 of the selector.  Integer thresholds per register
+    // (clamped to +-16384: a sum lies in [-8192, 8128], so the test is the same and sum - T cannot overflow)
+    constexpr int T_NEVER = 16384;
+    int T4[4] = {T_NEVER, T_NEVER, T_NEVER, T_NEVER};
+    // SUMS: lane (g, j) counts two queries of key j: g < 2 its own registers 0, 1 (queries 4 g, 4 g + 1), g >= 2 the registers 2, 3 of
+    // lane (g - 2, j), which arrive by v_permlane32_swap (queries 4 (g - 2) + 2, + 3): two atomics per lane on all 64 lanes
+    // (odd keys count their two queries in the other order: every atomic instruction then spreads over all 8 histograms, 8 lanes each --
+    // counters of one address serialise)
+    uint32_t *hist_a = nullptr, *hist_b = nullptr;
     if (SUMS) {
-        for (int e = tid; e < QG * HIST_BINS; e += NTH) hist[e] = 0u;
-        // lanes j >= 8 hold nothing of their own (the MFMA's columns 8 .. 15): they count HALF of the keys of lane j - 8
-        const int jq = j & 7, qjq = gq[jq];
-        if (qjq >= 0 && p.grp_out[(int64_t)grp * QG + jq] >= 0) hist_j = hist + jq * HIST_BINS;
+        const int q0 = 4 * (g & 1) + (g >= 2 ? 2 : 0) + (j & 1), q1 = q0 ^ 1;
+        if (gq[q0] >= 0 && p.grp_out[(int64_t)grp * QG + q0] >= 0) hist_a = hist + q0 * HIST_BINS;
+        if (gq[q1] >= 0 && p.grp_out[(int64_t)grp * QG + q1] >= 0) hist_b = hist + q1 * HIST_BINS;
+    } else if (g < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qr = gq[4 * g + r];
+            if (qr >= 0) T4[r] = max(-T_NEVER, min(T_NEVER, filter_threshold(p.qmeta, qr, p.coarse[(int64_t)qr * p.ld_coarse + list], p.tau[qr])));
+        }
     }
-    if (!SUMS && qj >= 0) T = filter_threshold(p.qmeta, qj, p.coarse[(int64_t)qj * p.ld_coarse + list], p.tau[qj]);
 #if GNNLM_IVF8_EXP & 32
-    if (p.cap > 0) T = 0x7fffffff;                   // nothing survives, but the compiler cannot know: every instruction stays
-#elif GNNLM_IVF8_EXP
-    T = 0x7fffffff;                                  // ablation builds time the main loop: nothing survives
+    if (p.cap > 0) T4[0] = T4[1] = T4[2] = T4[3] = T_NEVER;          // nothing survives, but the compiler cannot know: every instruction stays
+#elif GNNLM_IVF8_EXP & 255
+    T4[0] = T4[1] = T4[2] = T4[3] = T_NEVER;                         // ablation builds time the main loop: nothing survives
 #endif
+    // the accumulators start at -T: register r then holds the key's EXCESS over query 4 g + r's threshold, a survivor is a non-negative one
+    const v4i negT = SUMS ? v4i{0, 0, 0, 0} : v4i{-T4[0], -T4[1], -T4[2], -T4[3]};
     __syncthreads();                                                       // the tables are in place
+    phase(0);
+#if GNNLM_IVF8_EXP & 1024
+    const long long g0 = clock64();
+#endif
 
     // ---- look-up constants of the lane: slot byte offsets of look-ups 2 s / 2 s + 1 and the table half in byte 2
     uint32_t tc[8];
@@ -313,8 +357,24 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         const uint32_t s0 = (uint32_t)(16 * (g & 1) + ((j + 2 * s) & 15)) << 3, s1 = (uint32_t)(16 * (g & 1) + ((j + 2 * s + 1) & 15)) << 3;
         tc[s] = s0 | s1 << 8 | (uint32_t)(g >> 1) << 16;
     }
-    const uint32_t b0 = j < 4 ? 1u << (8 * j) : 0u, b1 = (j >= 4 && j < 8) ? 1u << (8 * (j - 4)) : 0u;
-    const v4i Bc = {(int)b0, (int)b1, (int)b0, (int)b1};                    // B[(look-up, query)][j] = [query == j]
+    // The selector S[query m][(look-up, query')] = [query' == m] as the SPARSE operand of v_smfmac_i32_16x16x128_i8 (2 kept values out of every
+    // 4 along k; layout measured with tools/probes/smfmac_layout.hip): lane (kb, m) holds 16 kept bytes -- bytes 8 h .. 8 h + 7 meet a 16-byte
+    // stretch of the dense operand (two look-ups of 8 query bytes), kept byte s its group of four bytes 4 (s / 2) .. + 3 at the position the
+    // index register names (2 bits per kept byte).  Row m < 8 keeps a 1 at query byte m of both look-ups of each stretch, rows 8 .. 15 nothing.
+    uint32_t sel[4] = {0u, 0u, 0u, 0u}, sidx = 0xccccccccu;                  // pairs default to positions (0, 3)
+    if (j < QG) {
+        const int pos = j & 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int lk = 0; lk < 2; ++lk) {
+                const int s0 = 8 * h + 2 * (2 * lk + (j >> 2));               // the kept pair of the group that holds byte m of look-up lk
+                const int sb = pos < 3 ? s0 : s0 + 1;                        // (position 3 goes to the pair's second byte, whose index is 3 already)
+                sel[sb >> 2] |= 1u << (8 * (sb & 3));
+                if (pos < 3) sidx = (sidx & ~(3u << (2 * s0))) | (uint32_t)pos << (2 * s0);
+            }
+    }
+    const v4i Asel = {(int)sel[0], (int)sel[1], (int)sel[2], (int)sel[3]};
 
     // ---- the list's tiles: wave w takes tiles w, w + 16, ... two per step.  Everything that steers the loop is scalar (the wave
     // index through readfirstlane), the code bytes come by buffer loads off one resource over the list's tile range (lane
@@ -334,21 +394,21 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane(u * 1024), 0);   // (u is wave-uniform: tell the compiler)
 #endif
     };
-    // 16 look-ups of one tile: address = {0, half, code byte, slot offset} by one v_perm_b32 each
-    auto lookups = [&](const v4u& cw, v4i (&A)[8]) {
+    // look-ups 4 q .. 4 q + 3 of one tile (= the 32-byte dense operand of one matrix instruction): address = {0, half, code byte, slot
+    // offset} by one v_perm_b32 each
+    auto lookups4 = [&](const v4u& cw, int q, v8i& X) __attribute__((always_inline)) {
         const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int p0 = 2 * s, p1 = 2 * s + 1;
-            const uint32_t a0 = GNNLM_PERM(w[p0 >> 2], tc[s], 0x0c020000u | (uint32_t)(4 + (p0 & 3)) << 8 | 0u);
-            const uint32_t a1 = GNNLM_PERM(w[p1 >> 2], tc[s], 0x0c020000u | (uint32_t)(4 + (p1 & 3)) << 8 | 1u);
+        for (int e = 0; e < 4; ++e) {
+            const int pp = 4 * q + e;                                        // look-up pp: byte pp of the lane's 16 code bytes
+            const uint32_t ad = GNNLM_PERM(w[pp >> 2], tc[pp >> 1], 0x0c020000u | (uint32_t)(4 + (pp & 3)) << 8 | (uint32_t)(pp & 1));
 #if GNNLM_IVF8_EXP & 4
-            const u32x2 x0 = u32x2{a0, a1}, x1 = u32x2{a1, a0};
+            const u32x2 x = u32x2{ad, ad ^ 0x55u};
 #else
-            const u32x2 x0 = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(a0);
-            const u32x2 x1 = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(a1);
+            const u32x2 x = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(ad);
 #endif
-            A[s] = v4i{(int)x0.x, (int)x0.y, (int)x1.x, (int)x1.y};
+            X[2 * e] = (int)x.x;
+            X[2 * e + 1] = (int)x.y;
         }
     };
     // Survivors of one tile.  A wave stages its survivors in its OWN LDS region, {row - lo, query slot} packed in a dword, at
@@ -380,7 +440,7 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
 #pragma unroll
         for (int sl = 0; sl < QG; ++sl) {
             const int base = __builtin_amdgcn_readlane(basev, sl), qsl = __builtin_amdgcn_readlane(qs_lane, sl);
-            const int Tsl = __builtin_amdgcn_readlane(T, sl);                  // lane sl holds query slot sl's integer threshold (j = lane)
+            const int Tsl = __builtin_amdgcn_readlane(T4[sl & 3], 16 * (sl >> 2));   // lanes (g, .) hold the thresholds of slots 4 g .. 4 g + 3
             if (qsl < 0) continue;
             int run = 0;
 #pragma unroll
@@ -416,124 +476,96 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     // entry = excess << 22 | local row << 3 | query slot: `excess` = how far the key's integer sum lies above the query's integer
     // threshold (clamped to 1023) -- ivfpq_refine_kernel turns it into a lower bound of the key's score (SURV_ROW_BITS = 19: lists
     // of up to 524,287 rows; the launcher checks)
-    auto append = [&](uint64_t m, bool mine, int local_row, int sum) {       // m: the wave's mask, mine: this lane's bit
+    // (excess: the register's value; rowslot: local row << 3 | query slot of the register)
+    auto append = [&](uint64_t m, bool mine, int excess, uint32_t rowslot) {   // m: the wave's mask, mine: this lane's bit
         if (m == 0ull) return;
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 #if !(GNNLM_IVF8_EXP & 64)
-        if (mine) wbuf[wcnt + rank] = (uint32_t)min(sum - T, SURV_EXCESS_MAX) << (SURV_ROW_BITS + 3) | (uint32_t)local_row << 3 | (uint32_t)(j & 7);
+        if (mine) wbuf[wcnt + rank] = (uint32_t)min(excess, SURV_EXCESS_MAX) << (SURV_ROW_BITS + 3) | rowslot;
 #endif
         wcnt = __builtin_amdgcn_readfirstlane(wcnt + __builtin_popcountll(m));   // (scalar: the compiler's divergence analysis gives up on it)
 #if GNNLM_IVF8_EXP & 128
         wcnt = 0;
 #endif
     };
-    const int g4 = 4 * g;
-    // Software pipeline, one tile per step: the 8 MFMAs of tile i are issued interleaved with the 16 look-ups of tile i + 1
-    // (address + read pairs between the matrix instructions), the code bytes of tile i + 3 are requested at the top of the
-    // step.  Look-up results alternate between two register sets, code bytes rotate through three: the loop is unrolled six
-    // times so that every name is static.
-    auto step = [&](v4i (&Xc)[8], v4i (&Xn)[8], const v4u& cn, v4u& cl, int u) {
-        cl = load_tile(u + GNNLM_IVF8_PF * NW);
-        lookups(cn, Xn);
-        v4i acc = {0, 0, 0, 0};
+    // Software pipeline at the grain of ONE matrix instruction: the four look-ups behind instruction q of tile i + 1 are issued right after
+    // instruction q of tile i has read the same registers (one set of 32 look-up registers per lane; a second set, the next tile's look-ups
+    // all issued ahead of this tile's instructions, measured the same: 8.35 against 8.17 ms).  The code bytes of tile i + PF are requested at
+    // the top of step i into the registers tile i's bytes leave; the loop is unrolled PF times so that every name is static.
+    constexpr int PF = SUMS ? GNNLM_IVF8_PF_SUMS : GNNLM_IVF8_PF;
+    v8i X[4];
+    auto step = [&](const v4u& cn, v4u& cl, int u) __attribute__((always_inline)) {
+        tick(-1);
+        cl = load_tile(u + PF * NW);
+        v4i acc = negT;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int q = 0; q < 4; ++q) {
 #if GNNLM_IVF8_EXP & 8
-            acc += Xc[s];
+            acc += v4i{X[q][0], X[q][1], X[q][2], X[q][3]} + v4i{X[q][4], X[q][5], X[q][6], X[q][7]};
 #else
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(Xc[s], Bc, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_smfmac_i32_16x16x128_i8(Asel, X[q], acc, (int)sidx, 0, 0);
 #endif
+            lookups4(cn, q, X[q]);
+            // nothing crosses: left alone, the scheduler deals the 16 reads out look-up-major (by address register), every quarter is then
+            // complete only when nearly all 16 reads are, and the first matrix instruction of the next step waits for a drained queue
+            __builtin_amdgcn_sched_barrier(0);
         }
-#if !(GNNLM_IVF8_EXP & 12)
-#if GNNLM_IVF8_ORDER == 0
-        // the next tile's 16 look-ups first (address + read pairs), then this tile's 8 matrix instructions: every read has the
-        // whole MFMA chain and the test behind it to come back before the next step needs it
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#else
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one matrix instruction of this tile,
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);               // two look-up addresses and
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);               // their two reads of the next tile
-        }
-#endif
-#endif
+        tick(0);
+        const int row = 16 * u + j - row_shift;                              // the lane's key (local row of the list)
+        const bool edge = u == 0 || u >= nt - 1;                             // the two edge tiles share rows with the neighbouring lists (and beyond: nothing)
         if (SUMS) {
-            // the lane's four keys (rows 4 g .. 4 g + 3 of the tile) of query j -> four counters of the query's histogram (LDS
-            // atomics without return: nothing waits for them); the two edge tiles count the list's own rows only
-            // keys 2, 3 of lane (g, j) move to lane (g, j + 8) (row_shr:8 inside the row of 16 lanes): two atomics per lane on all
-            // 64 lanes instead of four on half of them
-            const int b2 = __builtin_amdgcn_update_dpp(0, acc[2], 0x118, 0xf, 0xf, false);
-            const int b3 = __builtin_amdgcn_update_dpp(0, acc[3], 0x118, 0xf, 0xf, false);
-            if (hist_j) {
-                const bool up = j >= 8;
-                const int s0 = up ? b2 : acc[0], s1 = up ? b3 : acc[1];
-                const int r0 = 16 * u + 4 * g + (up ? 2 : 0) - row_shift;
-                const bool edge = u == 0 || u == nt - 1;
-                if (!edge || (unsigned)r0 < (unsigned)len) atomicAdd(&hist_j[(s0 + 128 * 64) >> HIST_SHIFT], 1u);
-                if (!edge || (unsigned)(r0 + 1) < (unsigned)len) atomicAdd(&hist_j[(s1 + 128 * 64) >> HIST_SHIFT], 1u);
+            // (LDS atomics without return: nothing waits for them)
+            const gnnlm_u32x2 w2 = __builtin_amdgcn_permlane32_swap((uint32_t)acc[2], (uint32_t)acc[2], false, false);
+            const gnnlm_u32x2 w3 = __builtin_amdgcn_permlane32_swap((uint32_t)acc[3], (uint32_t)acc[3], false, false);
+            const int e0 = g >= 2 ? (int)w2.x : acc[0], e1 = g >= 2 ? (int)w3.x : acc[1];
+            const int s0 = (j & 1) ? e1 : e0, s1 = (j & 1) ? e0 : e1;
+            if (!edge || (unsigned)row < (unsigned)len) {
+                if (hist_a) atomicAdd(&hist_a[(s0 + 128 * 64) >> HIST_SHIFT], 1u);
+                if (hist_b) atomicAdd(&hist_b[(s1 + 128 * 64) >> HIST_SHIFT], 1u);
             }
         } else {
-            // four compares straight into scalar masks; a tile with survivors (about every second one) appends them mask by mask.
-            // The two edge tiles of the list share rows with the neighbouring lists: they take the same steps with the range test
-            const int rb = 16 * u - row_shift + g4;                          // local row of the lane's first key
-            if (wcnt + 128 > WAVE_CAP) flush_wave();                         // a tile adds at most 4 x 32 entries (8 query columns x 4 lane groups)
-            if (u == 0 || u == nt - 1) {
+            // four compares straight into scalar masks; a tile with survivors (about every second one) appends them mask by mask
+            if (wcnt + 128 > WAVE_CAP) flush_wave();                         // a tile adds at most 4 x 32 entries (8 queries x 16 keys)
+            tick(1);
+            const uint32_t rs0 = (uint32_t)row << 3 | (uint32_t)(4 * (g & 1));   // (slot 4 (g & 1) + r: r goes into the two zero bits)
+            if (edge) {
+                const bool in = (unsigned)row < (unsigned)len;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool sr = acc[r] >= T && (unsigned)(rb + r) < (unsigned)len;
-                    append(__builtin_amdgcn_ballot_w64(sr), sr, rb + r, acc[r]);
+                    const bool sr = acc[r] >= 0 && in;
+                    append(__builtin_amdgcn_ballot_w64(sr), sr, acc[r], rs0 | r);
                 }
             } else {
-                const uint64_t m0 = __builtin_amdgcn_ballot_w64(acc[0] >= T), m1 = __builtin_amdgcn_ballot_w64(acc[1] >= T),
-                               m2 = __builtin_amdgcn_ballot_w64(acc[2] >= T), m3 = __builtin_amdgcn_ballot_w64(acc[3] >= T);
+                const uint64_t m0 = __builtin_amdgcn_ballot_w64(acc[0] >= 0), m1 = __builtin_amdgcn_ballot_w64(acc[1] >= 0),
+                               m2 = __builtin_amdgcn_ballot_w64(acc[2] >= 0), m3 = __builtin_amdgcn_ballot_w64(acc[3] >= 0);
                 if ((m0 | m1 | m2 | m3) != 0ull) {
-                    append(m0, acc[0] >= T, rb + 0, acc[0]);
-                    append(m1, acc[1] >= T, rb + 1, acc[1]);
-                    append(m2, acc[2] >= T, rb + 2, acc[2]);
-                    append(m3, acc[3] >= T, rb + 3, acc[3]);
+                    append(m0, acc[0] >= 0, acc[0], rs0 | 0u);
+                    append(m1, acc[1] >= 0, acc[1], rs0 | 1u);
+                    append(m2, acc[2] >= 0, acc[2], rs0 | 2u);
+                    append(m3, acc[3] >= 0, acc[3], rs0 | 3u);
                 }
             }
+            tick(2);
         }
     };
     {
         int u = wv;
-        v4i XA[8], XB[8];
-        v4u C0 = load_tile(u), C1 = load_tile(u + NW), C2 = load_tile(u + 2 * NW);   // (loads beyond the list's tiles return zeros)
-#if GNNLM_IVF8_PF == 4
-        v4u C3 = load_tile(u + 3 * NW);
-#endif
-        lookups(C0, XA);
-        while (true) {
-#if GNNLM_IVF8_PF == 4
-            if (u >= nt) break;
-            step(XA, XB, C1, C0, u); u += NW;
-            if (u >= nt) break;
-            step(XB, XA, C2, C1, u); u += NW;
-            if (u >= nt) break;
-            step(XA, XB, C3, C2, u); u += NW;
-            if (u >= nt) break;
-            step(XB, XA, C0, C3, u); u += NW;
-#else
-            if (u >= nt) break;
-            step(XA, XB, C1, C0, u); u += NW;
-            if (u >= nt) break;
-            step(XB, XA, C2, C1, u); u += NW;
-            if (u >= nt) break;
-            step(XA, XB, C0, C2, u); u += NW;
-            if (u >= nt) break;
-            step(XB, XA, C1, C0, u); u += NW;
-            if (u >= nt) break;
-            step(XA, XB, C2, C1, u); u += NW;
-            if (u >= nt) break;
-            step(XB, XA, C0, C2, u); u += NW;
-#endif
+        v4u C[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) C[i] = load_tile(u + i * NW);             // (loads beyond the list's tiles return zeros)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lookups4(C[0], q, X[q]);
+        // The loop is left only between two blocks of PF steps and every step of a block RUNS -- a step beyond the list's tiles reads zeros (the
+        // buffer's range check) and takes the edge tiles' path, where its rows fail the range test.  With an exit or a skipped step inside the
+        // block the compiler's s_waitcnt insertion merges paths with different loads in flight and falls back to waiting for (nearly) all of
+        // them: `vmcnt(1)` with seven tiles in flight, once per block -- the waves stood at the code loads 17 % of their time (PMC).
+#define GNNLM_IVF8_STEP(t) if constexpr (PF > (t)) { step(C[((t) + 1) % PF], C[(t)], u); u += NW; }
+        while (u < nt) {
+            GNNLM_IVF8_STEP(0) GNNLM_IVF8_STEP(1) GNNLM_IVF8_STEP(2) GNNLM_IVF8_STEP(3)
+            GNNLM_IVF8_STEP(4) GNNLM_IVF8_STEP(5) GNNLM_IVF8_STEP(6) GNNLM_IVF8_STEP(7)
         }
+#undef GNNLM_IVF8_STEP
+        static_assert(PF >= 3 && PF <= 8, "GNNLM_IVF8_PF");
     }
     if (SUMS) {
         __syncthreads();
@@ -550,7 +582,9 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     int* wtot = reinterpret_cast<int*>(smem + TAB_BYTES);                     // [16 waves][8 slots] totals, then first positions
     const int mytot = slot_totals();
     if (lane < QG) wtot[wave * QG + lane] = mytot;
+    phase(3);
     __syncthreads();
+    phase(4);
     if (tid < QG) {
         int tot = 0;
         for (int w = 0; w < NW; ++w) tot += wtot[w * QG + tid];
@@ -558,8 +592,15 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         for (int w = 0; w < NW; ++w) { const int t = wtot[w * QG + tid]; wtot[w * QG + tid] = at; at += t; }
     }
     __syncthreads();
+    phase(5);
     write_entries(lane < QG ? wtot[wave * QG + lane] : 0);
     }
+#if GNNLM_IVF8_EXP & 512
+    if (tid == 0 && p.work_ctr) {
+        atomicAdd(&p.work_ctr[(blockIdx.x & 7) * 16 + 12], (int)((clock64() - k0) >> 4));
+        atomicAdd(&p.work_ctr[(blockIdx.x & 7) * 16 + 13], (int)(wall_clock64() - w0));
+    }
+#endif
 }
 
 // Threshold from the histograms of a query's D dense lists (written by the SUMS pass): a LOWER bound of its k-th best exact

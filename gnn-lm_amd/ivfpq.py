@@ -499,6 +499,8 @@ class IVFPQIndex:
         d.grp_list, d.grp_q, d.n_groups, d.max_groups = groups[0].data_ptr(), groups[1].data_ptr(), groups[2].data_ptr(), groups[3]
         ctr = torch.zeros(8, 16, device=self.device, dtype=torch.int32)          # the persistent workgroups' work counters (one per XCD)
         d.work_ctr = ctr.data_ptr()
+        if getattr(self, "keep_work_ctr", False):                              # instrumented builds (GNNLM_IVF8_EXP & 512) leave phase times here
+            self.last_work_ctr = ctr
         if hist is not None:
             d.out_hist, d.grp_out = hist.data_ptr(), groups[4].data_ptr()
         else:

@@ -26,3 +26,15 @@ if __name__ == "__main__":
     print(f"IVF-PQ search: {n} queries, k={k}, nprobe={idx.nprobe}, N={N}: {dt * 1e3:.1f} ms = {n / dt:.0f} queries/s")
     for kn, e in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
         print(f"   {kn:24s} {e['launches']:4d} launches {e['total_ms']:9.2f} ms")
+    reps = int(os.environ.get("REPS", 0))                 # A/B runs: medians over REPS more searches
+    if reps:
+        import statistics
+        per = {}
+        tot = []
+        for _ in range(reps):
+            _lib.profile_begin()
+            t0 = time.perf_counter(); idx.search_device(q, k); torch.cuda.synchronize(); tot.append((time.perf_counter() - t0) * 1e3)
+            for kn, e in _lib.profile_end().items():
+                per.setdefault(kn, []).append(e["total_ms"])
+        print(f"medians of {reps}: search {statistics.median(tot):.2f} ms; " + ", ".join(
+            f"{kn} {statistics.median(v):.2f}" for kn, v in sorted(per.items(), key=lambda kv: -statistics.median(kv[1]))[:4]))
