@@ -837,14 +837,24 @@ __global__ __launch_bounds__(GNNLM_REFINE_NT) void ivfpq_refine_kernel(gnnlm_ivf
 // Exact float32 scores of the survivors, in the summation order of the f32 scan (ivfpq.hip scan_rot: look-up s of half h
 // goes to sub-quantizer 32 h + (row + s) % 32, even look-ups into one chain, odd ones into the other, halves in order,
 // score = bias + (chain0 + chain1)).  One workgroup per query, its table in LDS.
+#ifndef GNNLM_RESCORE_NT
+#define GNNLM_RESCORE_NT 1024   // threads per query (A/B, medians of 7: 1024: 1.14 ms, 512: 1.13, 256 with two workgroups per CU: 1.34)
+#endif
 template <int M>
-__global__ __launch_bounds__(1024) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore_t p) {
+__global__ __launch_bounds__(GNNLM_RESCORE_NT) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore_t p) {
     extern __shared__ __attribute__((aligned(16))) float rtab[];            // [M][256] f32, then the threads' code rows [M / 4 dwords][NT]
     __shared__ int ccnt;
-    constexpr int NT = 1024;                                                // 16 waves: the survivors' code rows are random 64-B reads
+    constexpr int NT = GNNLM_RESCORE_NT;                                    // 16 waves: the survivors' code rows are random 64-B reads
     uint32_t* cdw = reinterpret_cast<uint32_t*>(rtab + M * 256);            // dword k of thread t at [k][t]: bank = t mod 32 for stores and byte reads alike
     const int tid = threadIdx.x;
     const int64_t q = blockIdx.x;
+#ifdef GNNLM_RESCORE_DBG
+    // instrumented build (tools/rescore_phases.py): thread 0's clock64 deltas per phase in the last 8 slots of the query's candidate row
+    long long dbg_t = clock64(); int dbg_i = 0;
+    auto dbg = [&]() { const long long t = clock64(); if (tid == 0) reinterpret_cast<int*>(p.cand_val + (q + 1) * p.cand_cap - 8)[dbg_i] = (int)(t - dbg_t); ++dbg_i; dbg_t = t; };
+#else
+    auto dbg = [&]() {};
+#endif
     const int n = min(p.surv_cnt[q * SURV_CNT_STRIDE], p.cap);
     if (tid == 0) ccnt = 0;
     const uint2* surv = reinterpret_cast<const uint2*>(p.surv) + q * p.cap;
@@ -879,7 +889,9 @@ __global__ __launch_bounds__(1024) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore
         rowload(r1, cr1, bias1);
         rid1 = r1.x;
     }
+    dbg();                                                                   // 0: table copy, first records and rows issued
     __syncthreads();
+    dbg();                                                                   // 1: barrier
     const float tau = p.tau[q];
     const uint8_t* cb = reinterpret_cast<const uint8_t*>(cdw + tid);        // byte m of the row: cb[(m >> 2) * 4 * NT + (m & 3)]
     // one survivor: its row (set `cr`) -> LDS, the next loads issued (record i + 3 into rec_new, then row i + 2 -- named by rec_old,
@@ -932,11 +944,16 @@ __global__ __launch_bounds__(1024) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore
         if (e + NT >= n) break;
         one(e + NT, cr1, bias1, rid1, recD, recC);
     }
+    dbg();                                                                   // 2: thread 0's records
     __syncthreads();
+    dbg();                                                                   // 3: the other waves' records
     if (tid == 0) p.cand_cnt[q] = ccnt;
     // rows -> payloads (ids, labels): every thread's loads independent of each other, nothing else in flight
     const int nc = min(ccnt, p.cand_cap);
+    // (loading the payload with every row instead, and the first records without waiting for the count, moved the time into the first
+    // phase and added requests: 1.22 against 1.14 ms -- the kernel runs at ~0.7 of the memory system's request rate, ~3 per record)
     for (int e = tid; e < nc; e += NT) p.cand_id[q * p.cand_cap + e] = p.payload[p.cand_id[q * p.cand_cap + e]];
+    dbg();                                                                   // 4: payloads
 }
 
 }  // namespace
@@ -1048,13 +1065,13 @@ int ivfpq_rescore(const gnnlm_ivfpq_rescore_t& d, hipStream_t stream) {
                       (uintptr_t)d.codes % 16 == 0,
                   "ivfpq_rescore: need M = 32 or 64, 16-byte aligned tables");
     ProfScope prof(K_RESCORE, stream, 0.0, 0.0);
-    const size_t lds = (size_t)d.M * 256 * 4 + 1024 * (size_t)d.M;
+    const size_t lds = (size_t)d.M * 256 * 4 + GNNLM_RESCORE_NT * (size_t)d.M;
     if (d.M == 64) {
         GNNLM_LDS_OPT_IN(&ivfpq_rescore_kernel<64>, lds);
-        hipLaunchKernelGGL(ivfpq_rescore_kernel<64>, dim3((unsigned)d.n), dim3(1024), lds, stream, d);
+        hipLaunchKernelGGL(ivfpq_rescore_kernel<64>, dim3((unsigned)d.n), dim3(GNNLM_RESCORE_NT), lds, stream, d);
     } else {
         GNNLM_LDS_OPT_IN(&ivfpq_rescore_kernel<32>, lds);
-        hipLaunchKernelGGL(ivfpq_rescore_kernel<32>, dim3((unsigned)d.n), dim3(1024), lds, stream, d);
+        hipLaunchKernelGGL(ivfpq_rescore_kernel<32>, dim3((unsigned)d.n), dim3(GNNLM_RESCORE_NT), lds, stream, d);
     }
     GNNLM_LAUNCH_CHECK();
     return OK;
