@@ -16,7 +16,7 @@ k-th-best threshold, the remaining lists only emit scores above that threshold.
 
 At M = 64 (the reference's PQ64) the thresholded round is a FILTER on the int8 matrix cores followed by an exact re-score
 (``csrc/ivfpq_mfma.hip``: 8-bit tables with a guaranteed one-sided bound, eight queries of a list per workgroup, the
-sums taken by ``v_mfma_i32_16x16x64_i8``; survivors re-scored in float32 in the summation order of the float32 scan), so
+sums taken by ``v_smfmac_i32_16x16x128_i8`` (round 3: ``v_mfma_i32_16x16x64_i8``); survivors re-scored in float32 in the summation order of the float32 scan), so
 candidates and scores are those of the one-pass float32 scan -- ``GNNLM_IVF_SCAN=f32`` selects that scan for A/B runs.
 With ``attach_vals`` the index carries each key's label next to its id (one 8-byte payload per key), and the search
 returns ``vals[ids]`` with the neighbours: the label gather of knn/knn_model.py:198 disappears.
