@@ -43,7 +43,8 @@ constexpr int TAB_BYTES = 2 * 256 * 32 * QG;            // [half][code][slot][qu
 #define GNNLM_IVF8_WAVE_CAP 320
 #endif
 constexpr int WAVE_CAP = GNNLM_IVF8_WAVE_CAP;                           // survivors a wave stages per task (all 8 queries of its group)
-constexpr int SCAN_LDS = TAB_BYTES + 512 + 16 * WAVE_CAP * 4;
+constexpr int SCAN_CTL = 640;                           // behind the tables: [16 waves][8] flush counters, then the group's {counters, thresholds, queries}[8]
+constexpr int SCAN_LDS = TAB_BYTES + SCAN_CTL + 16 * WAVE_CAP * 4;
 constexpr int HIST_BINS = 1024, HIST_SHIFT = 4;         // threshold pass: sum_u (0 .. 16320) >> 4
 constexpr int SUMS_LDS = TAB_BYTES + QG * HIST_BINS * 4;  // = 160 KiB: the whole LDS of a CU
 constexpr int SURV_CNT_STRIDE = 16;                     // survivor counters one per 64-byte line: they are hammered by atomics
@@ -272,7 +273,9 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         }
         continue;
     }
-    uint32_t* wbuf = reinterpret_cast<uint32_t*>(smem + TAB_BYTES + 512) + wave * WAVE_CAP;   // this wave's survivors: (row - lo) << 3 | query slot
+    uint32_t* wbuf = reinterpret_cast<uint32_t*>(smem + TAB_BYTES + SCAN_CTL) + wave * WAVE_CAP;   // this wave's survivors: (row - lo) << 3 | query slot
+    int* wc = reinterpret_cast<int*>(smem + TAB_BYTES) + wave * QG;          // this wave's per-slot counters / first positions (a flush in the middle of a group)
+    int* wgc = reinterpret_cast<int*>(smem + TAB_BYTES + 512);               // the group's: [0..8) counters / first positions, [8..16) thresholds, [16..24) queries
     const int* gq = p.grp_q + (int64_t)grp * QG;
     uint2* surv = reinterpret_cast<uint2*>(p.surv);                           // {row, list} per survivor
     int qs[QG];
@@ -342,6 +345,15 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
 #elif GNNLM_IVF8_EXP & 255
     T4[0] = T4[1] = T4[2] = T4[3] = T_NEVER;                         // ablation builds time the main loop: nothing survives
 #endif
+    if (!SUMS && wave == 0) {
+        int Tl = 0;                                                          // lane s < 8: the threshold of slot s
+#pragma unroll
+        for (int sl = 0; sl < QG; ++sl) {
+            const int t = __builtin_amdgcn_readlane(T4[sl & 3], 16 * (sl >> 2));
+            if (lane == sl) Tl = t;
+        }
+        if (lane < QG) { wgc[lane] = 0; wgc[8 + lane] = Tl; wgc[16 + lane] = qs_lane; }
+    }
     // the accumulators start at -T: register r then holds the key's EXCESS over query 4 g + r's threshold, a survivor is a non-negative one
     const v4i negT = SUMS ? v4i{0, 0, 0, 0} : v4i{-T4[0], -T4[1], -T4[2], -T4[3]};
     __syncthreads();                                                       // the tables are in place
@@ -414,64 +426,51 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     // Survivors of one tile.  A wave stages its survivors in its OWN LDS region, {row - lo, query slot} packed in a dword, at
     // positions it computes itself: a scalar count of what it has staged so far + scalar popcounts of the compare masks + the
     // lane's rank inside its mask (v_mbcnt).  No LDS atomic, nothing to wait for: the look-ups of the next tile that are in
-    // flight stay in flight.  A full region (and the region at the end of the task) is flushed by the wave alone: one global
-    // atomic per query for the base, positions by ballot ranks again.
+    // flight stay in flight.  A full region is flushed by the wave alone, the regions left at the end of the group by the
+    // workgroup together: one global atomic per query slot for the first positions (below).
     int wcnt = 0;                                                            // (scalar) entries staged by this wave
     uint32_t ent[WAVE_CAP / 64];                                             // the staged entries while they are written out
-    // entries of the region per query slot: lane s (0..7) gets the total of slot s
-    auto slot_totals = [&]() __attribute__((always_inline)) -> int {
+    // A staged region -> the queries' lists, in three moves: (1) every entry takes its rank among the entries of its query slot with an LDS
+    // atomic on one of 8 counters (the wave's own for a flush in the middle of a group, the workgroup's at its end), (2) lanes 0..7 turn the
+    // counters into first positions with ONE global atomic per slot, (3) every entry goes to position first[slot] + rank.  (Round 3 sorted
+    // the region by slot with ballots: 8 slots x 5 chunks of compares, ~500 vector instructions per flush against ~120.)
+    int rk[WAVE_CAP / 64];
+    auto take_ranks = [&](int* ctr) __attribute__((always_inline)) {
         const int n = wcnt;
 #pragma unroll
-        for (int x = 0; x < WAVE_CAP / 64; ++x) ent[x] = (lane + 64 * x < n) ? wbuf[lane + 64 * x] : 0xffffffffu;
-        int mytot = 0;
-#pragma unroll
-        for (int sl = 0; sl < QG; ++sl) {
-            int t = 0;
-#pragma unroll
-            for (int x = 0; x < WAVE_CAP / 64; ++x)
-                if (64 * x < n) t += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ent[x] != 0xffffffffu && (int)(ent[x] & 7u) == sl));
-            if (lane == sl) mytot = t;
+        for (int x = 0; x < WAVE_CAP / 64; ++x) {
+            const bool valid = lane + 64 * x < n;
+            ent[x] = valid ? wbuf[lane + 64 * x] : 0xffffffffu;
+            rk[x] = valid ? atomicAdd(&ctr[ent[x] & 7u], 1) : 0;
         }
-        return mytot;
     };
-    // the region's entries -> the queries' lists; basev: lane s holds the first position of slot s
-    auto write_entries = [&](int basev) __attribute__((always_inline)) {
-        const int n = wcnt;
+    auto write_entries = [&](const int* first) __attribute__((always_inline)) {
 #pragma unroll
-        for (int sl = 0; sl < QG; ++sl) {
-            const int base = __builtin_amdgcn_readlane(basev, sl), qsl = __builtin_amdgcn_readlane(qs_lane, sl);
-            const int Tsl = __builtin_amdgcn_readlane(T4[sl & 3], 16 * (sl >> 2));   // lanes (g, .) hold the thresholds of slots 4 g .. 4 g + 3
-            if (qsl < 0) continue;
-            int run = 0;
-#pragma unroll
-            for (int x = 0; x < WAVE_CAP / 64; ++x) {
-                if (64 * x >= n) continue;
-                const bool mine = ent[x] != 0xffffffffu && (int)(ent[x] & 7u) == sl;
-                const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
-                if (m == 0ull) continue;
-                if (mine) {
-                    const int64_t at = (int64_t)base + run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (at < p.cap) {
-                        // the key's integer sum sum_u = excess + T + 128 * 64 (0 .. 16320); SURV_SUM_BIG: more than the entry could hold
-                        const int ex = (int)(ent[x] >> (SURV_ROW_BITS + 3));
-                        const int su = ex >= SURV_EXCESS_MAX ? SURV_SUM_BIG : min(SURV_SUM_BIG - 1, max(0, ex + Tsl + 128 * 64));
-                        surv[(int64_t)qsl * p.cap + at] = uint2{(uint32_t)(lo + ((ent[x] >> 3) & ((1u << SURV_ROW_BITS) - 1u))),
-                                                                (uint32_t)list | (uint32_t)su << SURV_LIST_BITS};
-                    }
-                }
-                run += __builtin_popcountll(m);
+        for (int x = 0; x < WAVE_CAP / 64; ++x) {
+            if (ent[x] == 0xffffffffu) continue;
+            const int sl = (int)(ent[x] & 7u);
+            const int64_t at = (int64_t)first[sl] + rk[x];
+            const int Tsl = wgc[8 + sl], qsl = wgc[16 + sl];
+            if (at < p.cap && qsl >= 0) {
+                // the key's integer sum sum_u = excess + T + 128 * 64 (0 .. 16320); SURV_SUM_BIG: more than the entry could hold
+                const int ex = (int)(ent[x] >> (SURV_ROW_BITS + 3));
+                const int su = ex >= SURV_EXCESS_MAX ? SURV_SUM_BIG : min(SURV_SUM_BIG - 1, max(0, ex + Tsl + 128 * 64));
+                surv[(int64_t)qsl * p.cap + at] = uint2{(uint32_t)(lo + ((ent[x] >> 3) & ((1u << SURV_ROW_BITS) - 1u))),
+                                                        (uint32_t)list | (uint32_t)su << SURV_LIST_BITS};
             }
         }
         wcnt = 0;
     };
-    // a full region in the middle of a task (the best lists of a query hold thousands of its survivors): the wave flushes alone,
-    // one global atomic per query slot
+    // a full region in the middle of a group (the best lists of a query hold thousands of its survivors): the wave flushes alone
     auto flush_wave = [&]() __attribute__((always_inline)) {
         if (wcnt == 0) return;
-        const int mytot = slot_totals();
-        int basev = 0;
-        if (lane < QG && mytot > 0 && qs_lane >= 0) basev = atomicAdd(&p.surv_cnt[(int64_t)qs_lane * SURV_CNT_STRIDE], mytot);
-        write_entries(basev);
+        if (lane < QG) wc[lane] = 0;
+        take_ranks(wc);
+        if (lane < QG) {
+            const int tot = wc[lane];
+            wc[lane] = (tot > 0 && qs_lane >= 0) ? atomicAdd(&p.surv_cnt[(int64_t)qs_lane * SURV_CNT_STRIDE], tot) : 0;
+        }
+        write_entries(wc);
     };
     // entry = excess << 22 | local row << 3 | query slot: `excess` = how far the key's integer sum lies above the query's integer
     // threshold (clamped to 1023) -- ivfpq_refine_kernel turns it into a lower bound of the key's score (SURV_ROW_BITS = 19: lists
@@ -577,23 +576,20 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         }
         continue;
     }
-    // ---- end of the task: the 16 waves' regions -> the queries' lists with ONE global atomic per query slot for the whole
-    // workgroup (the counters are contended: 30 lists x their groups add to every query's): per-wave slot totals meet in LDS
-    int* wtot = reinterpret_cast<int*>(smem + TAB_BYTES);                     // [16 waves][8 slots] totals, then first positions
-    const int mytot = slot_totals();
-    if (lane < QG) wtot[wave * QG + lane] = mytot;
+    // ---- end of the group: the 16 waves' regions -> the queries' lists with ONE global atomic per query slot for the whole
+    // workgroup (the counters are contended: 30 lists x their groups add to every query's): the entries take their ranks on the
+    // workgroup's 8 LDS counters (zeroed when the group was set up)
+    take_ranks(wgc);
     phase(3);
     __syncthreads();
     phase(4);
     if (tid < QG) {
-        int tot = 0;
-        for (int w = 0; w < NW; ++w) tot += wtot[w * QG + tid];
-        int at = (tot > 0 && qs_lane >= 0) ? atomicAdd(&p.surv_cnt[(int64_t)qs_lane * SURV_CNT_STRIDE], tot) : 0;
-        for (int w = 0; w < NW; ++w) { const int t = wtot[w * QG + tid]; wtot[w * QG + tid] = at; at += t; }
+        const int tot = wgc[tid];
+        wgc[tid] = (tot > 0 && qs_lane >= 0) ? atomicAdd(&p.surv_cnt[(int64_t)qs_lane * SURV_CNT_STRIDE], tot) : 0;
     }
     __syncthreads();
     phase(5);
-    write_entries(lane < QG ? wtot[wave * QG + lane] : 0);
+    write_entries(wgc);
     }
 #if GNNLM_IVF8_EXP & 512
     if (tid == 0 && p.work_ctr) {
