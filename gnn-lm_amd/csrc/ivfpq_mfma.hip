@@ -43,7 +43,7 @@ constexpr int TAB_BYTES = 2 * 256 * 32 * QG;            // [half][code][slot][qu
 #define GNNLM_IVF8_WAVE_CAP 320
 #endif
 constexpr int WAVE_CAP = GNNLM_IVF8_WAVE_CAP;                           // survivors a wave stages per task (all 8 queries of its group)
-constexpr int SCAN_CTL = 640;                           // behind the tables: [16 waves][8] flush counters, then the group's {counters, thresholds, queries}[8]
+constexpr int SCAN_CTL = 768;                           // behind the tables: [16 waves][8] flush counters, then {counters, thresholds, queries}[8] of the group, twice (groups alternate)
 constexpr int SCAN_LDS = TAB_BYTES + SCAN_CTL + 16 * WAVE_CAP * 4;
 constexpr int HIST_BINS = 1024, HIST_SHIFT = 4;         // threshold pass: sum_u (0 .. 16320) >> 4
 constexpr int SUMS_LDS = TAB_BYTES + QG * HIST_BINS * 4;  // = 160 KiB: the whole LDS of a CU
@@ -241,17 +241,19 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     auto tick = [&](int) {};
 #endif
     int nxt = 0;                                                             // (thread 0) the counter's value for the group after this one
+    int gi_next = 0, par = 0;
+    // the index of the next group: thread 0's to everybody (three barriers; the filter's groups do this inside the two barriers their end has anyway)
+    auto next_index = [&]() -> int { return p.work_ctr ? (int)(gridDim.x >> 3) + nxt : gi + (int)(gridDim.x >> 3); };
+    auto advance_slow = [&]() {
+        __syncthreads();                                                     // the group's tables and histograms are done with
+        if (tid == 0) *next_s = next_index();
+        __syncthreads();
+        gi_next = *next_s;
+        __syncthreads();
+    };
     for (;;) {
     phase(2);
-    if (!first) {
-        __syncthreads();                                                     // the previous group's tables, totals and histograms are done with
-        if (p.work_ctr) {
-            if (tid == 0) *next_s = (int)(gridDim.x >> 3) + nxt;
-            __syncthreads();
-            gi = *next_s;
-            __syncthreads();
-        } else gi += (int)(gridDim.x >> 3);
-    }
+    if (!first) gi = gi_next;
     first = false;
     if (gi >= per_xcd) break;
     const int grp = (int)(blockIdx.x & 7) * per_xcd + gi;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     // stand between two groups, 135 times per workgroup
     if (tid == 0 && p.work_ctr) nxt = atomicAdd(&p.work_ctr[(blockIdx.x & 7) * 16], 1);
     const int list = p.grp_list[grp];
-    if (list < 0) continue;
+    if (list < 0) { advance_slow(); continue; }
     const int64_t lo = p.list_off[list], hi = p.list_off[list + 1];
     if (hi <= lo) {
         // an empty list: the threshold pass still owes ivfpq_tau_kernel a (zero) histogram for every (query, list) pair of the group
@@ -271,11 +273,15 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
                 for (int e = tid; e < HIST_BINS; e += NTH) p.out_hist[ob + e] = 0u;
             }
         }
+        advance_slow();
         continue;
     }
     uint32_t* wbuf = reinterpret_cast<uint32_t*>(smem + TAB_BYTES + SCAN_CTL) + wave * WAVE_CAP;   // this wave's survivors: (row - lo) << 3 | query slot
     int* wc = reinterpret_cast<int*>(smem + TAB_BYTES) + wave * QG;          // this wave's per-slot counters / first positions (a flush in the middle of a group)
-    int* wgc = reinterpret_cast<int*>(smem + TAB_BYTES + 512);               // the group's: [0..8) counters / first positions, [8..16) thresholds, [16..24) queries
+    // the group's [0..8) counters / first positions, [8..16) thresholds, [16..24) queries; two copies in turn: a wave that is done with a group
+    // sets the next one up while others still write the records of this one
+    par ^= 1;
+    int* wgc = reinterpret_cast<int*>(smem + TAB_BYTES + 512) + 32 * par;
     const int* gq = p.grp_q + (int64_t)grp * QG;
     uint2* surv = reinterpret_cast<uint2*>(p.surv);                           // {row, list} per survivor
     int qs[QG];
@@ -574,12 +580,14 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
             if (qs[u] < 0 || ob < 0) continue;
             for (int e = tid; e < HIST_BINS; e += NTH) p.out_hist[ob + e] = hist[u * HIST_BINS + e];
         }
+        advance_slow();
         continue;
     }
     // ---- end of the group: the 16 waves' regions -> the queries' lists with ONE global atomic per query slot for the whole
     // workgroup (the counters are contended: 30 lists x their groups add to every query's): the entries take their ranks on the
     // workgroup's 8 LDS counters (zeroed when the group was set up)
     take_ranks(wgc);
+    if (tid == 0) *next_s = next_index();                                    // (the next group's index rides on the same two barriers)
     phase(3);
     __syncthreads();
     phase(4);
@@ -588,8 +596,11 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         wgc[tid] = (tot > 0 && qs_lane >= 0) ? atomicAdd(&p.surv_cnt[(int64_t)qs_lane * SURV_CNT_STRIDE], tot) : 0;
     }
     __syncthreads();
+    gi_next = *next_s;
     phase(5);
     write_entries(wgc);
+    // no barrier here: the tables are free (every wave has left its tile loop), the staging regions are the waves' own, the next group's
+    // counters are the other copy, and nobody flushes (the wave-0 counters hold *next_s) before the next "tables in place" barrier
     }
 #if GNNLM_IVF8_EXP & 512
     if (tid == 0 && p.work_ctr) {
