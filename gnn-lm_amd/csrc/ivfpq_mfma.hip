@@ -571,6 +571,15 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         }
 #undef GNNLM_IVF8_STEP
         static_assert(PF >= 3 && PF <= 8, "GNNLM_IVF8_PF");
+        phase(1);
+#if GNNLM_IVF8_EXP & 512
+        if (tid == 512 && p.work_ctr) for (int i = 0; i < 3; ++i) { atomicAdd(&p.work_ctr[(blockIdx.x & 7) * 16 + 8 + i], acc_t[i]); acc_t[i] = 0; }
+        if (tid == 512 && p.work_ctr) atomicAdd(&p.work_ctr[(blockIdx.x & 7) * 16 + 11], (nt - wv + NW - 1) / NW);
+#endif
+#if GNNLM_IVF8_EXP & 1024
+        // when does each wave leave the tile loop?  (ticks since the group's tables were in place; slot 15 <- waves 0 and 15)
+        if (lane == 0 && p.work_ctr) atomicAdd(&p.work_ctr[(blockIdx.x & 7) * 16 + (wave ? wave : 15)], (int)((clock64() - g0) >> 4));
+#endif
     }
     if (SUMS) {
         __syncthreads();
