@@ -396,6 +396,21 @@ def recipe_l3(args, eng1, batches, dev):
     uni = [batch_at(i, pool_ids) for i in range(n_pool)]
     out["uniform_ids"] = dict(timed(uni, 0.0), neighbour_ids="i.i.d. uniform over the store (no equal context groups: the worst case; state cache off -- it could only miss)")
     out["uniform_ids"]["unelided_equivalent_TFLOPs"] = round(out["flop_per_token_unelided_survey_8d"] * out["uniform_ids"]["tokens_per_s"] / 1e12, 1)
+    if args.precision == "f32":
+        # the same worst case under the opt-in split-bf16 emulation of the f32 product (`--precision bf16x3`: three bf16 MFMA products per
+        # multiply-add, f32 accumulate): NOT the headline's arithmetic -- reported with its measured distance from the f32 path
+        lp32 = eng.score(uni[0], args.lmbda, args.temperature)["logp"].clone()
+        saved = hgt.gemm_precision, eng.asm.gemm_precision
+        hgt.gemm_precision = eng.asm.gemm_precision = ops.PRECISIONS["bf16x3"]
+        try:
+            lp3 = eng.score(uni[0], args.lmbda, args.temperature)["logp"]
+            dl = float((lp3 - lp32).abs().max().item())
+            t3 = timed(uni, 0.0, settle_s=0.3)
+            out["uniform_ids_bf16x3_opt_in"] = {"tokens_per_s": t3["tokens_per_s"], "ms_per_step": t3["ms_per_step"], "ms_per_step_median": t3["ms_per_step_median"],
+                                                "steps": t3["steps"], "max_abs_dlogp_vs_f32": dl,
+                                                "what": "`--precision bf16x3` (split-bf16 emulation of the f32 product on the bf16 matrix cores, f32 accumulate); opt-in, not the headline's arithmetic"}
+        finally:
+            hgt.gemm_precision, eng.asm.gemm_precision = saved
     # searched neighbours: one id table for the whole pool
     n_srch = n_pool * n
     ids_s, desc = searched_neighbour_ids(args, dev, n_srch, T)
