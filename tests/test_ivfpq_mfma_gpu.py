@@ -352,6 +352,20 @@ def test_mfma_search_identical_to_f32_scan(dev, small_index):
     _same_search(mixed, f32, many, 1024)
 
 
+def test_search_repeats_bit_for_bit(dev, small_index):
+    """The filter's records reach a query's list in any order (atomics between workgroups, ranks from LDS atomics inside one, waves that
+    run ahead into the next group): nothing downstream may depend on it -- 20 searches of the same batch return the same bits
+    (`tools/search_repeat.py` does the same at the 103 M-key shape)."""
+    import torch
+    index, q = small_index
+    qd = torch.from_numpy(np.concatenate([q, q[::-1]])).to(dev)
+    v0, i0 = index.search_device(qd, 1024)
+    v0, i0 = v0.clone(), i0.clone()
+    for _ in range(20):
+        v, i = index.search_device(qd, 1024)
+        assert torch.equal(v, v0) and torch.equal(i, i0)
+
+
 def test_empty_list_among_the_threshold_lists(dev, small_index):
     """A query whose best probes include EMPTY lists: the threshold pass writes no histogram for an empty list, so the tau kernel
     must not read stale memory there (a too-high tau silently drops true neighbours).  Empty lists are added as scaled-up copies of
