@@ -499,9 +499,11 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     // the top of step i into the registers tile i's bytes leave; the loop is unrolled PF times so that every name is static.
     constexpr int PF = SUMS ? GNNLM_IVF8_PF_SUMS : GNNLM_IVF8_PF;
     v8i X[4];
+    // (the threshold pass may histogram a SAMPLE of the list: every TS-th tile, starting at a tile that differs from list to list)
+    const int TS = SUMS ? max(1, p.sums_stride) : 1;
     auto step = [&](const v4u& cn, v4u& cl, int u) __attribute__((always_inline)) {
         tick(-1);
-        cl = load_tile(u + PF * NW);
+        cl = load_tile(u + PF * NW * TS);
         v4i acc = negT;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -554,17 +556,17 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         }
     };
     {
-        int u = wv;
+        int u = SUMS ? wv * TS + list % TS : wv;                                  // (by list, not by group: which queries share a group is not specified)
         v4u C[PF];
 #pragma unroll
-        for (int i = 0; i < PF; ++i) C[i] = load_tile(u + i * NW);             // (loads beyond the list's tiles return zeros)
+        for (int i = 0; i < PF; ++i) C[i] = load_tile(u + i * NW * TS);        // (loads beyond the list's tiles return zeros)
 #pragma unroll
         for (int q = 0; q < 4; ++q) lookups4(C[0], q, X[q]);
         // The loop is left only between two blocks of PF steps and every step of a block RUNS -- a step beyond the list's tiles reads zeros (the
         // buffer's range check) and takes the edge tiles' path, where its rows fail the range test.  With an exit or a skipped step inside the
         // block the compiler's s_waitcnt insertion merges paths with different loads in flight and falls back to waiting for (nearly) all of
         // them: `vmcnt(1)` with seven tiles in flight, once per block -- the waves stood at the code loads 17 % of their time (PMC).
-#define GNNLM_IVF8_STEP(t) if constexpr (PF > (t)) { step(C[((t) + 1) % PF], C[(t)], u); u += NW; }
+#define GNNLM_IVF8_STEP(t) if constexpr (PF > (t)) { step(C[((t) + 1) % PF], C[(t)], u); u += NW * TS; }
         while (u < nt) {
             GNNLM_IVF8_STEP(0) GNNLM_IVF8_STEP(1) GNNLM_IVF8_STEP(2) GNNLM_IVF8_STEP(3)
             GNNLM_IVF8_STEP(4) GNNLM_IVF8_STEP(5) GNNLM_IVF8_STEP(6) GNNLM_IVF8_STEP(7)

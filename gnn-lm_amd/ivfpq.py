@@ -171,15 +171,21 @@ def build_groups(pl, nlist, seg=None):
 
 
 class IVFPQIndex:
+    UNDERFLOW = 1 << 30      # "survivor count" of a query whose sampled threshold left fewer than k candidates: searched again like an overflow
     """faiss ``search`` contract: ``search(queries [n, d] f32, k) -> (scores [n, k] descending, ids [n, k], -1 padded)``."""
 
     LABEL_BITS = 24                                                          # payload = id << 24 | label (ids < 2^39, labels < 2^24)
 
-    def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=None, cand_cap=16384,
+    def __init__(self, R, coarse, pq, list_off, list_ids, list_codes, nprobe=32, cosine=True, dense_probes=None, cand_cap=None,
                  score_bytes=6 << 30, scan=None, metric="ip", list_term_bytes=4 << 30):
         self.R, self.coarse, self.pq = R, coarse, pq                         # [d, d], [nlist, d], [M, 256, dsub]  f32
         self.list_off, self.list_ids, self.list_codes = list_off, list_ids, list_codes   # i64 [nlist+1], i64 [N], u8 [N, M]
         self.nprobe, self.cosine, self.dense_probes, self.cand_cap = nprobe, cosine, dense_probes, cand_cap
+        # every S-th tile of the threshold lists is histogrammed (GNNLM_IVF_SAMPLE; 1: all of them -- see _search_block_mfma)
+        self.threshold_sample = max(1, int(os.environ.get("GNNLM_IVF_SAMPLE", "4")))
+        self.sample_min_keys_per_k = 64          # ... when the threshold lists hold at least this many keys per neighbour asked for
+        self.sample_sigmas = 4.5                 # margin of the sample's rank (tests lower it to force the verification to fail)
+        self.sample_fail_frac = 0.01             # more failing queries than this in a batch: the index stops sampling
         self.score_bytes = score_bytes                                       # budget of the dense round's score rows per query block
         self.payload, self.has_vals, self.val_last = list_ids, False, 0      # what a candidate carries through the selection
         self.device = R.device
@@ -220,6 +226,10 @@ class IVFPQIndex:
         # bound a little loose, 6 lists give the tighter threshold (fewer survivors to re-score) for less time
         if self.dense_probes is None:
             self.dense_probes = 6 if self.tiles is not None else 2
+        # records per query: the int8 filter's SURVIVORS (8 bytes each; a sampled threshold lets ~8 k of them through on average and twice that
+        # where list lengths vary: 32768 keeps the re-searches of overflowing queries rare), the float32 scan's candidates
+        if self.cand_cap is None:
+            self.cand_cap = 32768 if self.tiles is not None else 16384
         self.refine_tau = os.environ.get("GNNLM_IVF_REFINE", "1") != "0"     # gnnlm_ivfpq_refine between the filter and the re-score (A/B: 0)
         self.stats = {}                                                      # device-side work counters of the last search (bench.py)
 
@@ -399,7 +409,13 @@ class IVFPQIndex:
             bad = (over > self.cand_cap).nonzero().reshape(-1)                # host sync
             if bad.numel() == 0:
                 break
-            if bad.numel() * 8 > q.shape[0] and self.cand_cap < (1 << 18):
+            n_under = int((over[bad] >= self.UNDERFLOW).sum().item())
+            if n_under > self.sample_fail_frac * q.shape[0] and self.threshold_sample > 1:   # the sample does not stand for its lists on this data: stop sampling
+                self.threshold_sample = 1
+                self.stats = _LazyStats(pairs=0, survivors=0, candidates=0, queries=q.shape[0], M=self.M, requeried=0)
+                val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
+                continue
+            if (bad.numel() - n_under) * 8 > q.shape[0] and self.cand_cap < (1 << 18):
                 self.cand_cap *= 2
                 self.stats = _LazyStats(pairs=0, survivors=0, candidates=0, queries=q.shape[0], M=self.M, requeried=0)
                 val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
@@ -464,11 +480,14 @@ class IVFPQIndex:
         g.M, g.N, g.K, g.batch1 = nq, 256, self.dsub, self.M
         g.sA1, g.sW1, g.sC1 = self.dsub, 256 * self.dsub, 256
         _lib.call_desc("gnnlm_gemm_nt", g)
-        cv = torch.empty(nq, cap, device=dev, dtype=torch.float32)
-        ci = torch.empty(nq, cap, device=dev, dtype=torch.int64)
+        # (the int8 path: `cap` bounds a query's SURVIVORS of the filter; what scores above the refined threshold afterwards is a fraction of them
+        # and gets 16384 columns at most -- the width the one-chunk k-selection takes)
+        ccap = min(cap, 16384) if self.tiles is not None else cap
+        cv = torch.empty(nq, ccap, device=dev, dtype=torch.float32)
+        ci = torch.empty(nq, ccap, device=dev, dtype=torch.int64)
         cc = torch.zeros(nq, device=dev, dtype=torch.int32)
         if self.tiles is not None:
-            return self._search_block_mfma(k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc)
+            return self._search_block_mfma(k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc, cap)
         lut_s = lut
         if self.packed_codes is not None:
             lut_s = torch.empty_like(lut)
@@ -492,8 +511,9 @@ class IVFPQIndex:
         ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=False, row_ncols=cc.clamp(max=cap))
         return cc
 
-    def _scan8(self, qlut, qmeta, cs, groups, tau=None, surv=None, hist=None):
+    def _scan8(self, qlut, qmeta, cs, groups, tau=None, surv=None, hist=None, stride=1):
         d = _lib.gnnlm_ivfpq_scan8_t()
+        d.sums_stride = stride
         d.tiles, d.list_off, d.M = self.tiles.data_ptr(), self.list_off.data_ptr(), self.M
         d.qlut, d.qmeta, d.coarse, d.ld_coarse = qlut.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0)
         d.grp_list, d.grp_q, d.n_groups, d.max_groups = groups[0].data_ptr(), groups[1].data_ptr(), groups[2].data_ptr(), groups[3]
@@ -507,21 +527,27 @@ class IVFPQIndex:
             d.tau, d.surv, d.surv_cnt, d.cap = tau.data_ptr(), surv[0].data_ptr(), surv[1].data_ptr(), surv[0].shape[1]
         _lib.call_desc("gnnlm_ivfpq_scan8", d)
 
-    def _search_block_mfma(self, k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc):
+    def _search_block_mfma(self, k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc, cap):
         """M = 64: everything on the int8 matrix cores (csrc/ivfpq_mfma.hip).  (1) threshold pass: histograms of the integer sums of the
         first `dense` lists -> a lower bound tau of the query's k-th best score (no per-key output, no selection); (2) filter: every probed
         list, keys whose integer sum can reach tau; (3) exact float32 scores of the survivors, score > tau -> candidates;
         (4) one k-selection over the candidates."""
         dev = self.device
-        nq, cap = pv.shape[0], cv.shape[1]
+        nq, ccap = pv.shape[0], cv.shape[1]
         qlut, qmeta = ops.ivfpq_quantize_lut(lut, self.M)
         hist = torch.empty(nq, dense, 1024, device=dev, dtype=torch.int32)      # per (query, list): sum_u >> 4 counted on the device
-        self._scan8(qlut, qmeta, cs, self._groups(pi[:, :dense], seg=1024), hist=hist)
+        # The threshold pass histograms a SAMPLE of its lists' keys (every S-th tile of 16) when they hold plenty of them: tau is then the
+        # bound of rank k / S + 4.5 sigma of the sample (sigma = sqrt(k (S - 1)) / S: the k best land in the sample binomially), i.e. with
+        # probability ~1e-5 per query fewer than k keys score above it.  Nothing is taken on trust: a query with fewer than k candidates
+        # above its threshold is reported like an overflowing one and searched again with every probed list in an exact threshold pass.
+        S = self.threshold_sample if (dense < nprobe and self.ntotal / max(self.nlist, 1) * dense >= self.sample_min_keys_per_k * k) else 1
+        rank = k if S == 1 else max(1, min(k, -(-k // S) + int(np.ceil(self.sample_sigmas * np.sqrt(k * (S - 1)) / S))))
+        self._scan8(qlut, qmeta, cs, self._groups(pi[:, :dense], seg=1024), hist=hist, stride=S)
         tau = torch.empty(nq, device=dev, dtype=torch.float32)
         t = _lib.gnnlm_ivfpq_tau_t()
         t.hist, t.D = hist.data_ptr(), dense
         t.probe_list, t.probe_bias, t.ld_probe = pi.data_ptr(), pv.data_ptr(), pi.stride(0)
-        t.qmeta, t.n, t.k, t.tau = qmeta.data_ptr(), nq, k, tau.data_ptr()
+        t.qmeta, t.n, t.k, t.tau = qmeta.data_ptr(), nq, rank, tau.data_ptr()
         _lib.call_desc("gnnlm_ivfpq_tau", t)
         surv = torch.empty(nq, cap, 2, device=dev, dtype=torch.int32)
         sc16 = torch.zeros(nq, 16, device=dev, dtype=torch.int32)              # one 64-byte line per counter (column 0)
@@ -542,14 +568,22 @@ class IVFPQIndex:
         r.codes, r.payload, r.M = self.list_codes.data_ptr(), self.payload.data_ptr(), self.M
         r.lut, r.ld_lut, r.coarse, r.ld_coarse, r.tau = lut.data_ptr(), lut.stride(0), cs.data_ptr(), cs.stride(0), tau.data_ptr()
         r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), rc16.data_ptr(), cap, nq
-        r.cand_val, r.cand_id, r.cand_cnt, r.cand_cap = cv.data_ptr(), ci.data_ptr(), cc.data_ptr(), cap
+        r.cand_val, r.cand_id, r.cand_cnt, r.cand_cap = cv.data_ptr(), ci.data_ptr(), cc.data_ptr(), ccap
         _lib.call_desc("gnnlm_ivfpq_rescore", r)
         self.stats.add("survivors", lambda sc=sc: sc.sum().double())
         self.stats.add("candidates", lambda cc=cc: cc.sum().double())
         if getattr(self, "keep_candidates", False):
             self.last_candidates = (cv, ci, cc, tau)
-        ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=True, row_ncols=cc.clamp(max=cap))
-        return sc                                                              # every candidate is a survivor: sc >= cc
+        ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=True, row_ncols=cc.clamp(max=ccap))
+        over = sc                                                              # every candidate is a survivor: sc >= cc
+        if ccap < cap:                                                         # more candidates than columns: an overflow like any other
+            over = torch.where(cc > ccap, torch.full_like(sc, cap + 1), over)
+        if S > 1:                                                              # the sampled threshold's proof: k candidates above it (or every key there is)
+            avail = (self.list_off[1:] - self.list_off[:-1])[pi.clamp(min=0)].masked_fill(pi < 0, 0).sum(1)
+            short = cc.to(torch.int64) < avail.clamp(max=k)
+            self.stats.add("underflow", lambda short=short: short.sum().double())
+            over = torch.where(short, torch.full_like(sc, self.UNDERFLOW), over)
+        return over
 
     def check(self):
         """Kept for callers of earlier versions: ``search_device`` itself re-searches queries whose survivors did not fit."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNLM_ABI_VERSION 7
+#define GNNLM_ABI_VERSION 8
 #define GNNLM_OK 0
 #define GNNLM_E_INVALID (-22)
 #define GNNLM_E_NOMEM (-12)
@@ -362,6 +362,10 @@ typedef struct gnnlm_ivfpq_scan8 {
      * histogrammed per query (1024 bins of 16) and written to out_hist[grp_out[group * 8 + j] .. + 1024) for query j of the group
      * (grp_out < 0: skipped; every (query, list) pair belongs to exactly one group: plain stores) */
     uint32_t* out_hist;  const int64_t* grp_out;
+    /* ABI 8, threshold pass only: histogram every sums_stride-th tile of 16 keys of a list (0 / 1: every tile).  A SAMPLE of the
+     * keys: the caller asks gnnlm_ivfpq_tau for rank ~k / stride (+ a margin) and must then verify that at least k candidates
+     * score above the threshold it got -- gnn-lm_amd/ivfpq.py searches the (rare) queries that fail again with stride 1 */
+    int32_t sums_stride;
     /* the workgroups are persistent (one per CU); with work_ctr != NULL ([8, 16] int32, ZEROED by the caller before every call:
      * one counter per XCD, one 64-byte line each) a workgroup fetches its next group from its XCD's counter -- lists of very
      * different lengths stay balanced; NULL: static striding */

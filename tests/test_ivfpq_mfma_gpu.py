@@ -352,6 +352,33 @@ def test_mfma_search_identical_to_f32_scan(dev, small_index):
     _same_search(mixed, f32, many, 1024)
 
 
+def test_sampled_threshold_pass_is_verified(dev, small_index):
+    """The threshold pass over a SAMPLE of its lists' tiles (ABI 8, `sums_stride`): the search result is the exact one whatever the sample
+    says -- a query left with fewer than k candidates above its threshold is searched again with an exact threshold pass (few of them), or
+    the index stops sampling (many of them)."""
+    import torch
+    from gnnlm_amd.ivfpq import IVFPQIndex
+    index, q = small_index
+    args = (index.R, index.coarse, index.pq, index.list_off, index.list_ids, index.list_codes)
+    f32 = IVFPQIndex(*args, nprobe=9, scan="f32")
+    qd = np.concatenate([q, q[::-1]])
+    for k in (1024, 64):
+        for S in (2, 4, 8):
+            a = IVFPQIndex(*args, nprobe=9)
+            a.threshold_sample, a.sample_min_keys_per_k = S, 0                  # sample whatever the lists hold
+            _same_search(a, f32, qd, k)
+            assert a.threshold_sample == S and "underflow" in a.stats
+    # a margin far below zero: the sampled rank is 1, the threshold too high for most queries
+    b = IVFPQIndex(*args, nprobe=9)
+    b.threshold_sample, b.sample_min_keys_per_k, b.sample_sigmas, b.sample_fail_frac = 4, 0, -1e9, 1.0
+    _same_search(b, f32, qd, 1024)
+    assert b.threshold_sample == 4 and int(b.stats["requeried"]) > 0 and float(b.stats["underflow"]) > 0   # searched again one by one
+    c = IVFPQIndex(*args, nprobe=9)
+    c.threshold_sample, c.sample_min_keys_per_k, c.sample_sigmas = 4, 0, -1e9
+    _same_search(c, f32, qd, 1024)
+    assert c.threshold_sample == 1                                             # too many of them: no more sampling on this index
+
+
 def test_search_repeats_bit_for_bit(dev, small_index):
     """The filter's records reach a query's list in any order (atomics between workgroups, ranks from LDS atomics inside one, waves that
     run ahead into the next group): nothing downstream may depend on it -- 20 searches of the same batch return the same bits

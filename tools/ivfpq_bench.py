@@ -10,7 +10,7 @@ from gnnlm_amd.synthetic import synthetic_ivfpq_index
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     N = int(os.environ.get("N", 103227021)); n = int(os.environ.get("NQ", 8192)); k = int(os.environ.get("K", 1024))
-    idx = synthetic_ivfpq_index(N, 1024, 4096, 64, dev, skew=float(os.environ.get("SKEW", 0.0)), dense_probes=(int(os.environ["DENSE"]) if "DENSE" in os.environ else None), cand_cap=int(os.environ.get("CAP", 16384)))
+    idx = synthetic_ivfpq_index(N, 1024, 4096, 64, dev, skew=float(os.environ.get("SKEW", 0.0)), dense_probes=(int(os.environ["DENSE"]) if "DENSE" in os.environ else None), cand_cap=(int(os.environ["CAP"]) if "CAP" in os.environ else None))
     if os.environ.get("PLAIN"):
         idx.packed_codes = None                            # the row-major kernels (A/B)
     torch.manual_seed(0)
