@@ -764,7 +764,7 @@ def knn_search(args, eng, batches, dev, step_ms):
         torch.cuda.empty_cache()
     return {"index": "synthetic OPQ64_1024,IVF4096,PQ64", "keys": args.n_store, "nprobe": 32, "k": args.k, "queries": n,
             "skewed_lists": skewed, "driver_with_search": drv,
-            "scan": scan_name, "threshold_lists": thr_lists, "cand_cap": cap_now, "ms_per_4096_queries": round(ms_4096, 3),
+            "scan": scan_name, "threshold_lists": thr_lists, "threshold_sample": getattr(idx, "threshold_sample", 1), "cand_cap": cap_now, "ms_per_4096_queries": round(ms_4096, 3),
             "ms_per_batch": round(dt * 1e3, 2), "ms_per_batch_runs": [round(t_ * 1e3, 2) for t_ in times], "queries_per_s": round(n / dt, 1),
             "pairs_per_query": round(st["pairs"] / n), "survivors_per_query": round(st["survivors"] / n), "candidates_per_query": round(st["candidates"] / n), "queries_searched_again": st.get("requeried", 0),
             "kernels_ms": {k_: round(v_["total_ms"], 3) for k_, v_ in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
