@@ -674,7 +674,7 @@ def knn_search(args, eng, batches, dev, step_ms):
         th.append(time.perf_counter() - t0)
     ms_4096 = sorted(th)[1] * 1e3
     scan_name = "int8-MFMA filter + exact float32 re-score" if idx.tiles is not None else "float32"
-    thr_lists, cap_now = idx.dense_probes, idx.cand_cap
+    thr_lists, cap_now, thr_sample = idx.dense_probes, idx.cand_cap, getattr(idx, "threshold_sample", 1)
     # roofline of the search's dominant kernel, the int8-MFMA filter: one table byte per (query, key, sub-quantizer) goes
     # through LDS (ds_read_b64 of 8 queries' bytes) and through the matrix core (a byte of the MFMA's A operand = 32 int8 ops)
     filt = prof.get("ivfpq_scan8_kernel", {"total_ms": 0.0, "launches": 0})
@@ -764,7 +764,7 @@ def knn_search(args, eng, batches, dev, step_ms):
         torch.cuda.empty_cache()
     return {"index": "synthetic OPQ64_1024,IVF4096,PQ64", "keys": args.n_store, "nprobe": 32, "k": args.k, "queries": n,
             "skewed_lists": skewed, "driver_with_search": drv,
-            "scan": scan_name, "threshold_lists": thr_lists, "threshold_sample": getattr(idx, "threshold_sample", 1), "cand_cap": cap_now, "ms_per_4096_queries": round(ms_4096, 3),
+            "scan": scan_name, "threshold_lists": thr_lists, "threshold_sample": thr_sample, "cand_cap": cap_now, "ms_per_4096_queries": round(ms_4096, 3),
             "ms_per_batch": round(dt * 1e3, 2), "ms_per_batch_runs": [round(t_ * 1e3, 2) for t_ in times], "queries_per_s": round(n / dt, 1),
             "pairs_per_query": round(st["pairs"] / n), "survivors_per_query": round(st["survivors"] / n), "candidates_per_query": round(st["candidates"] / n), "queries_searched_again": st.get("requeried", 0),
             "kernels_ms": {k_: round(v_["total_ms"], 3) for k_, v_ in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
