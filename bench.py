@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the GNN+kNN eval hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        (N > 1: one process per GPU -- either launched by torch.distributed.run, which sets WORLD_SIZE / RANK, or plainly:
+         the script then starts its own N ranks as child processes before it touches the GPU and relays rank 0's line)
 
 A step = one pass of the hot path (gather -> HGT -> adaptive softmax -> kNN interpolation -> score
 sum) over one batch of `--blocks` independent 256-token blocks of synthetic input with the real
@@ -855,8 +857,33 @@ def pmc_traffic(kernel):
     return round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n), meta.get("profile")
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): start the N ranks ourselves -- one process
+    per GPU under torch.distributed.run, the launch the driver's own command line names -- relay their output (rank 0 prints the
+    JSON line) and return the launcher's exit code.  Runs BEFORE this process touches the GPU, and the ranks are CHILD
+    processes (never an exec of a process that initialised HIP).  `torch.cuda.device_count()` does not initialise the device."""
+    import socket
+    import subprocess
+    one_gpu_test = os.environ.get("GNNLM_BENCH_BACKEND", "nccl") != "nccl"     # tests: N ranks on device 0 over gloo
+    have = torch.cuda.device_count()
+    if have < args.gpus and not one_gpu_test:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible (one rank per GPU over RCCL)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL / mapped shards across processes need it
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     # GNNLM_BENCH_BACKEND=gloo GNNLM_BENCH_DEVICE=0 (tests only): several ranks on ONE GPU, collectives staged through the host --
@@ -865,7 +892,8 @@ def main():
     if backend != "nccl":
         os.environ["GNNLM_TEST_HOST_STAGED"] = "1"
     local_rank = int(os.environ.get("GNNLM_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment (unset it, or launch {args.gpus} ranks)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

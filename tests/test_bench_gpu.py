@@ -77,3 +77,23 @@ def test_bench_two_ranks_on_one_gpu(extra):
     assert c["rccl_ranks"] == 2 and c["store"].startswith("range-sharded") and c["xgmi_bytes_per_step_per_rank"] > 0
     if "--shard-vals" not in extra:                                    # (the comparison run needs the full label table)
         assert c["replicated_store"]["tokens_per_s"] > 0
+
+
+def test_bench_plain_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (what the driver's scaling run types): the script starts the two
+    ranks itself as child processes, relays rank 0's one JSON line and the exit code.  Both ranks on device 0 over gloo."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--small", "--blocks", "2", "--steps", "3", "--warmup", "2",
+           "--n-store", "30000", "--gcn-k", "16", "--k", "32", "--tokens-per-sample", "32", "--no-cpu-baseline", "--settle-s", "0.05"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GNNLM_BENCH_BACKEND="gloo", GNNLM_BENCH_DEVICE="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["config"]["rccl_ranks"] == 2
+    assert r["config"]["xgmi_bytes_per_step_per_rank"] > 0 and r["config"]["replicated_store"]["tokens_per_s"] > 0
+    # more ranks than GPUs without the one-GPU test transport: refused before anything is launched
+    env.pop("GNNLM_BENCH_BACKEND")
+    p = subprocess.run(cmd[:2] + ["--gpus", "64", "--small"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 2 and "GPU(s) are visible" in p.stderr
