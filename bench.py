@@ -120,6 +120,10 @@ def build(args, dev, rank, world):
     store.vals_row0 = shard.store_row0 if shard_vals else 0
     torch.manual_seed(1234)
     hgt = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=args.layers, n_heads=H)
+    # the headline cycles a small pool of synthetic batches: with the cross-batch centre-state cache on, every group would be a
+    # hit from the second cycle on and `value` would be the all-hits floor, not the multi-layer step.  Off here; the cache has its
+    # own, labelled lines (recipe_L3: cold pass / all hits)
+    hgt.state_cache_gib = 0.0
     w = make_asm_weights(rs, vocab, d, cutoff)
     asm = AdaptiveSoftmax(w["cutoff"], w["emb"], w["proj"], w["class_proj"], dev)
     eng = GnnLmEngine(hgt, asm, store, 2, 2)
@@ -374,10 +378,11 @@ def recipe_l3(args, eng1, batches, dev):
         marks[0].record()
         for j in range(steps):
             step(bs[(i + j) % len(bs)])
-            groups.append(hgt.last_groups[1] if hgt.last_groups else n * args.gcn_k)
+            groups.append(hgt._last_groups)                               # (n, device counter): read after the loop, no sync inside it
             marks[j + 1].record()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        groups = [int(g_[1][0].item()) if g_ is not None else n * args.gcn_k for g_ in groups]
         prof = _lib.profile_end()[dominant]
         per = sorted(marks[j].elapsed_time(marks[j + 1]) for j in range(steps))
         r = roofline_entry(dominant, prof, args.precision)
@@ -426,7 +431,7 @@ def recipe_l3(args, eng1, batches, dev):
     for rep in range(3):                                                  # pass 0 allocates (cache, workspace); passes 1, 2 are timed, each from an EMPTY cache
         if hgt.state_cache is not None:
             hgt.state_cache.clear()
-            hgt.state_cache.stats.update(lookups=0, groups=0, computed=0)
+            hgt.state_cache.reset_stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for b_ in srch:
@@ -937,6 +942,11 @@ def main():
                 self.link_bytes += int(n * (world - 1) / world) * eng.store.codes.shape[1]     # rows the kernels pull over the links
                 return None, None, None
 
+            def account_merged(self, n_ids, n_groups, left, right):
+                # multi-layer model on the mapped store: layer 0's star edges read every neighbour's centre row, the ntgt pipeline
+                # the slots of the DISTINCT groups only (merged on the device before any row is touched)
+                self.link_bytes += int((n_ids + n_groups * (1 + left + right)) * (world - 1) / world) * eng.store.codes.shape[1]
+
             def fetch_knn_vals(self, knn_ids):
                 r = pf.fetch_knn_vals(knn_ids)
                 self.link_bytes += pf.link_bytes
@@ -949,6 +959,12 @@ def main():
     elif sharded:
         fetcher = ShardedFetcher(eng.store, shard, mode=args.exchange)
     centres_only = args.layers == 1
+    # multi-layer model: the engine fetches inside the step, AFTER merging equal context groups -- one request per distinct centre
+    # row of the batch (hgt.py; the one-layer step prefetches the next batch's centre rows on a side stream instead, below)
+    fetch_in_step = fetcher is not None and args.layers > 1
+    if fetch_in_step and isinstance(fetcher, ShardedFetcher):
+        eng.fetcher, eng.fetch_vals = fetcher, bool(args.shard_vals)
+    merged_counts = []
     acc = torch.zeros(1, device=dev, dtype=torch.float64)
 
     assert args.blocks % args.streams == 0, "--blocks must be a multiple of --streams"
@@ -981,7 +997,11 @@ def main():
 
     def score_one(bi, a, prefetch_next):
         b = batches[bi % len(batches)]
-        if fetcher is not None:
+        if fetch_in_step:
+            n_fetches[0] += 1
+            if not isinstance(fetcher, ShardedFetcher) and args.shard_vals:
+                b.knn_vals = fetcher.fetch_knn_vals(b.knn_ids)
+        elif fetcher is not None:
             if bi not in pending:
                 issue_fetch(bi)
             codes, valid, index, kv, ev = pending.pop(bi)
@@ -994,7 +1014,9 @@ def main():
             b.fetched_centres_only = centres_only
         out = eng.score(b, args.lmbda, args.temperature)
         ops.masked_sum_f64(out["logp"], None, a)                  # score_sum (eval_lm.py:273)
-        if fetcher is not None and prefetch_next is not None:
+        if fetch_in_step and len(merged_counts) < 64:
+            merged_counts.append(eng.hgt._last_groups)            # (n, device counter) -- read after the run
+        if fetcher is not None and not fetch_in_step and prefetch_next is not None:
             issue_fetch(prefetch_next)                            # host waits for the split sizes while the GPU computes
 
     def step(i, last=False):
@@ -1053,6 +1075,10 @@ def main():
         step(i + 3)
     dominant = max(kern, key=lambda k_: kern[k_]["total_ms"])
     names = [_lib.lib().gnnlm_kernel_name(i).decode() for i in range(12)]
+    if fetch_in_step and isinstance(fetcher, ShardedFetcher) and args.exchange == "padded" and eng.hgt._last_groups is not None:
+        # merged requests in the fixed-capacity exchange: buckets sized from the distinct-group count the warm-up measured (agreed
+        # among the ranks by a MAX all-reduce, here, outside the timed region) instead of the worst case
+        fetcher.calibrate_groups(eng.hgt._last_groups[1])
     if args.graph:
         capture_graphs()
     # ---- settle (untimed): keep stepping back to back until at least `--settle-s` seconds of GPU work have run and two
@@ -1117,8 +1143,17 @@ def main():
     for a in accs[1:]:
         acc += a
     link_bytes_per_step = replicated = None
+    merged_groups = None
     if fetcher is not None:
         fetcher.check()                                           # no request was dropped by the fixed-capacity buckets
+        mc = [(g_[0], int(g_[1][0].item())) for g_ in merged_counts if g_ is not None]
+        if mc:
+            merged_groups = {"context_groups_per_step": mc[0][0], "distinct_requested_per_step_mean": round(sum(c_ for _, c_ in mc) / len(mc), 1)}
+            if not isinstance(fetcher, ShardedFetcher):           # mapped store: no fetch call to count bytes in
+                fetcher.link_bytes = 0
+                for n_, c_ in mc:
+                    fetcher.account_merged(n_, c_, 2, 2)
+                fetcher.link_bytes *= n_fetches[0] / len(mc)
         link_bytes_per_step = fetcher.link_bytes / max(1, n_fetches[0])
         # the same steps on a REPLICATED store (every rank holds the whole table, no exchange): what the sharding costs
         from gnnlm_amd.engine import GnnLmEngine
@@ -1233,10 +1268,12 @@ def main():
                        "store": ("range-sharded + RCCL all-to-all" if sharded else "replicated" if world > 1 else "single GPU"),
                        "rccl_ranks": world if dist.is_initialized() else 0,
                        "exchange": (args.exchange if sharded else None),
-                       "exchange_requests": ((("one per context group (halo layout)" if args.layers > 1 else "centre rows only")) if sharded else None),
+                       "exchange_requests": ((("one per DISTINCT context group of the batch (merged on the device before the exchange; halo layout)" if args.layers > 1 else "centre rows only")) if sharded else None),
+                       "merged_groups": merged_groups,
                        "xgmi_bytes_per_step_per_rank": (round(link_bytes_per_step) if link_bytes_per_step is not None else None),
                        "replicated_store": replicated,
                        "gemm_precision": args.precision, "max_abs_dlogp_vs_f32": dlogp,
+                       "centre_state_cache": "off in the timed region (a cycled pool would be all hits); see recipe_L3 for the cached lines",
                        "synthetic_ppl": round(float(2 ** (-score_sum / tokens / np.log(2))), 4)},
             "roofline": r,
             "kernels": [roof(k_, v) for k_, v in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"])],

@@ -120,8 +120,11 @@ struct HgtBufs {
     float *hn[2], *nq, *nk, *nv;
     uint8_t* valid;
     int32_t *rows_out, *rows_kv;     // slot subsets of the elided ntgt updates
+    int32_t *win_counts;             // device-side group count (ABI 9): rows per GEMM window x multiplier
+    int32_t *nb_row;                 // merged groups on fetched codes: code row of every neighbour's centre
     int64_t Tp;
 };
+constexpr int MAX_WINDOWS = 128;
 
 bool needs_ntgt(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io) { return m.n_layers > 1 || io.out_ntgt != nullptr; }
 
@@ -141,6 +144,8 @@ void carve_hgt(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, Carver& c, HgtBuf
     b.ms = c.take<float>(Tt * d);
     b.aout = c.take<float>(Tt * d);
     b.has_nb = c.take<float>(Tt);
+    b.win_counts = io.n_unique_dev ? c.take<int32_t>(MAX_WINDOWS * 8) : nullptr;
+    b.nb_row = (io.group_ids && io.fetched_codes && !io.state_cache) ? c.take<int32_t>(Tt * io.kg) : nullptr;
     if (needs_ntgt(m, io)) {
         const int64_t S = (io.group_ids ? io.n_unique : Tt * io.kg) * (1 + m.left + m.right);
         b.hn[0] = c.take<float>(S * dmax);
@@ -159,24 +164,28 @@ void carve_hgt(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, Carver& c, HgtBuf
 }
 
 int linear(const float* A, int64_t lda, const float* W, const float* bias, float* C, int64_t M, int N, int K,
-           const float* R, float alpha, hipStream_t s) {
+           const float* R, float alpha, hipStream_t s, const int32_t* m_dev = nullptr) {
     GemmParams g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = N;
     g.bias = bias; g.bias_mode = bias ? 1 : 0;
     g.R = R; g.ldr = N; g.alpha = alpha;
     g.M = (int)M; g.N = N; g.K = K;
+    g.m_dev = m_dev;
+    if (m_dev && M > N) g.tile_order = 1;       // the walk the host-side count would have picked (gemm_nt's default assumes a small device count)
     return gemm_nt(g, s);
 }
 
 // the same on a subset of rows: logical row r reads A row rows[r] and writes C row rows[r] (both in their full layouts)
 int linear_rows(const float* A, int64_t lda, const float* W, const float* bias, float* C, int64_t ldc, const int32_t* rows,
-                int64_t n_rows, int N, int K, float alpha, hipStream_t s, int64_t rows_bound = 0) {
+                int64_t n_rows, int N, int K, float alpha, hipStream_t s, int64_t rows_bound = 0, const int32_t* m_dev = nullptr) {
     GemmParams g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = ldc;
     g.bias = bias; g.bias_mode = bias ? 1 : 0;
     g.alpha = alpha;
     g.a_rows = rows; g.c_rows = rows; g.a_rows_bound = rows_bound;
     g.M = (int)n_rows; g.N = N; g.K = K;
+    g.m_dev = m_dev;
+    if (m_dev && n_rows > N) g.tile_order = 1;
     return gemm_nt(g, s);
 }
 
@@ -193,18 +202,21 @@ int linear_rows(const float* A, int64_t lda, const float* W, const float* bias, 
 struct GroupWindows {
     int64_t G, per;       // groups, groups per window (a multiple of 128)
     int n_g;
+    const int32_t* counts = nullptr;      // device-side group count: counts[w * 8 + mult - 1] = rows of window w x mult (window_counts)
     GroupWindows(int64_t G_, int n_g_, int64_t row_bytes) : G(G_), n_g(n_g_) {
         const int64_t max_rows = ((1ll << 32) - 1) / std::max<int64_t>(row_bytes, 1);
         const int64_t max_groups = std::max<int64_t>(128, max_rows / n_g / 128 * 128);
         const int64_t n_win = std::max<int64_t>(1, cdiv(G, max_groups));
         per = std::min<int64_t>(max_groups, cdiv(cdiv(G, n_win), (int64_t)128) * 128);
     }
+    int64_t n_windows() const { return std::max<int64_t>(1, cdiv(G, per)); }
+    const int32_t* m_dev(int64_t g0, int mult) const { return counts ? counts + (g0 / per) * 8 + (mult - 1) : nullptr; }
 };
 // every slot row of every group
 int linear_windows(const GroupWindows& w, const float* A, int64_t lda, const float* W, const float* bias, float* C, int N, int K, hipStream_t s) {
     for (int64_t g0 = 0; g0 < w.G; g0 += w.per) {
         const int64_t g1 = std::min(w.G, g0 + w.per), r0 = g0 * w.n_g;
-        const int rc = linear(A + r0 * lda, lda, W, bias, C + r0 * N, (g1 - g0) * w.n_g, N, K, nullptr, 1.f, s);
+        const int rc = linear(A + r0 * lda, lda, W, bias, C + r0 * N, (g1 - g0) * w.n_g, N, K, nullptr, 1.f, s, w.m_dev(g0, w.n_g));
         if (rc != OK) return rc;
     }
     return OK;
@@ -215,7 +227,7 @@ int linear_rows_windows(const GroupWindows& w, const float* A, int64_t lda, cons
                         const int32_t* rows, int n_sel, int N, int K, hipStream_t s) {
     for (int64_t g0 = 0; g0 < w.G; g0 += w.per) {
         const int64_t g1 = std::min(w.G, g0 + w.per), r0 = g0 * w.n_g;
-        const int rc = linear_rows(A + r0 * lda, lda, W, bias, C + r0 * ldc, ldc, rows, (g1 - g0) * n_sel, N, K, 1.f, s, (g1 - g0) * w.n_g);
+        const int rc = linear_rows(A + r0 * lda, lda, W, bias, C + r0 * ldc, ldc, rows, (g1 - g0) * n_sel, N, K, 1.f, s, (g1 - g0) * w.n_g, w.m_dev(g0, n_sel));
         if (rc != OK) return rc;
     }
     return OK;
@@ -250,12 +262,18 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
     // ABI 6: the ntgt pipeline over the DISTINCT centre rows of the batch (io.group_ids); the star edges reach a group through
     // io.group_index
     const bool dedup = io.group_ids != nullptr;
-    GNNLM_REQUIRE(!dedup || (ntgt && !dense0 && !io.fetched_codes && io.group_index && io.n_unique >= 0 && !io.out_ntgt && !io.out_valid),
-                  "hgt: group_ids needs group_index, a multi-layer model on a resident store and no ntgt outputs");
+    GNNLM_REQUIRE(!dedup || (ntgt && !dense0 && io.group_index && io.n_unique >= 0 && !io.out_ntgt && !io.out_valid),
+                  "hgt: group_ids needs group_index, a multi-layer model on a code store and no ntgt outputs");
+    // ABI 9: the number of groups lives on the device; n_unique is then the capacity of the group arrays
+    const int32_t* gdev = io.n_unique_dev;
+    GNNLM_REQUIRE(!gdev || dedup, "hgt: n_unique_dev needs group_ids");
     // ABI 7: centre states kept across calls (io.state_cache): group_ids are the groups the cache lacks, group_index holds slots
     const bool cached = io.state_cache != nullptr;
     GNNLM_REQUIRE(!cached || (dedup && io.cache_cap > 0 && (io.group_slot || io.n_unique == 0) && m.n_layers > 1),
                   "hgt: state_cache needs group_ids / group_index / group_slot, cache_cap > 0 and a multi-layer model");
+    // ABI 9: merged groups on a sharded store -- the fetched slots are those of the groups; with the cache, the code rows of the
+    // cached centres live in io.code_cache (layer 0's star edges read the code of every neighbour, fetched now or not)
+    GNNLM_REQUIRE(!(cached && io.fetched_codes) || (io.code_cache && m.M % 16 == 0), "hgt: state_cache on fetched codes needs code_cache and M % 16 == 0");
     const int64_t G = dedup ? io.n_unique : Tt * kg, S = G * n_g;
     GNNLM_REQUIRE(dk % 4 == 0 && d % 4 == 0 && dpq % 4 == 0, "hgt: d_k and the PQ dimension must be multiples of 4");
     GNNLM_REQUIRE(dense0 || m.opq_at || dpq == d, "hgt: without OPQ the PQ dimension must equal d");
@@ -290,6 +308,7 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         g.n_store = m.n_store; g.row0 = m.row0; g.n_local = m.n_local;
         g.M = m.M; g.dsub = m.dsub; g.centroids = m.centroids;
         g.ids = dedup ? io.group_ids : io.ids; g.n_groups = G; g.left = m.left; g.right = m.right;
+        g.n_groups_dev = gdev;
         g.out_valid = b.valid;
         const gnnlm_hgt_layer_t& w0 = m.layers[0];
         fold0 = m.opq_at && w0.wq_n0 && w0.bq_n0 && w0.wk_n0 && w0.bk_n0 && w0.wv_n0 && w0.bv_n0;
@@ -389,6 +408,17 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             if (dedup) a.x_index = io.group_index;
             if (cached && l > 0) {
                 a.X = io.state_cache + (int64_t)(l - 1) * io.cache_cap * d; a.ldx = d; a.x_group_stride = 1;
+            } else if (l == 0 && !dense0 && dedup && io.fetched_codes) {
+                // merged groups on a sharded store: neighbour e's code row is the centre slot of its group
+                if (cached) {
+                    TRY(scatter_code_rows(io.fetched_codes, io.fetched_index, n_g, io.fetched_valid, io.code_cache, io.group_slot, gdev, G, m.M, s));
+                    a.codes = io.code_cache; a.codes_index = io.group_index;
+                } else {
+                    TRY(nb_code_rows(io.group_index, io.fetched_index, n_g, Tt * kg, b.nb_row, s));
+                    a.codes = io.fetched_codes; a.codes_index = b.nb_row;
+                }
+                a.codes_direct = 1;
+                a.row0 = 0; a.n_local = 0; a.M = m.M; a.dsub = m.dsub; a.centroids = m.centroids;
             } else if (l == 0 && !dense0) {
                 a.codes = io.fetched_codes ? io.fetched_codes : m.codes;
                 if (!io.fetched_codes) a.shards = m.shards;
@@ -437,7 +467,12 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
             const int kin = f0 ? dpq : d;
             const float *Wq = f0 ? w.wq_n0 : w.wq_n, *Bq = f0 ? w.bq_n0 : w.bq_n, *Wk = f0 ? w.wk_n0 : w.wk_n,
                         *Bk = f0 ? w.bk_n0 : w.bk_n, *Wv = f0 ? w.wv_n0 : w.wv_n, *Bv = f0 ? w.bv_n0 : w.bv_n;
-            const GroupWindows win(G, n_g, 4 * (int64_t)std::max<int64_t>(std::max<int64_t>(ld_pin, ld_hn), std::max(d, dpq)));
+            GroupWindows win(G, n_g, 4 * (int64_t)std::max<int64_t>(std::max<int64_t>(ld_pin, ld_hn), std::max(d, dpq)));
+            if (gdev) {
+                GNNLM_REQUIRE(win.n_windows() <= MAX_WINDOWS, "hgt: too many GEMM windows for a device-side group count");
+                TRY(window_counts(gdev, G, win.per, (int)win.n_windows(), b.win_counts, s));
+                win.counts = b.win_counts;
+            }
             if (all_slots) {
                 if (f0) TRY(linear_windows(win, b.hn[1], dpq, m.opq_at, m.opq_nba, b.hn[0], d, dpq, s));      // residual of every row
                 TRY(linear_windows(win, pin, ld_pin, Wq, Bq, b.nq, d, kin, s));
@@ -446,10 +481,11 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
                 ChainAttnParams ca{};
                 ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
                 ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
+                ca.n_groups_dev = gdev;
                 ca.out = b.nq; ca.ldo = d;      // in place over Q: a (group, head) task loads before it stores
                 TRY(chain_attn(ca, s));
                 TRY(linear_windows(win, b.nq, d, w.wa_n, w.ba_n, b.nk, d, d, s));
-                TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, S, d, m.ln_eps, valid, s, hn_cur, ld_hn));
+                TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, S, d, m.ln_eps, valid, s, hn_cur, ld_hn, nullptr, gdev, n_g));
             } else {
                 // slot of the position `o` relative to the centre: centre first, then o - left .. o - 1, then o + 1 .. o + right
                 auto slot = [&](int o) { return o == 0 ? 0 : (o < 0 ? m.left + 1 + o : m.left + o); };
@@ -468,14 +504,15 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
                 ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
                 ca.out = b.nq; ca.ldo = d;
                 ca.radius_p1 = rad + 1;
+                ca.n_groups_dev = gdev;
                 TRY(chain_attn(ca, s));
                 TRY(linear_rows_windows(win, b.nq, d, w.wa_n, w.ba_n, b.nk, d, b.rows_out, n_out, d, d, s));
-                TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, R_out, d, m.ln_eps, valid, s, hn_cur, ld_hn, b.rows_out));
+                TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, R_out, d, m.ln_eps, valid, s, hn_cur, ld_hn, b.rows_out, gdev, n_out));
             }
             hn_cur = hn_out;
             ld_hn = d;
             // the centre slot (row g * n_g) of every computed group -> its cache slot, for layer l + 1's star edges now and later
-            if (cached && !last) TRY(scatter_rows(hn_out, (int64_t)n_g * d, io.state_cache + (int64_t)l * io.cache_cap * d, d, io.group_slot, G, d, s));
+            if (cached && !last) TRY(scatter_rows(hn_out, (int64_t)n_g * d, io.state_cache + (int64_t)l * io.cache_cap * d, d, io.group_slot, G, d, s, gdev));
         }
         ht_in = ht_out;
     }
@@ -580,7 +617,7 @@ const char* gnnlm_target_arch(void) { return "gfx950"; }
 size_t gnnlm_sizeof(const char* name) {
     if (!name) return 0;
 #define GNNLM_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
-    GNNLM_SZ(gnnlm_gemm_t) GNNLM_SZ(gnnlm_gather_t) GNNLM_SZ(gnnlm_star_attn_t) GNNLM_SZ(gnnlm_chain_attn_t)
+    GNNLM_SZ(gnnlm_group_assign_t) GNNLM_SZ(gnnlm_gemm_t) GNNLM_SZ(gnnlm_gather_t) GNNLM_SZ(gnnlm_star_attn_t) GNNLM_SZ(gnnlm_chain_attn_t)
     GNNLM_SZ(gnnlm_adaptive_softmax_t) GNNLM_SZ(gnnlm_knn_interp_t) GNNLM_SZ(gnnlm_hgt_layer_t)
     GNNLM_SZ(gnnlm_hgt_t) GNNLM_SZ(gnnlm_hgt_io_t) GNNLM_SZ(gnnlm_profile_entry_t) GNNLM_SZ(gnnlm_topk_t) GNNLM_SZ(gnnlm_ivfpq_scan_t) GNNLM_SZ(gnnlm_ivfpq_scan8_t) GNNLM_SZ(gnnlm_ivfpq_rescore_t) GNNLM_SZ(gnnlm_ivfpq_tau_t) GNNLM_SZ(gnnlm_ivfpq_refine_t) GNNLM_SZ(gnnlm_peer_gather_t) GNNLM_SZ(gnnlm_shards_t)
 #undef GNNLM_SZ
@@ -594,6 +631,7 @@ size_t gnnlm_sizeof(const char* name) {
     }
 
 int gnnlm_gemm_nt(const gnnlm_gemm_t* d, void* stream) { GNNLM_DESC(d); return gemm_nt(*d, (hipStream_t)stream); }
+int gnnlm_group_assign(const gnnlm_group_assign_t* d, void* stream) { GNNLM_DESC(d); return group_assign(*d, (hipStream_t)stream); }
 int gnnlm_gather_rows_peer(const gnnlm_peer_gather_t* d, void* stream) { GNNLM_DESC(d); return gather_rows_peer(*d, (hipStream_t)stream); }
 int gnnlm_enable_peer_access(int32_t peer_device) {
     const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);

@@ -483,8 +483,9 @@ constexpr int MAX_EPT = 4;
 // One wave per (group, head).  Position order along the path: o-l .. o-1, o, o+1 .. o+r.
 __global__ __launch_bounds__(256) void chain_attn_kernel(ChainAttnParams p) {
     const int lane = threadIdx.x & 63;
-    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (task >= p.n_groups * p.H) return;
+    // (a device-side group count -- ABI 9 -- comes with a capped grid: the waves then walk the tasks)
+    const int64_t n_tasks = (p.n_groups_dev ? min(p.n_groups, (int64_t)*p.n_groups_dev) : p.n_groups) * p.H;
+  for (int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); task < n_tasks; task += (int64_t)gridDim.x * 4) {
     const int64_t g = task / p.H;
     const int h = (int)(task - g * p.H);
     const int n_g = 1 + p.left + p.right;
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(256) void chain_attn_kernel(ChainAttnParams p) {
             }
         }
     }
+  }
 }
 
 // One wave per score row.  Row w of matrix m: keep u <= w (and w-u < max_ctx), softmax, zero the rest
@@ -810,7 +812,8 @@ int chain_attn(const ChainAttnParams& p, hipStream_t stream) {
     if (tasks == 0) return OK;
     const double slots = (double)p.n_groups * (1 + p.left + p.right);
     ProfScope prof(K_CHAIN, stream, slots * p.H * p.dk * 12.0, slots * (16.0 * p.H * p.dk + 1.0));
-    hipLaunchKernelGGL(chain_attn_kernel, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, stream, p);
+    const int64_t wgs = cdiv(tasks, 4);
+    hipLaunchKernelGGL(chain_attn_kernel, dim3((unsigned)(p.n_groups_dev ? std::min<int64_t>(wgs, 256 * 32) : wgs)), dim3(256), 0, stream, p);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(GatherParams p) {
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int n_g = 1 + p.left + p.right;
-    const int64_t n_slots = p.n_groups * n_g;
+    const int64_t n_slots = (p.n_groups_dev ? min(p.n_groups, (int64_t)*p.n_groups_dev) : p.n_groups) * n_g;      // (device-side group count, ABI 9)
     const int D = p.M * p.dsub;
     const int nq = D / 4;                       // float4 per decoded row
     const int q_per_m = p.dsub / 4;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(GatherParams p) {
 // 16-B pieces, 8 rows per wave -- the byte-wise path above would spend a whole wave per row.
 __global__ __launch_bounds__(256) void gather_rows_kernel(GatherParams p) {
     const int per_row = p.M >> 4;                                   // 16-B pieces per row
-    const int64_t n = p.n_groups;
+    const int64_t n = p.n_groups_dev ? min(p.n_groups, (int64_t)*p.n_groups_dev) : p.n_groups;
     const int64_t total = n * per_row;
     const int64_t stride = (int64_t)gridDim.x * 256;
     // four independent (id -> row piece) chains per thread per trip: the kernel is bound by the latency of the

@@ -110,11 +110,23 @@ int causal_attn_fused(const float* Q, const float* K, const float* V, int64_t ld
 int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo,
               int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream,
               const float* residual = nullptr, int64_t ldr = 0,      // out = LN(x + residual)
-              const int32_t* rows_idx = nullptr);                    // only the rows rows_idx[0..rows) (of x, residual, out, valid)
+              const int32_t* rows_idx = nullptr,                     // only the rows rows_idx[0..rows) (of x, residual, out, valid)
+              const int32_t* n_dev = nullptr, int n_mult = 1);       // device-side count: rows = min(rows, *n_dev * n_mult)
 // idx[g * n_sel + j] = g * n_g + sel[j]
 int group_rows(int32_t* idx, int64_t n_groups, int n_g, const int* sel, int n_sel, hipStream_t stream);
 // dst[slots[g]][0..d) = src[g * ld_src][0..d) for g < n (rows of d floats, d % 4 == 0)
-int scatter_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, const int32_t* slots, int64_t n, int d, hipStream_t stream);
+int scatter_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, const int32_t* slots, int64_t n, int d, hipStream_t stream,
+                 const int32_t* n_dev = nullptr);                    // device-side count: n = min(n, *n_dev)
+
+// group assignment on the device (groups.hip, ABI 9)
+int group_assign(const gnnlm_group_assign_t& d, hipStream_t stream);
+// counts[w * 8 + mult - 1] = rows of window w (groups [w * per, (w + 1) * per) of min(*n_dev, cap)) times mult, mult = 1 .. 8
+int window_counts(const int32_t* n_dev, int64_t cap, int64_t per, int n_win, int32_t* counts, hipStream_t stream);
+// out[e] = row of the fetched buffer that holds the centre code of neighbour e's group (-1: none)
+int nb_code_rows(const int32_t* group_index, const int32_t* fetched_index, int n_g, int64_t n, int32_t* out, hipStream_t stream);
+// dst[slots[g]] = src[index ? index[g * stride] : g * stride] (zero row if valid && !valid[g * stride]) for g < min(*n_dev, cap)
+int scatter_code_rows(const uint8_t* src, const int32_t* index, int64_t stride, const uint8_t* valid, uint8_t* dst, const int32_t* slots,
+                      const int32_t* n_dev, int64_t cap, int bytes, hipStream_t stream);
 
 // out = 0.5 * (a + b)
 int mean2(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);

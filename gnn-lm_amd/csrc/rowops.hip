@@ -16,17 +16,18 @@ template <bool REGS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t ldx, const float* residual, int64_t ldr,
                                                         const float* gamma, const float* beta, float* out, int64_t ldo,
                                                         int64_t rows, int d, float eps, const uint8_t* valid,
-                                                        const int32_t* rows_idx) {
+                                                        const int32_t* rows_idx, const int32_t* n_dev, int n_mult) {
     const int lane = threadIdx.x & 63;
-    const int64_t r_ = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r_ >= rows) return;
+    // (a device-side count -- rows = min(rows, *n_dev * n_mult), ABI 9 -- comes with a capped grid: the waves walk the rows)
+    if (n_dev) rows = min(rows, (int64_t)*n_dev * n_mult);
+  for (int64_t r_ = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r_ < rows; r_ += (int64_t)gridDim.x * 4) {
     const int64_t row = rows_idx ? (int64_t)rows_idx[r_] : r_;          // a subset of the rows of x / residual / out / valid
     const float* xr = x + row * ldx;
     const float* rr = residual ? residual + row * ldr : nullptr;
     float* orow = out + row * ldo;
     if (valid && !valid[row]) {
         for (int e = lane; e < d; e += 64) orow[e] = 0.f;
-        return;
+        continue;
     }
     if constexpr (REGS) {
         float4 v[4];
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t 
         const float rstd = rsqrtf(wave_sum(v) / d + eps);
         for (int e = lane; e < d; e += 64) orow[e] = (xr[e] + (rr ? rr[e] : 0.f) - mean) * rstd * gamma[e] + beta[e];
     }
+  }
 }
 
 __global__ void mean2_kernel(const float* a, const float* b, float* out, int64_t n) {
@@ -378,19 +380,23 @@ __global__ __launch_bounds__(256) void group_rows_kernel(int32_t* idx, int64_t n
     idx[e] = (int32_t)(g * n_g + sel.c[(int)(e - g * n_sel)]);
 }
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, int64_t ld_src, float* __restrict__ dst, int64_t ld_dst,
-                                                           const int32_t* __restrict__ slots, int64_t n, int d4) {
-    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);         // one wave per row
-    if (g >= n) return;
-    const int64_t slot = slots[g];
-    if (slot < 0) return;
-    const float4* a = reinterpret_cast<const float4*>(src + g * ld_src);
-    float4* o = reinterpret_cast<float4*>(dst + slot * ld_dst);
-    for (int e = threadIdx.x & 63; e < d4; e += 64) o[e] = a[e];
+                                                           const int32_t* __restrict__ slots, int64_t n, int d4, const int32_t* n_dev) {
+    if (n_dev) n = min(n, (int64_t)*n_dev);
+    for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < n; g += (int64_t)gridDim.x * 4) {      // one wave per row
+        const int64_t slot = slots[g];
+        if (slot < 0) continue;
+        const float4* a = reinterpret_cast<const float4*>(src + g * ld_src);
+        float4* o = reinterpret_cast<float4*>(dst + slot * ld_dst);
+        for (int e = threadIdx.x & 63; e < d4; e += 64) o[e] = a[e];
+    }
 }
-int scatter_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, const int32_t* slots, int64_t n, int d, hipStream_t stream) {
+int scatter_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, const int32_t* slots, int64_t n, int d, hipStream_t stream,
+                 const int32_t* n_dev) {
     GNNLM_REQUIRE(src && dst && slots && n >= 0 && d > 0 && d % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "scatter_rows: bad arguments");
     if (n == 0) return OK;
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)cdiv(n, (int64_t)4)), dim3(256), 0, stream, src, ld_src, dst, ld_dst, slots, n, d / 4);
+    const int64_t wgs = cdiv(n, (int64_t)4);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)(n_dev ? std::min<int64_t>(wgs, 256 * 16) : wgs)), dim3(256), 0, stream, src, ld_src, dst, ld_dst,
+                       slots, n, d / 4, n_dev);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }
@@ -407,15 +413,15 @@ int group_rows(int32_t* idx, int64_t n_groups, int n_g, const int* sel, int n_se
 
 int layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo,
               int64_t rows, int d, float eps, const uint8_t* valid, hipStream_t stream, const float* residual, int64_t ldr,
-              const int32_t* rows_idx) {
+              const int32_t* rows_idx, const int32_t* n_dev, int n_mult) {
     GNNLM_REQUIRE(x && gamma && beta && out && d > 0, "layernorm: bad arguments");
     if (rows == 0) return OK;
     ProfScope prof(K_LAYERNORM, stream, 0.0, (residual ? 12.0 : 8.0) * rows * d);
     const bool a16 = ((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)residual) % 16 == 0;
     const bool regs = d <= 1024 && d % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (!residual || ldr % 4 == 0) && a16;
-    const dim3 grid((unsigned)cdiv(rows, 4)), block(256);
-    if (regs) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, stream, x, ldx, residual, ldr, gamma, beta, out, ldo, rows, d, eps, valid, rows_idx);
-    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, stream, x, ldx, residual, ldr, gamma, beta, out, ldo, rows, d, eps, valid, rows_idx);
+    const dim3 grid((unsigned)(n_dev ? std::min<int64_t>(cdiv(rows, 4), 256 * 32) : cdiv(rows, 4))), block(256);
+    if (regs) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, stream, x, ldx, residual, ldr, gamma, beta, out, ldo, rows, d, eps, valid, rows_idx, n_dev, n_mult);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, stream, x, ldx, residual, ldr, gamma, beta, out, ldo, rows, d, eps, valid, rows_idx, n_dev, n_mult);
     GNNLM_LAUNCH_CHECK();
     return OK;
 }

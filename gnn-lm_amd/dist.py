@@ -241,6 +241,11 @@ class ShardedFetcher:
         self.overflow = None                                # device counter of rows that did not fit (padded mode)
         self.link_bytes = 0                                 # bytes this rank put on / took off its xGMI links so far
         assert store.row0 == shard.store_row0 and store.codes.shape[0] == shard.store_rows
+        # fixed-capacity mode: the all-to-alls are equal-split, so EVERY rank must derive the same bucket capacity.  Ranks whose
+        # batches differ in size (a ragged last batch, an idle rank) set `fixed_requests` to the agreed largest request count of
+        # a step; `group_requests` (calibrate_groups) does the same for merged requests, whose count is data dependent
+        self.fixed_requests = None
+        self.group_requests = None
 
     def check(self):
         """Raise if the fixed-capacity exchange dropped requests (skewed ids): rerun with mode='exact' or more slack."""
@@ -248,9 +253,9 @@ class ShardedFetcher:
             raise RuntimeError(f"sharded exchange: {int(self.overflow.item())} row requests did not fit their fixed-capacity "
                                f"buckets (slack {self.slack}); use mode='exact' or a larger slack")
 
-    def _padded(self, rows, gather, row_bytes):
+    def _padded(self, rows, gather, row_bytes, requests=None):
         W = self.shard.world
-        cap = bucket_capacity(rows.numel(), W, self.slack)
+        cap = bucket_capacity(requests or rows.numel(), W, self.slack)
         back, index, ovf = exchange_fetch_padded(rows, self.shard, gather, cap, self.group, bucket=bucket_padded_hip)
         self.overflow = ovf if self.overflow is None else self.overflow + ovf
         self.link_bytes += cap * (W - 1) * 2 * (8 + row_bytes)       # ids out + payload in, and the same served to the peers
@@ -260,7 +265,7 @@ class ShardedFetcher:
         W = self.shard.world
         self.link_bytes += int(n_rows * (W - 1) / W) * 2 * (8 + row_bytes)     # uniform-id expectation
 
-    def _fetch_groups(self, ids, left, right):
+    def _fetch_groups(self, ids, left, right, cap_requests=None):
         """Halo layout: one request per context group (see exchange_fetch_groups)."""
         st, W, n_g = self.store, self.shard.world, 1 + left + right
         M = st.codes.shape[1]
@@ -271,7 +276,7 @@ class ShardedFetcher:
         G = ids.numel()
         valid = slot_rows(ids, left, right, st.n_store) >= 0
         if self.mode == "padded":
-            cap = bucket_capacity(G, W, self.slack)
+            cap = bucket_capacity((self.fixed_requests or G) if cap_requests is None else cap_requests, W, self.slack)
             codes, index, ovf = exchange_fetch_groups(ids, left, right, self.shard, gather, self.group, cap, bucket_padded_hip)
             self.overflow = ovf if self.overflow is None else self.overflow + ovf
             self.link_bytes += cap * (W - 1) * 2 * (8 + n_g * M)
@@ -280,6 +285,42 @@ class ShardedFetcher:
             codes, index, _ = exchange_fetch_groups(ids, left, right, self.shard, gather, self.group, 0, bucket_hip)
             self._account_exact(G, n_g * M)
         return codes, valid.to(torch.uint8), index
+
+    def calibrate_groups(self, counters, slack=1.15):
+        """Fixed-capacity mode, merged requests: size the buckets from a MEASURED distinct-group count instead of the worst case
+        (every neighbour its own group).  ``counters``: the device counters of a representative merged step
+        (``HGT._last_groups[1]``).  Synchronises and all-reduces (MAX) -- every rank must end up with the same capacity, the
+        all-to-alls are equal-split -- so call it in a warm-up phase, never inside a timed region.  A later batch with more
+        distinct groups than measured x slack overflows its buckets: counted, and raised by :meth:`check`."""
+        t = counters[:1].to(torch.int64).clone()
+        if self.shard.world > 1:
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+                t = h
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self.group_requests = int(int(t.item()) * slack) + 1024
+        return self.group_requests
+
+    def fetch_groups(self, centres, left, right, counters):
+        """The slots of MERGED context groups (HGT.forward, multi-layer models): ``centres`` int64 [n] are the distinct centre rows
+        of a batch -- the first ``counters[0]`` entries (a device-side count, gnnlm_group_assign), -1 after them -- so every row is
+        requested from its owner once however many tokens retrieved it.  -> (codes uint8 [P, M], valid uint8 [n' * n_g],
+        index int32 [n' * n_g]): slot c of group g lives in row index[g * n_g + c].  Exact mode reads the count (its exchange
+        synchronises for the split sizes anyway) and requests exactly that many groups; padded mode stays sync-free."""
+        n_g, st, W = 1 + left + right, self.store, self.shard.world
+        M = st.codes.shape[1]
+        halo = self.shard.halo_left >= left and self.shard.halo_right >= right
+        if self.mode == "exact":
+            centres = centres[:int(counters[0].item())]
+            if not halo or n_g == 1:
+                return self.fetch_codes(centres.view(-1, 1), left, right, False)
+            return self._fetch_groups(centres, left, right)
+        if not halo or n_g == 1:
+            raise NotImplementedError("padded exchange of merged groups needs halo shards (Shard(halo_left, halo_right))")
+        worst = self.fixed_requests or centres.numel()
+        return self._fetch_groups(centres, left, right, cap_requests=min(worst, self.group_requests) if self.group_requests else worst)
 
     def _gather_codes(self, rows):
         st = self.store
@@ -299,7 +340,8 @@ class ShardedFetcher:
         rows = ids.reshape(-1) if centres_only else slot_rows(ids, left, right, self.store.n_store)
         rows = torch.where((rows >= 0) & (rows < self.store.n_store), rows, torch.full_like(rows, -1))
         if self.mode == "padded":
-            codes, index, cap = self._padded(rows, self._gather_codes, self.store.codes.shape[1])
+            req = self.fixed_requests * (1 if centres_only else 1 + left + right) if self.fixed_requests else None
+            codes, index, cap = self._padded(rows, self._gather_codes, self.store.codes.shape[1], req)
             return codes, ((rows >= 0) & (index.long() < self.shard.world * cap)).to(torch.uint8), index
         self._account_exact(rows.numel(), self.store.codes.shape[1])
         codes, index = exchange_fetch(rows, self.shard, self._gather_codes, self.group, bucket=bucket_hip, unpermute=False)
@@ -379,6 +421,10 @@ class PeerMappedFetcher:
         codes = torch.empty(rows.numel(), M, dtype=torch.uint8, device=ids.device)
         valid = self._gather(rows, "codes", M, codes)
         return codes, valid, torch.arange(rows.numel(), dtype=torch.int32, device=ids.device)
+
+    def fetch_groups(self, centres, left, right, counters):
+        """Merged groups (see ShardedFetcher.fetch_groups); consumers that hold the mapped store (`mapped_store`) never call this."""
+        return self.fetch_codes(centres.view(-1, 1), left, right, False)
 
     def fetch_knn_vals(self, knn_ids):
         assert self.share_vals, "built without the label shards"

@@ -41,9 +41,12 @@ class BlockBatch:
 
 class GnnLmEngine:
     def __init__(self, hgt: HGT, asm: AdaptiveSoftmax, store: CodeStore, left: int, right: int,
-                 max_intra_context: int = 0):
+                 max_intra_context: int = 0, fetcher=None, fetch_vals: bool = False):
         self.hgt, self.asm, self.store = hgt, asm, store
         self.left, self.right, self.max_intra_context = left, right, max_intra_context
+        # range-sharded store (dist.ShardedFetcher): the code rows -- and, with fetch_vals, the labels of the kNN ids -- are
+        # fetched from their owners inside the step (batches that bring their own fetched_* / knn_vals keep them)
+        self.fetcher, self.fetch_vals = fetcher, fetch_vals
 
     def features(self, batch: BlockBatch) -> torch.Tensor:
         """gcn_feat: HGT output for every token [n_blocks*T, d] (transformer.py:997)."""
@@ -53,7 +56,7 @@ class GnnLmEngine:
         G = NeighborGraph(ids=batch.ids, n_blocks=batch.n_blocks, T=batch.T, left=self.left, right=self.right,
                           store=self.store, fetched_codes=batch.fetched_codes, fetched_valid=batch.fetched_valid,
                           fetched_centres_only=batch.fetched_centres_only, fetched_index=batch.fetched_index,
-                          max_intra_context=self.max_intra_context)
+                          max_intra_context=self.max_intra_context, fetcher=self.fetcher if batch.fetched_codes is None else None)
         return self.hgt(G, features={"tgt": tgt})["tgt"]
 
     def score(self, batch: BlockBatch, lmbda: float = 0.0, temperature: float = 1.0):
@@ -64,9 +67,12 @@ class GnnLmEngine:
         if lmbda > 0.0:                                          # sequence_scorer.py:102
             if batch.knn_sims is None or batch.knn_ids is None:
                 raise ValueError("lmbda > 0 needs knn_sims / knn_ids (results of the kNN search)")
+            knn_vals = batch.knn_vals
+            if knn_vals is None and self.fetcher is not None and self.fetch_vals:
+                knn_vals = self.fetcher.fetch_knn_vals(batch.knn_ids)
             logp, p_knn, recall = ops.knn_interp(
                 lm_logp, batch.knn_sims, batch.knn_ids, batch.targets, temperature, lmbda,
                 vals=self.store.vals, n_store=self.store.n_store,
-                row0=getattr(self.store, "vals_row0", self.store.row0), knn_vals=batch.knn_vals)
+                row0=getattr(self.store, "vals_row0", self.store.row0), knn_vals=knn_vals)
             out.update(logp=logp, p_knn=p_knn, recall=recall)
         return out

@@ -89,7 +89,21 @@ def get_parser():
     p.add_argument("--remove-bpe", nargs="?", const="@@ ", default=None)
     p.add_argument("--add-bos-token", action="store_true", default=False)
     p.add_argument("--log-format", default=None)
-    p.add_argument("--device", default="cuda:0")
+    p.add_argument("--device", default="cuda:0", help="(this build) one process: the device; under torch.distributed.run every rank takes "
+                                                      "cuda:LOCAL_RANK")
+    p.add_argument("--store", choices=["auto", "replicated", "sharded", "peer"], default="auto",
+                   help="(this build) multi-GPU runs (one process per GPU, `python -m torch.distributed.run --nproc-per-node N -m "
+                        "gnnlm_amd.eval_lm ...`): where the PQ code table lives.  replicated: every rank holds all of it, no exchange; "
+                        "sharded: by key range across the ranks (rank g owns rows [g*ceil(N/R), (g+1)*ceil(N/R)) plus a halo of the "
+                        "context sizes), rows fetched from their owners by an RCCL all-to-all, equal context groups merged BEFORE the "
+                        "exchange; peer: range shards mapped into every rank (HIP IPC), the kernels read rows from their owner's HBM "
+                        "over xGMI themselves.  auto: sharded when WORLD_SIZE > 1, else the one table")
+    p.add_argument("--result-json", default=None,
+                   help="(this build) write the run's figures (score_sum, count, ppl, tokens, seconds, per-rank sums, xGMI bytes) to this "
+                        "file as JSON; in a multi-process run rank r writes PATH.rank<r> and rank 0 also PATH")
+    p.add_argument("--exchange", choices=["exact", "padded"], default="exact",
+                   help="(this build) --store sharded: variable-split exchange that never drops a row (default), or the fixed-capacity "
+                        "sync-free one (checked at the end of the run)")
     return p
 
 
@@ -252,7 +266,8 @@ def check_tables(args, info, n_store):
         logger.info("targets of %s_dstore/vals.npy == token stream of %s.bin (%d tokens)", split, split, n_tok)
 
 
-def load_tables(args, device):
+def load_tables(args, device, shard=None):
+    """``shard`` (dist.Shard): upload only the rows of the code table this rank holds (its key range plus the halo)."""
     split, data = args.gen_subset, args.data
     info = json.load(open(os.path.join(dstore_path(data, split), "info.json")))
     tinfo = json.load(open(os.path.join(dstore_path(data, "train"), "info.json")))        # language_modeling.py:266-272
@@ -271,8 +286,13 @@ def load_tables(args, device):
                          f"[{tinfo['dstore_size']}, M] (one code row per key of train_dstore)")
     up = lambda a: torch.from_numpy(np.array(a)).to(device)
     tg = up(targets).long()
+    if shard is not None:
+        if shard.n_store != tinfo["dstore_size"]:
+            raise ValueError("the shard was laid out for another store size")
+        codes = codes[shard.store_row0:shard.store_row0 + shard.store_rows]
     return {"n_tok": n_tok, "d": d, "vocab": info.get("vocab_size"), "n_store": tinfo["dstore_size"],
             "feats": up(feats), "targets": tg, "nbrs": up(nbrs), "codes": up(codes),
+            "codes_row0": shard.store_row0 if shard is not None else 0,
             "no_pad": not bool(tg.eq(_Dict().pad()).any())}           # one look at the split instead of one sync per hypothesis
 
 
@@ -294,20 +314,63 @@ def main(args, tables=None, model=None):
         raise NotImplementedError("--context-window > 0 is not built (the GNN-LM recipes use --gcn-context-window)")
     if args.fp16:
         logger.warning("--fp16 ignored: the HIP path computes in float32")
-    device = torch.device(args.device)
-    torch.cuda.set_device(device)
-    tabs = tables if tables is not None else load_tables(args, device)
+    # ---- one process per GPU (torch.distributed.run): token blocks are data parallel, the code table is range-sharded
+    # (the reference has no multi-GPU eval path to mirror beyond --num-shards, fairseq_cli/eval_lm.py:131-132)
+    dist = torch.distributed
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    own_group = False
+    if world > 1:
+        device = torch.device("cuda", int(os.environ.get("GNNLM_EVAL_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+        torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            backend = os.environ.get("GNNLM_EVAL_BACKEND", "nccl")                          # "gloo": tests, several ranks on one GPU
+            if backend != "nccl":
+                os.environ["GNNLM_TEST_HOST_STAGED"] = "1"
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            own_group = True
+        if args.save_knnlm_dstore:
+            raise NotImplementedError("--save-knnlm-dstore writes ONE datastore: run it with one process")
+    else:
+        device = torch.device(args.device)
+        torch.cuda.set_device(device)
+    store_mode = args.store if args.store != "auto" else ("sharded" if world > 1 else "replicated")
+    if world == 1 and store_mode != "replicated" and not os.environ.get("GNNLM_EVAL_FORCE_EXCHANGE"):
+        store_mode = "replicated"                                                           # one rank owns every row
+    nc = ast.literal_eval(str(args.neighbor_context))                                      # language_modeling.py:295
+    left, right = (nc, nc) if isinstance(nc, int) else nc
+    shard = None
+    if store_mode != "replicated":
+        from .dist import Shard
+        n_store = tables["n_store"] if tables is not None else \
+            json.load(open(os.path.join(dstore_path(args.data, "train"), "info.json")))["dstore_size"]
+        shard = Shard(n_store, world, rank, halo_left=left, halo_right=right)
+    tabs = tables if tables is not None else load_tables(args, device, shard)
     overrides = ast.literal_eval(args.model_overrides)
     if model is None:
         model, margs = GnnLmModel.from_checkpoint(args.path, device, overrides, vocab_size=tabs["vocab"])
-    nc = ast.literal_eval(str(args.neighbor_context))                                      # language_modeling.py:295
-    left, right = (nc, nc) if isinstance(nc, int) else nc
-    store = model.make_store(tabs["codes"], tabs["n_store"], device)
+    fetcher = None
+    if shard is None:
+        store = model.make_store(tabs["codes"], tabs["n_store"], device)
+    else:
+        from .dist import PeerMappedFetcher, ShardedFetcher
+        codes = tabs["codes"]
+        if codes.shape[0] != shard.store_rows:                                             # (resident tables handed in whole: cut this rank's rows)
+            codes = codes[shard.store_row0:shard.store_row0 + shard.store_rows].contiguous()
+        store = model.make_store(codes, tabs["n_store"], device, row0=shard.store_row0)
+        if store_mode == "peer":
+            store = PeerMappedFetcher(store, shard).mapped_store()                          # the kernels read every row from its owner themselves
+        else:
+            fetcher = ShardedFetcher(store, shard, mode=args.exchange)
     T = args.tokens_per_sample - args.context_window
     blocks = [r + (bid,) for bid, r in enumerate(block_ranges(tabs["n_tok"], T, args.gcn_context_window))]   # (context start, start, end, sample id)
     if args.first > 0:
         blocks = blocks[:args.first]
     blocks = blocks[args.shard_id::args.num_shards]                                        # eval_lm.py:131-132
+    if world > 1:                                                                          # this rank's contiguous share of the blocks
+        per_rank = -(-len(blocks) // world)
+        blocks = blocks[rank * per_rank:(rank + 1) * per_rank]
     per_batch = max(1, (args.max_tokens or 36000) // max(1, T + args.gcn_context_window))
     if args.max_sentences:
         per_batch = min(per_batch, args.max_sentences)
@@ -370,17 +433,33 @@ def main(args, tables=None, model=None):
     if args.output_knn_recall and not args.knnlm:
         raise ValueError("--output-knn-recall needs --knnlm (the scorer returns no recall otherwise)")
     acc = torch.zeros(1, device=device, dtype=torch.float64)
+    hyp_sums = []
     count, ntok = 0, 0
     timers = []             # gen_timer (eval_lm.py:214-219) as HIP event pairs on the stream: no per-batch host sync
-    i = 0
-    torch.cuda.synchronize()
-    wall0 = time.perf_counter()
+    # the batches of this rank: runs of equally long blocks, up to per_batch of them
+    batches_, i = [], 0
     while i < len(blocks):
         group = [blocks[i]]
         while len(group) < per_batch and i + len(group) < len(blocks) and \
                 (blocks[i + len(group)][2] - blocks[i + len(group)][0]) == (group[0][2] - group[0][0]):
             group.append(blocks[i + len(group)])
         i += len(group)
+        batches_.append(group)
+    idle_steps = 0
+    if fetcher is not None and world > 1:
+        # the exchange is a collective: every rank takes part in as many of them as the rank with the most batches
+        t = torch.tensor([len(batches_)], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        idle_steps = int(t.item()) - len(batches_)
+        if args.exchange == "padded":
+            # equal-split all-to-alls: every rank sizes its buckets from the SAME request count, the largest batch of any rank
+            t = torch.tensor([max((len(g_) * (g_[0][2] - g_[0][0]) for g_ in batches_), default=0) * args.gcn_k], dtype=torch.int64, device=t.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fetcher.fixed_requests = int(t.item())
+    deep = getattr(getattr(model, "hgt_decoder", None), "n_layers", 1) > 1
+    torch.cuda.synchronize()
+    wall0 = time.perf_counter()
+    for group in batches_:
         L = group[0][2] - group[0][0]
         if all(group[j + 1][0] == group[j][2] for j in range(len(group) - 1)):
             idx = slice(group[0][0], group[-1][2])           # back-to-back blocks (no --gcn-context-window): plain views, no gather
@@ -392,7 +471,7 @@ def main(args, tables=None, model=None):
             tok_pos = torch.arange(idx.start, idx.stop, device=device) if isinstance(idx, slice) else idx     # global offsets in the split
             nb_ids = ops.filter_neighbors(nb_ids, tok_pos.contiguous(), invalid_ctx)
         graph = NeighborGraph(ids=nb_ids, n_blocks=len(group), T=L, left=left, right=right,
-                              store=store, tgt_h=tabs["feats"][idx].contiguous(), max_intra_context=args.intra_context)
+                              store=store, tgt_h=tabs["feats"][idx].contiguous(), max_intra_context=args.intra_context, fetcher=fetcher)
         sample = {"id": torch.tensor([g_[3] for g_ in group]), "nsentences": len(group), "ntokens": len(group) * L,
                   "net_input": {"src_tokens": target, "src_lengths": torch.full((len(group),), L), "graph": graph},
                   "target": target, "start_indices": [g_[1] - g_[0] for g_ in group]}
@@ -422,9 +501,21 @@ def main(args, tables=None, model=None):
             save["idx"] += n_new
         pos = torch.cat([h[0]["positional_scores"].float().reshape(-1) for h in hypos])     # one launch per batch
         ops.masked_sum_f64(pos, None, acc)                                                  # score_sum (:273), in f64
+        # ... and as the reference adds it up: one float32 sum per hypothesis (`pos_scores.sum()`), accumulated in a float32 scalar
+        # (`score_sum += ...cpu()`, :273) -- the per-hypothesis sums are kept on the device and chained on the host at the end
+        lens = [h[0]["positional_scores"].numel() for h in hypos]
+        hyp_sums.append(pos.view(len(hypos), -1).sum(dim=1) if len(set(lens)) == 1 and lens[0] > 0 else
+                        torch.stack([h[0]["positional_scores"].float().sum() for h in hypos]))
         count += pos.numel()                                                                # :274
         if want_words or bpe_toks is not None:
             count -= word_outputs(args, hypos, sample["id"], symbols, bpe_toks, bpe_len, word_stats)     # skipped_toks (:274)
+    for _ in range(idle_steps):                                                             # no batch left here: serve the peers' requests
+        if deep and getattr(model.hgt_decoder, "dedup_groups", False):
+            fetcher.fetch_groups(torch.empty(0, dtype=torch.int64, device=device), left, right, torch.zeros(4, dtype=torch.int32, device=device))
+        else:
+            fetcher.fetch_codes(torch.empty(0, args.gcn_k, dtype=torch.int64, device=device), left, right, not deep)
+    if fetcher is not None:
+        fetcher.check()                                                                     # (padded exchange: nothing was dropped)
     score_sum = acc.item()                                                                  # the only host sync
     if save is not None:
         save["keys"].flush()
@@ -432,22 +523,50 @@ def main(args, tables=None, model=None):
         logger.info(f"Saved {save['idx']} data to {save['dir']}")                           # :322-323
     wall = time.perf_counter() - wall0                                                      # the loop as a whole ("wps", :316)
     gen_time = sum(a.elapsed_time(b) for a, b in timers) / 1e3
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        t = torch.tensor([score_sum, float(count)], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t)
-        score_sum, count = t[0].item(), int(t[1].item())
+    rank_score_sum, rank_tokens = score_sum, ntok
+    score_sum_f32 = np.float32(0.0)
+    if hyp_sums:
+        for v in torch.cat(hyp_sums).cpu().numpy():                                         # float32 + float32, hypothesis by hypothesis
+            score_sum_f32 = np.float32(score_sum_f32 + v)
+    count_rank = count
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # the one reduction of the data-parallel run (16 B + the timer): score_sum, count, tokens summed; the time is the slowest rank's
+        host = dist.get_backend() != "nccl"
+        t = torch.tensor([score_sum, float(count), float(ntok)], device="cpu" if host else device, dtype=torch.float64)
+        dist.all_reduce(t)
+        tm = torch.tensor([gen_time, wall], device="cpu" if host else device, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        score_sum, count, ntok = t[0].item(), int(t[1].item()), int(t[2].item())
+        gen_time, wall = tm[0].item(), tm[1].item()
     avg_nll_loss = -score_sum / count / math.log(2)
     line1 = "Evaluated {} tokens in {:.1f}s ({:.2f} tokens/s)".format(ntok, gen_time, ntok / max(gen_time, 1e-9))
     line2 = "Loss (base 2): {:.4f}, Perplexity: {:.2f}".format(avg_nll_loss, 2 ** avg_nll_loss)
-    logger.info(line1)
-    logger.info(line2)
-    print(line1)
-    print(line2)
+    if rank == 0 or not (dist.is_available() and dist.is_initialized()):
+        logger.info(line1)
+        logger.info(line2)
+        print(line1)
+        print(line2)
+    # the same with the reference's float32 accumulation (fairseq_cli/eval_lm.py:273-274): logged, not printed --
+    # the two lines above are the reference's output.  Per rank in a multi-process run (the reference has one accumulator).
+    if count_rank:
+        nll32 = -float(score_sum_f32) / count_rank / math.log(2)
+        logger.info("float32 accumulation order (as the reference, rank {}): Loss (base 2): {:.4f}, Perplexity: {:.2f}".format(rank, nll32, 2 ** nll32))
     if args.output_word_stats:                                                              # :333-336
         for ws in sorted(word_stats.values(), key=lambda x: x.count, reverse=True):
             logger.info(ws)
-    return {"score_sum": score_sum, "count": count, "ppl": 2 ** avg_nll_loss, "tokens": ntok, "seconds": gen_time,
-            "wall_seconds": wall, "word_stats": word_stats if args.output_word_stats else None}
+    link_bytes = getattr(fetcher, "link_bytes", None)
+    if own_group:
+        dist.destroy_process_group()
+    res = {"score_sum": score_sum, "count": count, "ppl": 2 ** avg_nll_loss, "tokens": ntok, "seconds": gen_time,
+            "wall_seconds": wall, "word_stats": word_stats if args.output_word_stats else None,
+            "score_sum_f32_order": float(score_sum_f32), "rank": rank, "world": world, "store": store_mode, "rank_score_sum": rank_score_sum, "rank_tokens": rank_tokens,
+            "xgmi_bytes": link_bytes}
+    if getattr(args, "result_json", None):
+        js = {k_: v for k_, v in res.items() if k_ != "word_stats"}
+        for path in ([args.result_json + f".rank{rank}"] if world > 1 else []) + ([args.result_json] if rank == 0 else []):
+            with open(path, "w") as fh:
+                json.dump(js, fh)
+    return res
 
 
 def cli_main(argv=None):

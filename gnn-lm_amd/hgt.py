@@ -82,6 +82,10 @@ class NeighborGraph:
     fetched_centres_only: bool = False
     fetched_index: Optional[torch.Tensor] = None    # int32: slot s lives in row fetched_index[s] of fetched_codes
     max_intra_context: int = 0
+    # sharded store: the object that fetches code rows from their owners (dist.ShardedFetcher / PeerMappedFetcher interface:
+    # fetch_codes(ids, left, right, centres_only), fetch_groups(centres, left, right, counters)).  HGT.forward then fetches itself
+    # -- for a multi-layer model AFTER merging equal context groups, so every distinct centre row is requested once.
+    fetcher: Optional[object] = None
 
     @property
     def kg(self):
@@ -188,6 +192,24 @@ def prepare_hgt_weights(sd: Dict[str, torch.Tensor], n_layers: int, n_heads: int
     return layers, codec
 
 
+def _group_assign(flat_ids, n_store, slot_of, cache=None):
+    """gnnlm_group_assign on the current stream -> (group_ids int64 [n], group_slot int32 [n] | None, group_index int32 [n],
+    counters int32 [4] on the device: [0] = number of groups).  No host synchronisation."""
+    n, dev = flat_ids.numel(), flat_ids.device
+    d = _lib.gnnlm_group_assign_t()
+    group_ids = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    group_index = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    counters = torch.empty(4, dtype=torch.int32, device=dev)
+    group_slot = None
+    d.ids, d.n, d.n_store = flat_ids.data_ptr(), n, n_store
+    d.slot_of, d.group_ids, d.group_index, d.counters = slot_of.data_ptr(), group_ids.data_ptr(), group_index.data_ptr(), counters.data_ptr()
+    if cache is not None:
+        group_slot = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        d.id_of_slot, d.cache_state, d.cache_cap, d.group_slot = cache.id_of_slot.data_ptr(), cache.state.data_ptr(), cache.capacity, group_slot.data_ptr()
+    _lib.call_desc("gnnlm_group_assign", d)
+    return group_ids, group_slot, group_index, counters
+
+
 class CentreStateCache:
     """Cross-batch cache of the context groups' centre states (``gnnlm_hgt_io_t.state_cache``).
 
@@ -198,68 +220,54 @@ class CentreStateCache:
     keeps ``[n_layers - 1, capacity, d]`` float32 states in HBM and a direct row -> slot table (int32 per datastore row: no
     hashing).  Slots are filled in arrival order in TWO GENERATIONS (the halves of the table): when the current half is full
     the other one is emptied and refilled, so the more recent half of what was computed always survives.  Exact: the states
-    are the ones the un-cached call computes."""
+    are the ones the un-cached call computes.
 
-    def __init__(self, n_store, n_layers, d, capacity, device):
+    Everything that decides -- hit or miss, the slot of a new row, the generation switch -- runs on the DEVICE
+    (``gnnlm_group_assign``, csrc/groups.hip): the bookkeeping (`state`: half being filled, entries per half, switches, rows
+    computed) lives in device memory and a call never synchronises; `stats` / `used` read it back (and do)."""
+
+    def __init__(self, n_store, n_layers, d, capacity, device, code_bytes=0):
         self.n_store, self.capacity, self.device = n_store, int(capacity), device
-        self.half = max(1, self.capacity // 2)
+        self.half = self.capacity // 2
         self.slot_of = torch.full((n_store,), -1, dtype=torch.int32, device=device)
         self.id_of_slot = torch.empty(self.capacity, dtype=torch.int64, device=device)
         self.states = torch.empty(n_layers - 1, self.capacity, d, dtype=torch.float32, device=device)
-        self.gen, self.fill = 0, [0, 0]                                       # the half being filled, entries in each half
+        # sharded store: the PQ code row of every cached centre (layer 0's star edges read the code of every neighbour, and only the
+        # rows the cache lacks are fetched from their owners)
+        self.codes = torch.zeros(self.capacity, code_bytes, dtype=torch.uint8, device=device) if code_bytes else None
+        self.state = torch.zeros(8, dtype=torch.int32, device=device)       # gnnlm_group_assign_t.cache_state
         self.stream = torch.cuda.current_stream(device).cuda_stream          # slots are reused in stream order: one stream only
-        self.stats = {"lookups": 0, "groups": 0, "computed": 0, "generations": 1}
+        self._host = {"lookups": 0, "groups": 0, "clears": 0, "computed0": 0}
+
+    @property
+    def stats(self):
+        st = self.state.tolist()                                             # (synchronises: a reporting path)
+        return {"lookups": self._host["lookups"], "groups": self._host["groups"], "computed": st[4] - self._host["computed0"],
+                "generations": 1 + st[3] + self._host["clears"]}
+
+    def reset_stats(self):
+        self._host.update(lookups=0, groups=0, computed0=int(self.state[4].item()))
 
     @property
     def used(self):
-        return self.fill[0] + self.fill[1]
-
-    def _drop(self, g):
-        if self.fill[g]:
-            lo = g * self.half
-            self.slot_of[self.id_of_slot[lo:lo + self.fill[g]]] = -1
-        self.fill[g] = 0
+        st = self.state.tolist()
+        return st[1] + st[2]
 
     def clear(self):
-        self._drop(0)
-        self._drop(1)
-        self.gen = 0
-        self.stats["generations"] += 1
-
-    def _room(self, g):
-        return (self.half if g == 0 else self.capacity - self.half) - self.fill[g]
+        self.slot_of.fill_(-1)
+        self.state[:3] = 0
+        self._host["clears"] += 1
 
     def assign(self, flat_ids):
-        """flat_ids int64 [n]: neighbour rows (-1 / out of range: none) -> (miss_ids int64 [m] ascending, miss_slots int32 [m],
-        slot int32 [n] with -1 for "not a neighbour"), or None when the batch's new groups alone exceed a generation.
-        One host sync (the number of new groups), like the within-batch merge it extends."""
-        valid = (flat_ids >= 0) & (flat_ids < self.n_store)
-        key = torch.where(valid, flat_ids, torch.zeros_like(flat_ids))
-        none = torch.full_like(key, -1, dtype=torch.int32)
-        slot = torch.where(valid, self.slot_of[key], none)
-        miss = torch.unique(key[valid & (slot < 0)])
-        if miss.numel() > self._room(self.gen):
-            # the current generation is full: the OTHER (older) half is emptied and becomes the one being filled; what this batch
-            # found there has to be computed again
-            self.gen ^= 1
-            self._drop(self.gen)
-            self.stats["generations"] += 1
-            slot = torch.where(valid, self.slot_of[key], none)
-            miss = torch.unique(key[valid & (slot < 0)])
-            if miss.numel() > self._room(self.gen):
-                return None
-        m = miss.numel()
-        lo = self.gen * self.half + self.fill[self.gen]
-        new = torch.arange(lo, lo + m, dtype=torch.int32, device=self.device)
-        if m:
-            self.slot_of[miss] = new
-            self.id_of_slot[lo:lo + m] = miss
-            self.fill[self.gen] += m
-            slot = torch.where(valid, self.slot_of[key], none)
-        self.stats["lookups"] += 1
-        self.stats["groups"] += int(flat_ids.numel())
-        self.stats["computed"] += m
-        return miss, new, slot.contiguous()
+        """flat_ids int64 [n]: neighbour rows (-1 / out of range: none) -> (rows to compute int64 [n] of which the first
+        counters[0] count, their slots int32 [n], slot of every neighbour int32 [n] (-1: not a neighbour), counters), or None
+        when a batch of n neighbours may not fit one generation (n > capacity / 2: the caller merges within the batch only)."""
+        if flat_ids.numel() > self.half:
+            return None
+        out = _group_assign(flat_ids, self.n_store, self.slot_of, self)
+        self._host["lookups"] += 1
+        self._host["groups"] += int(flat_ids.numel())
+        return out
 
 
 class HGT(nn.Module):
@@ -289,11 +297,20 @@ class HGT(nn.Module):
         self._prepared = None
         self.gemm_precision = 0     # 0 exact f32 MFMA | 1 bf16x3 | 2 bf16x6 (opt-in split-bf16 emulation)
         self.dedup_groups = os.environ.get("GNNLM_DEDUP", "1") != "0"      # merge equal context groups of a batch (multi-layer models)
-        self.last_groups = None                                              # (groups of the last batch, distinct ones)
+        self._last_groups = None                                             # (groups of the last batch, device counter of the computed ones)
+        self._merge_tables = {}                                              # (device, n_store, stream) -> row -> group table of the within-batch merge
         # centre states of context groups kept ACROSS batches (CentreStateCache): HBM budget in GiB, 0 = off
         self.state_cache_gib = float(os.environ.get("GNNLM_STATE_CACHE_GIB", "32"))
         self.state_cache_slots = None
         self.state_cache = None
+
+    @property
+    def last_groups(self):
+        """(context groups of the last batch, groups its ntgt pipeline ran over); reads a device counter (synchronises)."""
+        if self._last_groups is None:
+            return None
+        n, counters = self._last_groups
+        return n, (int(counters[0].item()) if torch.is_tensor(counters) else counters)
 
     def _load_from_state_dict(self, *a, **k):
         self._prepared = None
@@ -335,26 +352,55 @@ class HGT(nn.Module):
                           "store": store}
         return self._prepared
 
-    def _state_cache_for(self, prep, store, device):
-        """The centre-state cache of (these weights, this store), or None (off, another stream, stale)."""
+    def _state_cache_for(self, prep, G, device):
+        """The centre-state cache of (these weights, this store, this graph shape), or None (off, another stream)."""
         if self.state_cache_gib <= 0 or self.n_layers < 2:
             return None
+        store = G.store
         c = self.state_cache
-        key = (prep["key"], id(store), store.codes.data_ptr(), store.n_store)
+        # everything the cached states are a function of: the folded weights (prep key: parameters + codec), the GEMM arithmetic,
+        # the context shape, and the code table itself (identity AND in-place version)
+        key = (prep["key"], id(store), store.codes.data_ptr(), store.codes._version, store.n_store, self.gemm_precision,
+               G.left, G.right, G.max_intra_context, G.fetcher is not None)
         if c is not None and (getattr(c, "key", None) != key):
-            c = self.state_cache = None                                       # other weights / another store: the states are stale
+            c = self.state_cache = None                                       # other weights / store / arithmetic: the states are stale
         if c is None:
-            per = (self.n_layers - 1) * self.hidden_dim * 4 + 8
-            cap = int(min(store.n_store, max(0, self.state_cache_gib * 2 ** 30 - 4 * store.n_store) // per))
+            if torch.cuda.is_current_stream_capturing():
+                return None                                                   # (persistent tables are not born inside a capture)
+            code_bytes = store.codes.shape[1] if G.fetcher is not None else 0
+            per = (self.n_layers - 1) * self.hidden_dim * 4 + 8 + code_bytes
+            budget = self.state_cache_gib * 2 ** 30
+            if self.state_cache_slots is None:                                # never more than half of what is free right now
+                budget = min(budget, 0.5 * torch.cuda.mem_get_info(device)[0])
+            cap = int(min(store.n_store, max(0, budget - 4 * store.n_store) // per))
             if self.state_cache_slots is not None:                            # explicit capacity (tests, tuning)
-                cap = int(min(store.n_store, self.state_cache_slots))
-            if cap < 1:
+                cap = int(min(2 * store.n_store, self.state_cache_slots))
+            if cap < 2:
                 return None
-            c = self.state_cache = CentreStateCache(store.n_store, self.n_layers, self.hidden_dim, cap, device)
+            try:
+                c = CentreStateCache(store.n_store, self.n_layers, self.hidden_dim, cap, device, code_bytes)
+            except torch.OutOfMemoryError:
+                self.state_cache_gib = 0.0                                    # run un-cached rather than fail
+                return None
+            self.state_cache = c
             c.key = key
         if c.stream != torch.cuda.current_stream(device).cuda_stream:
             return None
         return c
+
+    def _merge_table(self, n_store, device):
+        """Row -> group table of the within-batch merge (int32 per datastore row, all -1 between calls), one per stream.
+        Persistent tables (this one, the centre-state cache) are never born inside a HIP-graph capture -- they would live in the
+        graph's private pool: a step captured on a stream that has not run an eager forward yet is captured UN-merged (same
+        results).  To capture the merged step, run one eager forward on a stream and capture on it
+        (`torch.cuda.graph(g, stream=that_stream)`)."""
+        key = (str(device), n_store, torch.cuda.current_stream(device).cuda_stream)
+        t = self._merge_tables.get(key)
+        if t is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            t = self._merge_tables[key] = torch.full((n_store,), -1, dtype=torch.int32, device=device)
+        return t
 
     @staticmethod
     def _bind_store(m, store):
@@ -409,42 +455,62 @@ class HGT(nn.Module):
         io.n_blocks, io.T, io.kg = G.n_blocks, G.T, G.kg
         ids = G.ids.contiguous()
         io.tgt_feats, io.ids = tgt.data_ptr(), ids.data_ptr()
-        if G.fetched_codes is not None:
-            io.fetched_codes = G.fetched_codes.data_ptr()
-            if G.fetched_valid is not None:
-                io.fetched_valid = G.fetched_valid.data_ptr()
-            io.fetched_centres_only = int(G.fetched_centres_only)
-            if G.fetched_index is not None:
-                io.fetched_index = G.fetched_index.data_ptr()
+        fetched = (G.fetched_codes, G.fetched_valid, G.fetched_index, G.fetched_centres_only)
+        st, fetcher = G.store, G.fetcher
+        if fetcher is not None and adapted:
+            raise NotImplementedError("input adapters with a sharded store are not built")
         if adapted:
             io.ntgt_feats, io.ld_ntgt, io.ntgt_valid = ntgt0.data_ptr(), ntgt0.stride(0), ntgt_valid.data_ptr()
         # exact de-duplication of context groups (the reference's "todo: merge same nodes", token_block_dataset.py:355): the ntgt
         # states of a group depend on its centre row only, and the neighbour lists of nearby tokens overlap heavily -- the
-        # multi-layer ntgt pipeline runs once per DISTINCT centre row of the batch.  One host sync (the number of groups).
-        st = G.store
-        if (self.n_layers > 1 and self.dedup_groups and not adapted and not return_ntgt and G.fetched_codes is None
-                and not torch.cuda.is_current_stream_capturing()              # (a captured step stays sync-free: no merging)
-                and getattr(st, "shards", None) is None and st.row0 == 0 and st.codes.shape[0] == st.n_store):
+        # multi-layer ntgt pipeline runs once per DISTINCT centre row of the batch, and across batches only for the rows the
+        # cache lacks.  Decided on the device (gnnlm_group_assign): no sort, no host round trip, capturable.
+        keep = []                                                             # tensors the launch reads: alive until it is enqueued
+        cache = None
+        self._last_groups = None
+        merged = (self.n_layers > 1 and self.dedup_groups and not adapted and not return_ntgt and G.fetched_codes is None)
+        if merged:
             flat = ids.reshape(-1)
-            hit = None
-            cache = self._state_cache_for(prep, st, tgt.device)
-            if cache is not None:
-                hit = cache.assign(flat)
+            cache = self._state_cache_for(prep, G, tgt.device)
+            hit = cache.assign(flat) if cache is not None else None
             if hit is not None:
                 # across batches: only the groups the cache lacks are computed; every neighbour reads its group's slot
-                group_ids, group_slot, group_index = hit
-                # (an empty tensor has no address, and a null group_ids means "no merging" to the C side: name real memory)
-                io.group_ids = group_ids.data_ptr() if group_ids.numel() else cache.id_of_slot.data_ptr()
-                io.group_slot = group_slot.data_ptr() if group_slot.numel() else cache.slot_of.data_ptr()
-                io.n_unique, io.group_index = group_ids.numel(), group_index.data_ptr()
+                group_ids, group_slot, group_index, counters = hit
+                io.group_slot = group_slot.data_ptr()
                 io.state_cache, io.cache_cap = cache.states.data_ptr(), cache.capacity
+                if cache.codes is not None:
+                    io.code_cache = cache.codes.data_ptr()
             else:
-                key = torch.where((flat >= 0) & (flat < st.n_store), flat, torch.full_like(flat, -1))
-                u, inv = torch.unique(torch.cat([key.new_full((1,), -1), key]), return_inverse=True)     # u[0] == -1 always
-                group_ids = u[1:].contiguous()
-                group_index = (inv[1:] - 1).to(torch.int32).contiguous()                                  # -1: not a neighbour
-                io.group_ids, io.n_unique, io.group_index = group_ids.data_ptr(), group_ids.numel(), group_index.data_ptr()
-            self.last_groups = (flat.numel(), group_ids.numel())
+                cache = None
+                table = self._merge_table(st.n_store, tgt.device)
+                if table is None:
+                    merged = False
+                else:
+                    group_ids, _, group_index, counters = _group_assign(flat, st.n_store, table)
+        if merged:
+            io.group_ids, io.n_unique, io.group_index = group_ids.data_ptr(), flat.numel(), group_index.data_ptr()
+            io.n_unique_dev = counters.data_ptr()
+            keep += [group_ids, group_index, counters, hit]
+            self._last_groups = (flat.numel(), counters)
+            if fetcher is not None:                                           # every distinct centre row is requested ONCE
+                fetched = fetcher.fetch_groups(group_ids, G.left, G.right, counters) + (False,)
+        elif fetcher is not None and G.fetched_codes is None:
+            centres_only = self.n_layers == 1 and not return_ntgt
+            fetched = fetcher.fetch_codes(ids, G.left, G.right, centres_only) + (centres_only,)
+        if fetched[0] is not None:
+            # (an EMPTY answer -- every group of the batch was a cache hit -- has no address, and a null fetched_codes means "read the
+            # local table" to the C side: name real memory)
+            real = lambda t, dt: t if t.numel() else torch.zeros(16, dtype=dt, device=tgt.device)
+            fc, fv, fi = real(fetched[0], torch.uint8), fetched[1], fetched[2]
+            io.fetched_codes = fc.data_ptr()
+            if fv is not None:
+                fv = real(fv, torch.uint8)
+                io.fetched_valid = fv.data_ptr()
+            io.fetched_centres_only = int(fetched[3])
+            if fi is not None:
+                fi = real(fi, torch.int32)
+                io.fetched_index = fi.data_ptr()
+            keep.append((fc, fv, fi))
         out_tgt = torch.empty_like(tgt)
         io.out_tgt = out_tgt.data_ptr()
         S = ids.shape[0] * G.kg * n_g
@@ -453,19 +519,22 @@ class HGT(nn.Module):
             out_valid = torch.empty(S, device=tgt.device, dtype=torch.uint8)
             io.out_ntgt, io.out_valid = out_ntgt.data_ptr(), out_valid.data_ptr()
         L = _lib.lib()
-        need = L.gnnlm_hgt_workspace_bytes(ctypes.byref(m), ctypes.byref(io))
-        # one arena per stream: concurrent forwards on different streams must not share scratch
-        key = torch.cuda.current_stream().cuda_stream
-        if prep["ws"] is None:
-            prep["ws"] = {}
-        ws = prep["ws"].get(key)
-        if ws is None or ws.numel() < need or ws.device != tgt.device:
-            # with merged / cached groups the need varies from batch to batch: grow in steps of 1/8 (+ 64 MiB), not by the few
-            # rows the next batch happens to add -- a fresh multi-GB allocation stalls the step for a second
-            prep["ws"][key] = ws = None
-            ws = prep["ws"][key] = torch.empty(need + need // 8 + (64 << 20) if io.group_ids else need, device=tgt.device, dtype=torch.uint8)
-        _lib.check(L.gnnlm_hgt_forward(ctypes.byref(m), ctypes.byref(io), _lib.ptr(ws), ws.numel(),
-                                       _lib.stream()), "gnnlm_hgt_forward")
+        try:
+            need = L.gnnlm_hgt_workspace_bytes(ctypes.byref(m), ctypes.byref(io))
+            # one arena per stream: concurrent forwards on different streams must not share scratch
+            key = torch.cuda.current_stream().cuda_stream
+            if prep["ws"] is None:
+                prep["ws"] = {}
+            ws = prep["ws"].get(key)
+            if ws is None or ws.numel() < need or ws.device != tgt.device:
+                prep["ws"][key] = ws = None
+                ws = prep["ws"][key] = torch.empty(need, device=tgt.device, dtype=torch.uint8)
+            _lib.check(L.gnnlm_hgt_forward(ctypes.byref(m), ctypes.byref(io), _lib.ptr(ws), ws.numel(),
+                                           _lib.stream()), "gnnlm_hgt_forward")
+        except Exception:
+            if cache is not None:             # the new rows own slots whose states were never written: nothing cached survives
+                cache.clear()
+            raise
         out = {"tgt": out_tgt}
         if return_ntgt:
             out["ntgt"] = out_ntgt[out_valid.bool()]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNLM_ABI_VERSION 8
+#define GNNLM_ABI_VERSION 9
 #define GNNLM_OK 0
 #define GNNLM_E_INVALID (-22)
 #define GNNLM_E_NOMEM (-12)
@@ -121,6 +121,7 @@ typedef struct gnnlm_gather {
     const uint8_t* in_valid;   /*    validity comes from in_valid[n_slots]; ids is ignored */
     const int32_t* in_index;   /*    optional with direct: slot s reads row in_index[s] of `codes` */
     const gnnlm_shards_t* shards;  /* ABI 4 (DEVICE pointer): replaces codes / row0 / n_local for the code rows (not with direct, not for vals) */
+    const int32_t* n_groups_dev;   /* ABI 9, optional (DEVICE int32): only the first min(n_groups, *n_groups_dev) groups are processed */
 } gnnlm_gather_t;
 int gnnlm_pq_gather_decode(const gnnlm_gather_t* desc, void* stream);
 
@@ -175,6 +176,7 @@ typedef struct gnnlm_chain_attn {
     float* out;  int64_t ldo;
     int32_t radius_p1;         /* ABI 4.  0: every slot is computed; r + 1 > 0: only the slots within r positions of the centre
                                   are (Q is read for them, K / V up to r + 1 positions away; the other rows of `out` stay untouched) */
+    const int32_t* n_groups_dev;   /* ABI 9, optional (DEVICE int32): only the first min(n_groups, *n_groups_dev) groups */
 } gnnlm_chain_attn_t;
 int gnnlm_chain_attn(const gnnlm_chain_attn_t* desc, void* stream);
 
@@ -472,7 +474,9 @@ typedef struct gnnlm_hgt_io {
      * fairseq/data/token_block_dataset.py:355).  A group's ntgt states depend on its centre row only (ntgt nodes never
      * receive from tgt nodes), so the ntgt pipeline of every layer runs once per DISTINCT centre row of the batch:
      * group_ids [n_unique] the distinct valid rows, group_index [n_blocks*T*kg] the group of neighbour (i, j) (-1: not a
-     * neighbour).  Results are those of the un-merged graph.  Not with fetched_codes / ntgt_feats / out_ntgt / out_valid. */
+     * neighbour).  Results are those of the un-merged graph.  Not with ntgt_feats / out_ntgt / out_valid.
+     * ABI 9: with fetched_codes (sharded store) the fetched_* arrays describe the slots of the GROUPS -- slot g * (1+l+r) + c
+     * of group g -- i.e. only the distinct centre rows of the batch were requested from their owners. */
     const int64_t* group_ids;  int64_t n_unique;  const int32_t* group_index;
     /* ABI 7, optional, with group_ids: a CROSS-BATCH cache of the centre states.  The star edges of layer l >= 1 read the
      * centre slot of a group after l ntgt updates, and that state is a function of the centre row alone (fixed weights and
@@ -482,7 +486,48 @@ typedef struct gnnlm_hgt_io {
      * the cache SLOT of neighbour (i, j) (-1: not a neighbour), new and old alike.  Same kernels, same per-row arithmetic:
      * the result is that of the un-cached call. */
     float* state_cache;  int64_t cache_cap;  const int32_t* group_slot;
+    /* ABI 9, optional, with group_ids: the number of groups lives on the DEVICE (int32, written by gnnlm_group_assign on the
+     * same stream) -- `n_unique` is then the CAPACITY of group_ids / group_slot (the worst case: every neighbour its own
+     * group), which sizes the workspace and the launches; every kernel of the ntgt pipeline reads the count itself, so the
+     * caller never synchronises and the call can be captured into a HIP graph. */
+    const int32_t* n_unique_dev;
+    /* ABI 9, optional, with state_cache and fetched_codes (sharded store): [cache_cap, M] code rows of the cached centres.
+     * Layer 0's star edges read the PQ code of EVERY neighbour; with a sharded store only the groups the cache lacks are
+     * fetched, so the code row of a centre is kept beside its states (128 B per slot). */
+    uint8_t* code_cache;
 } gnnlm_hgt_io_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * ABI 9.  Group assignment on the device: which DISTINCT centre rows of a batch have to be computed, and where every
+ * neighbour finds its group -- what `torch.unique` + a host round trip did before.  No sort, no synchronisation:
+ * `slot_of` is a direct row -> slot table (int32 per datastore row, -1 = none, owned by the caller, persistent) claimed
+ * with atomicCAS; new groups are appended to group_ids through a device counter in ARRIVAL order (per-row arithmetic
+ * does not depend on the position of a row, so results are bit-identical whatever the order).
+ *   merge mode (cache_cap == 0): group_ids = the distinct valid rows of `ids`, group_index[e] = position of neighbour e's
+ *       row in group_ids (-1: not a neighbour); slot_of is returned clean (all -1).
+ *   cache mode (cache_cap > 0): slots are those of a two-generation cache of capacity cache_cap (halves [0, cap/2) and
+ *       [cap/2, cap)); group_ids = the rows the cache lacks, group_slot their new slots, group_index[e] = cache slot of
+ *       neighbour e.  When the half being filled has no room for the batch's new rows the OTHER half is emptied and
+ *       becomes the one being filled (rows this batch found there are computed again); the caller guarantees
+ *       n <= cache_cap / 2 so that a fresh half always has room.  cache_state (DEVICE int32[8], zero-initialised by the
+ *       caller once): [0] half being filled, [1] / [2] entries of the halves, [3] generation switches, [4] rows computed so far (low 31 bits).
+ * counters (DEVICE int32[4], written): [0] = number of groups (pass it as gnnlm_hgt_io_t.n_unique_dev), [1] = 1 if the
+ * generation was switched by this call.  group_ids entries beyond the count are -1.
+ * Replaces: nothing in the reference (its graph repeats equal nodes, token_block_dataset.py:355 "todo: merge same nodes").
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gnnlm_group_assign {
+    const int64_t* ids;  int64_t n;      /* neighbour rows of the batch; < 0 or >= n_store: not a neighbour */
+    int64_t n_store;
+    int32_t* slot_of;                    /* [n_store] */
+    int64_t* id_of_slot;                 /* cache mode: [cache_cap] row held by each slot */
+    int32_t* cache_state;                /* cache mode: DEVICE int32[8] */
+    int64_t cache_cap;
+    int64_t* group_ids;                  /* out [n] */
+    int32_t* group_slot;                 /* out [n], cache mode */
+    int32_t* group_index;                /* out [n] */
+    int32_t* counters;                   /* out DEVICE int32[4] */
+} gnnlm_group_assign_t;
+int gnnlm_group_assign(const gnnlm_group_assign_t* desc, void* stream);
 
 /* x = gelu(x) in place, the exact (erf) form of torch.nn.functional.gelu (input adapters of HGT, hgt.py:507) */
 int gnnlm_gelu(float* x, int64_t n, void* stream);

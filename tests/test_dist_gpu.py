@@ -71,6 +71,7 @@ def test_exchange_rccl_two_ranks():
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("exchange path == direct path") >= 9 and r.stdout.count("mapped shards == direct path") >= 3
+    assert r.stdout.count("merged exchange == direct path") == 28
 
 
 def test_exchange_over_rccl_single_rank():
@@ -80,6 +81,8 @@ def test_exchange_over_rccl_single_rank():
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("exchange path == direct path") == 9          # L = 1; L = 2 slot by slot and halo layout; x exact, padded, peer-mapped
     assert r.stdout.count("mapped shards == direct path") == 3           # ... and the kernels reading the shards themselves
+    # L = 2, 3 with equal context groups merged before the exchange: (halo: exact, padded, peer, mapped; slots: exact, peer, mapped) x cache on / off
+    assert r.stdout.count("merged exchange == direct path") == 28
 
 
 def test_exchange_two_ranks_on_one_gpu():
@@ -94,3 +97,4 @@ def test_exchange_two_ranks_on_one_gpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("exchange path == direct path") == 9 and "ranks 2" in r.stdout
     assert r.stdout.count("mapped shards == direct path") == 3
+    assert r.stdout.count("merged exchange == direct path") == 28       # incl. the link-byte check: < 1/4 of the un-merged requests' bytes

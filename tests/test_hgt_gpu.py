@@ -224,14 +224,16 @@ def test_hgt_dedup_context_groups(dev, L):
 
 @pytest.mark.parametrize("L", [2, 3])
 def test_hgt_centre_state_cache(dev, L):
-    """The cross-batch cache of context groups' centre states (gnnlm_hgt_io_t.state_cache, ABI 7): a sequence of batches with
-    overlapping neighbour rows -- cold, partly cached, fully cached, a generation turnover (cache emptied when full), a batch
-    whose new groups exceed the capacity (falls back to the within-batch merge), new weights (the cache is dropped) -- every
-    output bit-identical to the un-cached call, and equal to the un-merged float64 oracle."""
+    """The cross-batch cache of context groups' centre states (gnnlm_hgt_io_t.state_cache, ABI 7; slots assigned on the device,
+    gnnlm_group_assign, ABI 9): a sequence of batches with overlapping neighbour rows -- cold, partly cached, fully cached,
+    generation turnovers (the older half emptied when the one being filled has no room, once with rows of the current batch in
+    the half that goes), a batch too large for a generation (falls back to the within-batch merge), new weights (the cache is
+    dropped) -- every output bit-identical to the un-cached call, the rows computed per batch those of a host model of the
+    two-generation policy, and the result equal to the un-merged float64 oracle."""
     from gnnlm_amd.hgt import HGT, NeighborGraph
     d, H, M, dsub, T, kg, l, r, nblk = 128, 8, 16, 8, 12, 10, 2, 2, 2
     rs = np.random.RandomState(70 + L)
-    n_store = 500
+    n_store = 2000
     codes = rs.randint(0, 256, size=(n_store, M)).astype(np.uint8)
     cen = (rs.randn(M, 256, dsub) * 0.5).astype(np.float32)
     A = (rs.randn(M * dsub, d) / np.sqrt(M * dsub)).astype(np.float32)
@@ -242,12 +244,28 @@ def test_hgt_centre_state_cache(dev, L):
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
     plain_model = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=L, n_heads=H)
     plain_model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
-    plain_model.state_cache_gib = 0.0                                         # the within-batch merge only (round 3's path)
-    model.state_cache_slots = 60
+    plain_model.state_cache_gib = 0.0                                         # the within-batch merge only
+    cap = 2 * nblk * T * kg                                                   # a generation = the neighbours of one batch (the minimum)
+    model.state_cache_slots = cap
 
-    def batch(pool_lo, pool_hi, seed):
+    def policy(batches):
+        """Host model of the cache's policy: rows computed per batch."""
+        caps, gen, halves, out, switches = [cap // 2, cap - cap // 2], 0, [set(), set()], [], 0
+        for nb_, _ in batches:
+            rows = set(int(v) for v in nb_.reshape(-1) if 0 <= v < n_store)
+            miss = rows - halves[0] - halves[1]
+            if len(miss) > caps[gen] - len(halves[gen]):
+                gen ^= 1
+                halves[gen] = set()
+                switches += 1
+                miss = rows - halves[0] - halves[1]
+            halves[gen] |= miss
+            out.append(len(miss))
+        return out, switches
+
+    def batch(pool_lo, pool_hi, seed, extra=()):
         r_ = np.random.RandomState(seed)
-        pool = np.concatenate([[0, n_store - 1], r_.randint(pool_lo, pool_hi, 25)])
+        pool = np.concatenate([[0, n_store - 1], r_.randint(pool_lo, pool_hi, 600), np.asarray(extra, dtype=np.int64)])
         nb = pool[r_.randint(0, len(pool), size=(nblk * T, kg))].astype(np.int64)
         nb[r_.rand(*nb.shape) < 0.05] = -1
         nb[3] = -1
@@ -258,8 +276,10 @@ def test_hgt_centre_state_cache(dev, L):
         G = NeighborGraph(ids=torch.from_numpy(nb).to(dev), n_blocks=nblk, T=T, left=l, right=r, store=store)
         return mdl(G, features={"tgt": torch.from_numpy(tgt).to(dev)})["tgt"].cpu().numpy()
 
-    a, b_, c = batch(0, 200, 1), batch(100, 300, 2), batch(300, 500, 3)
-    seq = [a, b_, a, c, a, b_]                                                # 60 slots: c (or the a after it) turns the generation over
+    a, b_, c = batch(0, 400, 1), batch(200, 600, 2), batch(600, 1000, 3)
+    a_rows = np.unique(a[0][(a[0] >= 0) & (a[0] < n_store)])
+    mix = batch(1400, 1800, 4, extra=np.repeat(a_rows[:60], 2))               # new rows + rows of a: a's half is dropped under it
+    seq = [a, b_, a, mix, a, c, b_]                                           # 5 generation switches, 2 of them take rows of the batch at hand
     computed = []
     for i, (nb, tgt) in enumerate(seq):
         got = run(model, nb, tgt)
@@ -267,18 +287,20 @@ def test_hgt_centre_state_cache(dev, L):
         computed.append(model.last_groups[1])
         assert np.array_equal(got, run(plain_model, nb, tgt)), i              # same kernels, same per-row arithmetic: same bits
     st = model.state_cache.stats
+    want, switches = policy(seq)
+    assert computed == want, (computed, want)
     assert computed[1] < plain_model.last_groups[1] and computed[2] == 0      # b: only its new rows; a again: nothing to compute
-    assert st["generations"] >= 2 and st["computed"] == sum(computed)
+    assert switches == 5 and computed[3] > 125 and st["generations"] == 1 + switches and st["computed"] == sum(computed)
     nb, tgt = a
     nbo = np.where(nb >= n_store, -1, nb)
     ref = np.concatenate([oracle_hgt(sd, L, H, tgt[i * T:(i + 1) * T], nbo[i * T:(i + 1) * T], codes, cen, A, b, n_store, l, r)["tgt"].numpy()
                           for i in range(nblk)])
     assert np.abs(run(model, nb, tgt) - ref).max() < 1e-4
-    # a capacity below one batch's distinct groups: the call falls back to the within-batch merge
-    model.state_cache_slots, model.state_cache = 5, None
+    # a generation smaller than a batch's neighbour count: the call falls back to the within-batch merge
+    model.state_cache_slots, model.state_cache = 6, None
     assert np.array_equal(run(model, *a), run(plain_model, *a)) and model.state_cache.used == 0
     # new weights: cached states are stale and dropped
-    model.state_cache_slots, model.state_cache = 400, None
+    model.state_cache_slots, model.state_cache = cap, None
     run(model, *a)
     old_cache = model.state_cache
     assert old_cache.used > 0
@@ -321,3 +343,102 @@ def test_state_cache_bits_at_recipe_shapes(dev):
         computed.append(cached.last_groups[1])
         assert torch.equal(got, run(plain, ids_b)), frac
     assert computed[0] > 30000 and 2000 < computed[1] < 5000 and 0 < computed[2] < 300 and computed[3] == 0
+
+
+def test_group_assign_on_device(dev):
+    """gnnlm_group_assign (ABI 9) against numpy: merge mode = np.unique up to the order of the groups (arrival order), the row ->
+    group table handed back clean; cache mode = the two-generation policy, slot by slot, over a sequence with switches.  Sizes
+    from a handful to half a million ids; -1 / out-of-store ids are not neighbours."""
+    from gnnlm_amd.hgt import CentreStateCache, _group_assign
+    for n, n_store, n_rows in [(0, 50, 5), (7, 50, 5), (5000, 1000, 300), (524288, 3_000_000, 200_000)]:
+        rs = np.random.RandomState(n + 1)
+        pool = rs.randint(0, n_store, size=max(n_rows, 1))
+        ids = pool[rs.randint(0, len(pool), size=n)].astype(np.int64)
+        ids[rs.rand(n) < 0.02] = -1
+        ids[rs.rand(n) < 0.01] = n_store + 3
+        t = torch.from_numpy(ids).to(dev)
+        table = torch.full((n_store,), -1, dtype=torch.int32, device=dev)
+        gids, _, gidx, cnt = _group_assign(t, n_store, table)
+        torch.cuda.synchronize()
+        k = int(cnt[0])
+        ok = (ids >= 0) & (ids < n_store)
+        want = np.unique(ids[ok])
+        got = gids[:k].cpu().numpy()
+        assert k == len(want) and np.array_equal(np.sort(got), want)
+        assert bool((gids[k:n] == -1).all()) and bool((table == -1).all())
+        gi = gidx[:n].cpu().numpy()
+        assert (gi[~ok] == -1).all() and (gi[ok] >= 0).all() and (gi[ok] < k).all() and np.array_equal(got[gi[ok]], ids[ok])
+    # cache mode
+    n_store, n, cap = 5000, 600, 1400
+    cache = CentreStateCache(n_store, 2, 8, cap, dev)
+    halves, gen, fills = [dict(), dict()], 0, [0, 0]
+    rs = np.random.RandomState(9)
+    switches = 0
+    for step in range(12):
+        lo = int(rs.randint(0, 4)) * 1000
+        ids = rs.randint(lo, lo + 1500, size=n).astype(np.int64)
+        ids[rs.rand(n) < 0.03] = -1
+        gids, gslot, gidx, cnt = cache.assign(torch.from_numpy(ids).to(dev))
+        torch.cuda.synchronize()
+        rows = set(int(v) for v in ids if v >= 0)
+        miss = rows - set(halves[0]) - set(halves[1])
+        switched = len(miss) > (cap // 2 if gen == 0 else cap - cap // 2) - fills[gen]
+        if switched:
+            gen ^= 1
+            halves[gen], fills[gen] = dict(), 0
+            switches += 1
+            miss = rows - set(halves[0]) - set(halves[1])
+        k = int(cnt[0])
+        assert k == len(miss) and int(cnt[1]) == int(switched)
+        got_rows, got_slots = gids[:k].cpu().numpy(), gslot[:k].cpu().numpy()
+        assert set(got_rows.tolist()) == miss
+        base = (0 if gen == 0 else cap // 2) + fills[gen]
+        assert sorted(got_slots.tolist()) == list(range(base, base + k))                    # the next free slots of the half being filled
+        for r_, s_ in zip(got_rows.tolist(), got_slots.tolist()):
+            halves[gen][r_] = s_
+        fills[gen] += k
+        slot_of = {**halves[0], **halves[1]}
+        gi = gidx[:n].cpu().numpy()
+        assert all((gi[j] == -1) if ids[j] < 0 else (gi[j] == slot_of[int(ids[j])]) for j in range(n))
+        assert cache.id_of_slot[torch.from_numpy(got_slots).long().to(dev)].cpu().tolist() == got_rows.tolist()
+    st = cache.stats
+    assert switches >= 3 and st["generations"] == 1 + switches and cache.used == fills[0] + fills[1]
+    assert cache.assign(torch.zeros(cap // 2 + 1, dtype=torch.int64, device=dev)) is None  # more neighbours than a generation holds
+
+
+def test_merged_multilayer_step_is_graph_capturable(dev):
+    """L = 3 with merging ON inside a HIP graph: the group assignment, the device-side group count every ntgt kernel reads and
+    the centre-state cache leave nothing for the host to decide, so the step -- captured on the stream that ran the eager
+    warm-up (the persistent tables belong to it) -- replays bit for bit, also after the neighbour ids changed IN PLACE to a
+    batch with a different number of distinct groups, with the cache warm, cold, and off."""
+    from gnnlm_amd.synthetic import build_engine, make_problem, to_batch
+    prob = make_problem(n_store=3000, d=64, n_heads=4, M=16, dsub=4, vocab=600, cutoff=[100, 300], T=16, kg=8,
+                        left=2, right=2, n_layers=3, k=32, seed=5)
+    for cache_slots in (None, 2048):
+        eng = build_engine(prob, dev)
+        eng.hgt.state_cache_gib, eng.hgt.state_cache_slots = (0.0, None) if cache_slots is None else (1.0, cache_slots)
+        plain = build_engine(prob, dev)
+        plain.hgt.dedup_groups = False
+        batch = to_batch(prob["block"], dev)
+        ids0 = batch.ids.clone()
+        ids1 = ids0.clone()
+        ids1[:, 1:] = ids1[:, :1]                                      # every token: one distinct neighbour row
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            eng.score(batch, 0.25, 1.0)                                # eager warm-up on the capture stream: tables, cache, workspace
+            n_all, n0 = eng.hgt.last_groups
+            assert 0 < n0 < n_all
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                out = eng.score(batch, 0.25, 1.0)
+            assert eng.hgt._last_groups is not None                    # the captured step is the merged one
+            for ids in (ids0, ids1, ids0):
+                batch.ids.copy_(ids)
+                g.replay()
+                s.synchronize()
+                got = {k: out[k].clone() for k in ("logp", "gcn_feat")}
+                ref = plain.score(batch, 0.25, 1.0)
+                for k in got:
+                    assert torch.equal(got[k], ref[k]), (cache_slots, k)
+        torch.cuda.current_stream().wait_stream(s)

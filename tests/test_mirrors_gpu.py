@@ -167,11 +167,11 @@ def test_sequence_scorer_golden(dev, golden, tmp_path, keytype, lmbda, temp):
             assert h["knn_recall"] is None
 
 
-def make_data_dir(tmp_path):
+def make_data_dir(tmp_path, n_test=41, L=2):
     """A synthetic data directory in the reference's on-disk formats + a reference-style checkpoint."""
     from gnnlm_amd.synthetic import make_problem
-    d, H, M, dsub, V, kg, T, L = 64, 4, 16, 4, 600, 6, 16, 2
-    n_train, n_test = 2000, 41                      # 41 = 2 full blocks + a 9-token block
+    d, H, M, dsub, V, kg, T = 64, 4, 16, 4, 600, 6, 16
+    n_train = 2000                                  # n_test = 41: 2 full blocks + a 9-token block
     prob = make_problem(n_store=n_train, d=d, n_heads=H, M=M, dsub=dsub, vocab=V, cutoff=[100, 300], T=n_test, kg=kg,
                         left=2, right=2, n_layers=L, k=8, seed=3)
     data = tmp_path / "data-bin"
@@ -623,3 +623,52 @@ def test_pipeline_from_raw_keys(dev, tmp_path):
         p, _ = oknn_.knn_target_prob(dd.astype(np.float32), ii, prob["vals"], targets[s:e], temp)
         total += oknn_.combine_knn_and_vocab_probs(p, o["lm_logp"], lam).double().sum().item()
     assert res["count"] == n_test and abs(res["score_sum"] - total) < 5e-4 * n_test
+
+
+@pytest.mark.parametrize("L", [1, 3])
+def test_eval_lm_multi_process_sharded_store(dev, tmp_path, L):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m gnnlm_amd.eval_lm ...` (both ranks on device 0, collectives staged
+    through the host -- RCCL refuses two ranks per device): the driver initialises the process group itself, every rank scores
+    its share of the blocks against a range-sharded (exchange, exact and fixed-capacity), peer-mapped or replicated code table,
+    one all-reduce at the end, rank 0 prints the reference's two lines -- the same lines, and the same score sum to the last
+    bits float64 addition order allows, as the single-process run.  L = 3 merges equal context groups BEFORE the exchange
+    (fewer bytes on the links than groups x rows); one rank has a batch less than the other and serves its peer meanwhile."""
+    import json
+    import subprocess
+    import sys
+    c = make_data_dir(tmp_path, n_test=100, L=L)                            # 6 full blocks + a 4-token one: 4 blocks / 3 blocks
+    base = list(c["base"])
+    base[base.index("--max-tokens") + 1] = str(c["T"])                     # the recipe's one-block batches
+    knn = ["--knnlm", "--k", "8", "--lmbda", "0.25", "--dstore-dir", str(c["data"] / "train_dstore"),
+           "--index-file", str(c["data"] / "train_dstore" / "faiss_store.cosine"), "--temperature", "1.0", "--knn-sim-func", "ip"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+
+    def run(extra, ranks, port):
+        out = str(tmp_path / f"res_{port}.json")
+        cmd = [sys.executable] + (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                                   "--master-port", str(port)] if ranks > 1 else []) + ["-m", "gnnlm_amd.eval_lm"] + base + knn + extra + ["--result-json", out]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root,
+                           env=dict(env, GNNLM_EVAL_BACKEND="gloo", GNNLM_EVAL_DEVICE="0"))
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith(("Evaluated", "Loss"))]
+        assert len(lines) == 2, p.stdout                                    # rank 0 prints, once
+        return lines, json.load(open(out)), [json.load(open(out + f".rank{r}")) for r in range(ranks)] if ranks > 1 else None
+    one_lines, one, _ = run([], 1, 0)
+    assert one["count"] == 100 and one["world"] == 1
+    bytes_seen = {}
+    for i, extra in enumerate([["--store", "sharded"], ["--store", "sharded", "--exchange", "padded"], ["--store", "peer"], ["--store", "replicated"]]):
+        lines, res, ranks = run(extra, 2, 29650 + 4 * L + i)
+        assert lines[1] == one_lines[1], (extra, lines, one_lines)          # "Loss (base 2): ..., Perplexity: ..." byte for byte
+        assert res["count"] == 100 and res["tokens"] == 100 and res["world"] == 2 and res["store"] == extra[1]
+        assert abs(res["score_sum"] - one["score_sum"]) <= 1e-12 * abs(one["score_sum"])
+        assert [r["rank_tokens"] for r in ranks] == [64, 36]
+        assert abs(sum(r["rank_score_sum"] for r in ranks) - one["score_sum"]) <= 1e-12 * abs(one["score_sum"])
+        if extra[1] == "sharded":
+            assert all(r["xgmi_bytes"] > 0 for r in ranks)
+            bytes_seen[tuple(extra)] = ranks[0]["xgmi_bytes"]
+    if L > 1:
+        # requests were merged before the exchange: rank 0 (64 tokens x 6 neighbours) asked for fewer groups than it has neighbours
+        M, n_g = 16, 5
+        assert bytes_seen[("--store", "sharded")] < 64 * 6 * (8 + n_g * M)

@@ -66,4 +66,66 @@ for L in (1, 2):
         assert torch.equal(out["logp"], ref["logp"]) and torch.equal(out["recall"], ref["recall"]), (L, "mapped", halo)
         if rank == 0:
             print("mapped shards == direct path, L =", L, "halo" if halo[0] else "slots", "ranks", world)
+# ---- multi-layer models: equal context groups are merged ON THE DEVICE before the exchange (one request per distinct centre row;
+# with the cross-batch cache only for the rows it lacks) -- bit-identical to the un-merged direct path, fewer bytes on the links
+from gnnlm_amd.engine import GnnLmEngine
+from gnnlm_amd.hgt import HGT
+for L in (2, 3):
+    prob = make_problem(n_store=5000, d=64, n_heads=4, M=16, dsub=4, vocab=600, cutoff=[100, 300], T=16, kg=8,
+                        left=2, right=2, n_layers=L, k=32, seed=30 + L, n_blocks=2)
+    eng = build_engine(prob, dev)
+    eng.hgt.dedup_groups = False                        # the reference of this section: the un-merged graph on the whole table
+    per = -(-prob["n_store"] // world)
+    rs = np.random.RandomState(100 * L + rank)
+    # few distinct rows (heavy overlap between tokens, blocks and batches), some of them at the shard boundaries and store ends
+    pool = np.concatenate([rs.randint(0, prob["n_store"], 40), [0, 1, prob["n_store"] - 1, per - 1, per, per + 1, min(prob["n_store"] - 1, 2 * per)]])
+    batches = []
+    for j in range(3):
+        bb = to_batch(prob["block"], dev)
+        ids = pool[rs.randint(0, len(pool) - 10 * (j == 0), size=tuple(bb.ids.shape))].astype(np.int64)     # (batch 0 never sees the last rows: later misses)
+        ids[rs.rand(*ids.shape) < 0.05] = -1
+        bb.ids = torch.from_numpy(ids).to(dev)
+        batches.append(bb)
+    refs = [eng.score(bb, 0.25, 0.01)["logp"].clone() for bb in batches]
+    full = eng.store
+    for halo in ((2, 2), (0, 0)):
+        hs = Shard(prob["n_store"], world, rank, halo_left=halo[0], halo_right=halo[1])
+        sl = slice(hs.store_row0, hs.store_row0 + hs.store_rows)
+        part = CodeStore(codes=full.codes[sl].contiguous(), centroids=full.centroids, n_store=full.n_store, row0=hs.store_row0,
+                         vals=full.vals, A=full.A, b=full.b)
+        part.vals_row0 = 0                              # (labels replicated)
+        for mode in ("exact", "padded", "peer", "mapped"):
+            if mode == "padded" and not halo[0]:
+                continue                                # (the fixed-capacity exchange of merged groups needs halo shards)
+            for cache_slots in (None, 4096):
+                hgt = HGT(in_dim=64, hidden_dim=64, out_dim=64, n_layers=L, n_heads=4)
+                hgt.load_state_dict(eng.hgt.state_dict())
+                assert hgt.dedup_groups
+                hgt.state_cache_gib, hgt.state_cache_slots = (0.0, None) if cache_slots is None else (1.0, cache_slots)
+                if mode == "mapped":
+                    f = None
+                    e2 = GnnLmEngine(hgt, eng.asm, PeerMappedFetcher(part, hs).mapped_store(), eng.left, eng.right)
+                    e2.store.vals_row0 = 0
+                else:
+                    f = PeerMappedFetcher(part, hs) if mode == "peer" else ShardedFetcher(part, hs, mode=mode)
+                    e2 = GnnLmEngine(hgt, eng.asm, part, eng.left, eng.right, fetcher=f)
+                computed = []
+                for bb, ref in zip(batches + batches[:1], refs + refs[:1]):
+                    out = e2.score(bb, 0.25, 0.01)
+                    torch.cuda.synchronize()
+                    assert torch.equal(out["logp"], ref), (L, mode, halo, cache_slots)
+                    computed.append(hgt.last_groups)
+                if f is not None:
+                    f.check()
+                n_all = computed[0][0]
+                assert all(c[1] < n_all // 4 for c in computed), computed             # requests merged: far fewer groups than neighbours
+                if cache_slots is not None:
+                    assert computed[-1][1] == 0 and computed[1][1] < computed[0][1]   # batch 0 again: every group cached
+                if mode == "exact":
+                    per_request = (8 + 5 * 16) if halo[0] else 5 * (8 + 16)       # one request per group (halo layout) / per slot
+                    unmerged = sum(int(c[0] * (world - 1) / world) * 2 * per_request for c in computed)
+                    assert world == 1 or f.link_bytes < unmerged // 4, (f.link_bytes, unmerged)
+                if rank == 0:
+                    print("merged exchange == direct path, L =", L, mode, "halo" if halo[0] else "slots", "cache" if cache_slots else "no cache",
+                          "ranks", world, "groups computed", [c[1] for c in computed], "of", n_all)
 dist.destroy_process_group()
