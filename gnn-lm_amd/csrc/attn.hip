@@ -792,6 +792,7 @@ int star_attn(const StarAttnParams& p, hipStream_t stream) {
     }
     ProfScope prof(K_STAR, stream, 4.0 * rows * p.H * p.D,
                    rows * (8.0 + (p.codes ? (double)p.M : 4.0 * p.D)) + 8.0 * p.T * p.H * p.D);
+    if (star_attn_dense_eligible(p)) return star_attn_dense(p, stream);      // dense rows at the recipe's widths: one pass (star_dense.hip)
     dim3 grid(p.T), block(256);
     if (nq <= 64) {
         hipLaunchKernelGGL(star_attn_kernel<1>, grid, block, shmem, stream, p, stage);

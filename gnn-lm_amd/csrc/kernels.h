@@ -96,6 +96,9 @@ __device__ __forceinline__ const uint8_t* star_code_ptr(const StarAttnParams& p,
     if (p.shards) return shard_row_ptr(p.shards, id, p.M);
     return p.codes + star_code_row(p, i, j, id) * p.M;
 }
+// dense neighbour rows (layers >= 1), D in {256, 512, 1024}, H <= 8: one pass over the rows with a running softmax (star_dense.hip)
+bool star_attn_dense_eligible(const StarAttnParams& p);
+int star_attn_dense(const StarAttnParams& p, hipStream_t stream);
 int chain_attn(const ChainAttnParams& p, hipStream_t stream);
 
 // rows of S[b, h, w, :T] -> causal softmax (u <= w, and w-u < max_ctx if max_ctx > 0), in place

@@ -338,20 +338,30 @@ def test_star_attn_pq(ops, dev, T, H, M, dsub, kg):
     assert np.array_equal(has.cpu().numpy(), (ids >= 0).any(1).astype(np.float32))
 
 
-def test_star_attn_dense(ops, dev):
-    rs = np.random.RandomState(2)
-    T, H, D, kg, n_g = 6, 8, 64, 10, 3
+@pytest.mark.parametrize("T,H,D,kg,n_g", [(6, 8, 64, 10, 3), (5, 8, 1024, 128, 5), (4, 8, 1024, 37, 1), (3, 5, 512, 128, 5), (3, 8, 256, 9, 2),
+                                          (2, 8, 1024, 1024, 1), (2, 12, 1024, 16, 1)])
+def test_star_attn_dense(ops, dev, T, H, D, kg, n_g):
+    """Dense neighbour rows (layers >= 1): the generic two-pass kernel (D = 64, H = 12) and the one-pass running-softmax kernel of
+    star_dense.hip (D in {256, 512, 1024}, H <= 8) -- scores spread over a wide range (the running max moves), invalid
+    neighbours, a token without any, k_g not a multiple of the 8 rows a workgroup takes per trip, k_g = 1024."""
+    rs = np.random.RandomState(2 + D + kg)
     X = rs.randn(T * kg * n_g, D).astype(np.float32)
-    U = (rs.randn(T, H, D) / 8).astype(np.float32)
+    U = (rs.randn(T, H, D) / np.sqrt(D) * 3).astype(np.float32)
     ids = rs.randint(0, 100, size=(T, kg)).astype(np.int64)
-    ids[2, 3] = -1
-    Z, _ = ops.star_attn(torch.from_numpy(U).to(dev), torch.from_numpy(ids).to(dev), X=torch.from_numpy(X).to(dev),
-                         x_group_stride=n_g)
+    ids[2 % T, 3] = -1
+    ids[0, rs.rand(kg) < 0.3] = -1
+    ids[1] = -1                                     # no neighbour at all
+    Z, has = ops.star_attn(torch.from_numpy(U).to(dev), torch.from_numpy(ids).to(dev), X=torch.from_numpy(X).to(dev),
+                           x_group_stride=n_g)
     Xc = X.reshape(T, kg, n_g, D)[:, :, 0].astype(np.float64)
     s = np.where((ids >= 0)[:, None, :], np.einsum("tjd,thd->thj", Xc, U.astype(np.float64)), -np.inf)
-    a = np.exp(s - s.max(-1, keepdims=True))
-    a /= a.sum(-1, keepdims=True)
+    with np.errstate(invalid="ignore"):
+        a = np.exp(s - s.max(-1, keepdims=True))
+        a = np.nan_to_num(a / a.sum(-1, keepdims=True))
     assert np.abs(Z.cpu().numpy() - np.einsum("thj,tjd->thd", a, Xc)).max() < 2e-5
+    assert np.array_equal(has.cpu().numpy(), (ids >= 0).any(1).astype(np.float32))
+    Z2, _ = ops.star_attn(torch.from_numpy(U).to(dev), torch.from_numpy(ids).to(dev), X=torch.from_numpy(X).to(dev), x_group_stride=n_g)
+    assert torch.equal(Z, Z2)                       # deterministic: fixed order inside a wave, fixed order of the waves
 
 
 # ------------------------------------------------------------------------------------------ chain attention
