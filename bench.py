@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--exchange", choices=["padded", "exact", "peer"], default="padded",
                     help="sharded store: fixed-capacity sync-free exchange (2 all-to-alls, no host round trip; dropped rows are "
                          "checked for after the run) or the exact variable-split one (3 all-to-alls, 2 host syncs per table)")
+    ap.add_argument("--ids", choices=["uniform", "searched"], default="uniform",
+                    help="graph-neighbour ids of the timed batches: i.i.d. uniform over the store (the headline: worst-case locality, no two "
+                         "context groups coincide) or SEARCHED over a clustered synthetic corpus (searched_neighbour_ids: what the pipeline's own "
+                         "kNN producer returns; equal context groups exist and are merged -- with a sharded store BEFORE the exchange)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the sharded-store exchange even with one rank (exercises the RCCL path on one GPU)")
     return ap.parse_args()
@@ -152,6 +156,11 @@ def make_batches(args, dev, rank, d, vocab):
         targets = zipf_dev(n, vocab, gen, dev)
         out.append(BlockBatch(ids=ids, tgt_feats=feats, targets=targets, n_blocks=B, T=T,
                               knn_sims=sims.contiguous(), knn_ids=knn_ids))
+    if args.ids == "searched":
+        kw = dict(n_keys=min(10000, N // 2), d_c=32, n_clusters=100) if args.small else {}
+        rows, _ = searched_neighbour_ids(args, dev, n * len(out), T, seed=7 + rank, **kw)
+        for i, b in enumerate(out):
+            b.ids = rows[i * n:(i + 1) * n].contiguous()
     return out
 
 
@@ -351,7 +360,7 @@ def recipe_l3(args, eng1, batches, dev):
     step = lambda b_: ops.masked_sum_f64(eng.score(b_, args.lmbda, args.temperature)["logp"], None, acc)
     steps = max(20, args.l3_steps)
 
-    def timed(bs, cache_gib, settle_s=0.6):
+    def timed(bs, cache_gib, settle_s=0.6, steps=steps):
         """`steps` timed steps over the batch list `bs` (cycled), after one profiled step and a settle phase."""
         hgt.state_cache_gib, hgt.state_cache = cache_gib, None
         step(bs[0])
@@ -424,22 +433,25 @@ def recipe_l3(args, eng1, batches, dev):
     srch = [batch_at(i, ids_s) for i in range(n_pool)]
     flat = ids_s.reshape(n_pool, -1)
     per_batch = [int(torch.unique(flat[i][flat[i] >= 0]).numel()) for i in range(n_pool)]
-    merged = timed(srch, 0.0)                                             # within-batch merge only (round 3's path)
-    # with the cross-batch cache: a COLD pass over the pool (what an eval run over new text does), then the steady state
-    hgt.state_cache_gib, hgt.state_cache = float(args.l3_cache_gib), None
-    colds = []
-    for rep in range(3):                                                  # pass 0 allocates (cache, workspace); passes 1, 2 are timed, each from an EMPTY cache
-        if hgt.state_cache is not None:
-            hgt.state_cache.clear()
-            hgt.state_cache.reset_stats()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for b_ in srch:
-            step(b_)
-        torch.cuda.synchronize()
-        colds.append(time.perf_counter() - t0)
+    merged = timed(srch, 0.0)                                             # within-batch merge only
+
+    def cold_passes(bs):
+        """Cross-batch cache: COLD passes over the batch list (what an eval run over new text does), each from an empty cache."""
+        hgt.state_cache_gib, hgt.state_cache = float(args.l3_cache_gib), None
+        colds_ = []
+        for rep in range(3):                                              # pass 0 allocates (cache, workspace); passes 1, 2 are timed
+            if hgt.state_cache is not None:
+                hgt.state_cache.clear()
+                hgt.state_cache.reset_stats()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for b_ in bs:
+                step(b_)
+            torch.cuda.synchronize()
+            colds_.append(time.perf_counter() - t0_)
+        return colds_, (dict(hgt.state_cache.stats) if hgt.state_cache is not None else None)
+    colds, st = cold_passes(srch)
     cold = min(colds[1:])
-    st = dict(hgt.state_cache.stats) if hgt.state_cache is not None else None
     # and the steady state of a long run over text whose rows the cache already holds (every group a hit)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -458,6 +470,26 @@ def recipe_l3(args, eng1, batches, dev):
                                       "what": "the same pool again with every group's states cached: the floor of the cached path (tgt side + cache reads only)"},
         "note": "cold pass = every batch of the pool once from an empty cache (an eval run over new text); a group's centre states are "
                 "computed the first time its row is retrieved and read from HBM afterwards (exact)"}
+    # ---- sensitivity: the merge / cache factors are a property of how much the neighbour lists of nearby tokens overlap, i.e. of the
+    # corpus knob `p_stay_in_cluster` (how long a block dwells on one topic).  Three points instead of one; 0.7 is the line above
+    sens, l3_ids = {}, {"p_stay_0.7": ids_s}
+    for stay in (0.3, 0.9):
+        ids_x, _ = searched_neighbour_ids(args, dev, n_srch, T, stay=stay)
+        l3_ids[f"p_stay_{stay}"] = ids_x
+        bs = [batch_at(i, ids_x) for i in range(n_pool)]
+        fx = ids_x.reshape(n_pool, -1)
+        m_x = timed(bs, 0.0, settle_s=0.3, steps=10)
+        c_x, st_x = cold_passes(bs)
+        sens[f"p_stay_{stay}"] = {"distinct_context_groups_per_batch_mean": round(sum(int(torch.unique(fx[i][fx[i] >= 0]).numel()) for i in range(n_pool)) / n_pool),
+                                  "distinct_context_groups_whole_pool": int(torch.unique(fx[fx >= 0]).numel()),
+                                  "within_batch_merge_tokens_per_s": m_x["tokens_per_s"], "with_state_cache_cold_pass_tokens_per_s": round(n_srch / min(c_x[1:]), 1)}
+    sens["p_stay_0.7"] = {"distinct_context_groups_per_batch_mean": round(sum(per_batch) / len(per_batch)),
+                          "distinct_context_groups_whole_pool": out["searched_neighbours"]["distinct_context_groups_whole_pool"],
+                          "within_batch_merge_tokens_per_s": merged["tokens_per_s"], "with_state_cache_cold_pass_tokens_per_s": round(n_srch / cold, 1)}
+    out["searched_neighbours"]["sensitivity"] = dict(sorted(sens.items()), context_groups_per_batch=n * args.gcn_k,
+                                                     note="same corpus (4000 clusters, noise 0.9), same pool size; only the probability that a token stays "
+                                                          "in its predecessor's cluster changes.  uniform_ids above is the limit of no overlap at all")
+    out["_l3_ids"] = l3_ids                                               # (popped by main: knn_search runs them through eval_lm with the search inside)
     hgt.state_cache = None
     torch.cuda.empty_cache()
     out["through_eval_lm"] = {"what": "eval_lm.main -> SequenceScorer.generate, the recipe's command line (--max-tokens 256: one-block batches, "
@@ -628,7 +660,7 @@ def search_check(idx, q, k, n_check):
     return out
 
 
-def knn_search(args, eng, batches, dev, step_ms):
+def knn_search(args, eng, batches, dev, step_ms, l3_ids=None):
     """The kNN SEARCH the headline step leaves out (the reference runs it on the CPU with faiss inside its timer,
     knn_model.py:100 under fairseq_cli/eval_lm.py:214-219): the step's queries (the HGT features of one batch) through the
     on-device IVF-PQ search over a synthetic index of the reference's index shape (OPQ64_1024,IVF4096,PQ64, nprobe 32,
@@ -745,6 +777,35 @@ def knn_search(args, eng, batches, dev, step_ms):
         drv = {"tokens": r_["tokens"], "tokens_per_s_generate_timer": round(r_["tokens"] / r_["seconds"], 1),
                "tokens_per_s_wall": round(r_["tokens"] / r_["wall_seconds"], 1), "blocks_per_batch": nblk,
                "what": "eval_lm.main with the recipe's --max-tokens 256 (one-block batches, 32 per launch), kNN search on the device inside generate"}
+        # the 3-layer recipe through the same driver with the search inside generate, on the searched-neighbour id sets of
+        # recipe_L3's sensitivity points: within-batch merge only, and a cold pass of the cross-batch cache
+        l3_drv = None
+        if l3_ids:
+            from gnnlm_amd.hgt import HGT
+            torch.manual_seed(4321)
+            hgt3 = HGT(in_dim=eng.hgt.hidden_dim, hidden_dim=eng.hgt.hidden_dim, out_dim=eng.hgt.hidden_dim, n_layers=3, n_heads=eng.hgt.n_heads)
+            model3 = GnnLmModel(hgt3, eng.asm, None)
+            model3.make_store = lambda codes, n_store, device: st_
+            l3_drv = {}
+            for label, ids_x in sorted(l3_ids.items()):
+                n3 = min(ids_x.shape[0], pool[0].shape[0])
+                tabs3 = dict(tabs, n_tok=n3, feats=pool[0][:n3], targets=pool[1][:n3].clamp(min=4), nbrs=ids_x[:n3])
+                a.batch_blocks = -1                                             # (auto: 16 one-block batches per launch for a multi-layer model)
+                a.softmax_batch = 64 * T + 1
+                l3_drv[label] = {}
+                for name, gib in (("state_cache_off", 0.0), ("state_cache_on_cold", float(args.l3_cache_gib))):
+                    hgt3.state_cache_gib, hgt3.state_cache = gib, None
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        a.knn_model = SearchKnn()
+                        eval_lm.main(a, tables=tabs3, model=model3)                 # warm-up (allocations)
+                        if hgt3.state_cache is not None:
+                            hgt3.state_cache.clear()
+                        r3 = eval_lm.main(a, tables=tabs3, model=model3)
+                    l3_drv[label][name] = {"tokens": r3["tokens"], "tokens_per_s_generate_timer": round(r3["tokens"] / r3["seconds"], 1),
+                                           "tokens_per_s_wall": round(r3["tokens"] / r3["wall_seconds"], 1)}
+            hgt3.state_cache = None
+            del hgt3, model3
+            torch.cuda.empty_cache()
     # the same search over an index with SKEWED lists (log-normal lengths, sigma 0.7: ~30x between the shortest and the longest
     # of 4096 lists), as k-means lists of real keys are: the groups of a long list are long tasks
     skewed = None
@@ -771,6 +832,9 @@ def knn_search(args, eng, batches, dev, step_ms):
         torch.cuda.empty_cache()
     return {"index": "synthetic OPQ64_1024,IVF4096,PQ64", "keys": args.n_store, "nprobe": 32, "k": args.k, "queries": n,
             "skewed_lists": skewed, "driver_with_search": drv,
+            "recipe_L3_driver_with_search": (None if not l3_ids or args.small else dict(l3_drv, what="eval_lm.main, 3-layer model, the recipe's one-block batches (16 per "
+                                             "launch), the IVF-PQ search of the step's own queries inside generate (the reference's timer spans it): tokens/s on the "
+                                             "searched-neighbour id sets of recipe_L3.searched_neighbours.sensitivity")),
             "scan": scan_name, "threshold_lists": thr_lists, "threshold_sample": thr_sample, "cand_cap": cap_now, "ms_per_4096_queries": round(ms_4096, 3),
             "ms_per_batch": round(dt * 1e3, 2), "ms_per_batch_runs": [round(t_ * 1e3, 2) for t_ in times], "queries_per_s": round(n / dt, 1),
             "pairs_per_query": round(st["pairs"] / n), "survivors_per_query": round(st["survivors"] / n), "candidates_per_query": round(st["candidates"] / n), "queries_searched_again": st.get("requeried", 0),
@@ -1190,8 +1254,10 @@ def main():
         if args.layers == 1 and args.precision == "f32":
             recipe = recipe_l3(args, eng, batches, dev)
         drv = driver_path(args, eng, batches, dev)
+        l3_ids = recipe.pop("_l3_ids", None) if recipe is not None else None
         if args.precision == "f32":
-            search = knn_search(args, eng, batches, dev, dt / args.steps * 1e3)
+            search = knn_search(args, eng, batches, dev, dt / args.steps * 1e3, l3_ids)
+        del l3_ids
     if recipe is not None and search is not None and recipe["tokens_per_step"] == 4096:
         # step + on-device search of the step's own queries (what the reference's timer spans), for the recipe's lines
         for key in ("uniform_ids",):
@@ -1263,7 +1329,7 @@ def main():
                                    f"(`value`: search results given, SURVEY.md 8d; `value_with_search`: step + on-device IVF-PQ search of the same queries "
                                    f"= what the reference's own timer spans, fairseq_cli/eval_lm.py:214-219), {args.tokens_per_sample}-token blocks",
                        "n_store": args.n_store, "blocks_per_step_per_gpu": args.blocks, "streams": args.streams, "hip_graph": bool(args.graph), "tokens_per_block": args.tokens_per_sample,
-                       "gcn_k": args.gcn_k, "knn_k": args.k, "hgt_layers": args.layers, "d": d, "vocab": vocab,
+                       "gcn_k": args.gcn_k, "knn_k": args.k, "hgt_layers": args.layers, "d": d, "vocab": vocab, "neighbour_ids": args.ids,
                        "lmbda": args.lmbda, "temperature": args.temperature,
                        "store": ("range-sharded + RCCL all-to-all" if sharded else "replicated" if world > 1 else "single GPU"),
                        "rccl_ranks": world if dist.is_initialized() else 0,

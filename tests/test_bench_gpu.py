@@ -97,3 +97,27 @@ def test_bench_plain_launch_starts_its_own_ranks():
     env.pop("GNNLM_BENCH_BACKEND")
     p = subprocess.run(cmd[:2] + ["--gpus", "64", "--small"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode == 2 and "GPU(s) are visible" in p.stderr
+
+
+def test_bench_two_ranks_merge_before_the_exchange():
+    """`--layers 3 --ids searched` on two ranks (one-GPU transport): equal context groups are merged on the device BEFORE the
+    exchange, so a rank asks its peers for every distinct centre row once -- the bytes on the links fall with the merge factor
+    (reported: config.merged_groups), the exact and the fixed-capacity exchange and the peer-mapped store agree on the score."""
+    res = {}
+    for ex in ("exact", "padded", "peer"):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--small", "--blocks", "2", "--steps", "3", "--warmup", "3",
+               "--n-store", "30000", "--gcn-k", "16", "--k", "32", "--tokens-per-sample", "32", "--no-cpu-baseline", "--settle-s", "0.05",
+               "--layers", "3", "--ids", "searched", "--exchange", ex]
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(GNNLM_BENCH_BACKEND="gloo", GNNLM_BENCH_DEVICE="0")
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        res[ex] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c = res["exact"]["config"]
+    mg = c["merged_groups"]
+    n_all, n_req = mg["context_groups_per_step"], mg["distinct_requested_per_step_mean"]
+    assert n_all == 2 * 32 * 16 and 0 < n_req < 0.8 * n_all                     # searched neighbours repeat (1.45x on this tiny corpus; 2.6x at the bench's size)
+    unmerged = int(n_all / 2) * 2 * (8 + 5 * 16)                                # one request per group, halo layout (M = 16)
+    assert c["xgmi_bytes_per_step_per_rank"] <= unmerged * (n_req / n_all) * 1.05
+    assert res["padded"]["config"]["xgmi_bytes_per_step_per_rank"] < unmerged   # buckets sized from the measured distinct count
+    assert len({r["config"]["synthetic_ppl"] for r in res.values()}) == 1
