@@ -1022,6 +1022,8 @@ int ivfpq_scan8(const gnnlm_ivfpq_scan8_t& d, hipStream_t stream) {
                   "ivfpq_scan8: null operand");
     GNNLM_REQUIRE(d.M == 64 && (uintptr_t)d.tiles % 16 == 0 && (uintptr_t)d.qlut % 4 == 0, "ivfpq_scan8: need M = 64, aligned images");
     GNNLM_REQUIRE(!d.out_hist || d.grp_out, "ivfpq_scan8: out_hist needs grp_out");
+    GNNLM_REQUIRE(d.nlist > 0 && d.nlist <= (1 << SURV_LIST_BITS) && d.max_list >= 0 && d.max_list < (1ll << SURV_ROW_BITS),
+                  "ivfpq_scan8: the survivor records hold 18 bits of list and 19 bits of row: need 0 < nlist <= 2^18 and max_list < 2^19");
     GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<false>, SCAN_LDS);
     GNNLM_LDS_OPT_IN(&ivfpq_scan8_kernel<true>, SUMS_LDS);
     ProfScope prof(d.out_hist ? K_IVF8S : K_IVF8, stream, 0.0, 0.0);   // work figures are device-side (list lengths): bench.py computes them

@@ -70,9 +70,10 @@ class _LazyStats(dict):
 class _PendingSearch:
     """Handle of ``IVFPQIndex.search_begin``."""
 
-    def __init__(self, index, q, k, query_block, return_vals, val, idx, over, worst, ev):
+    def __init__(self, index, q, k, query_block, return_vals, val, idx, over, worst, ev, cap):
         self.index, self.q, self.k, self.query_block, self.return_vals = index, q, k, query_block, return_vals
         self.val, self.idx, self.over, self.worst, self.ev = val, idx, over, worst, ev
+        self.cap = cap                                   # survivor capacity the buffers of THIS search were allocated with
         self._out = None
 
     def result(self):
@@ -172,6 +173,7 @@ def build_groups(pl, nlist, seg=None):
 
 class IVFPQIndex:
     UNDERFLOW = 1 << 30      # "survivor count" of a query whose sampled threshold left fewer than k candidates: searched again like an overflow
+    COLUMNS = (1 << 30) - 1  # ... of a query with more candidates than the selection has columns (a larger survivor capacity would not help it)
     """faiss ``search`` contract: ``search(queries [n, d] f32, k) -> (scores [n, k] descending, ids [n, k], -1 padded)``."""
 
     LABEL_BITS = 24                                                          # payload = id << 24 | label (ids < 2^39, labels < 2^24)
@@ -385,7 +387,8 @@ class IVFPQIndex:
         the count and enqueues what follows: no pipeline bubble behind the search's one host round trip."""
         q = q.to(self.device, torch.float32).contiguous()
         self.stats = _LazyStats(pairs=0, survivors=0, candidates=0, queries=q.shape[0], M=self.M, requeried=0)
-        val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
+        cap = self.cand_cap                                                  # the capacity THIS search's buffers were allocated with
+        val, idx, over = self._search_once(q, k, query_block, self.dense_probes, cap)
         worst = ev = None
         if over is not None:
             if getattr(self, "_worst_host", None) is None:                    # pinned landing slots, one per search in flight (a ring of 8)
@@ -395,32 +398,35 @@ class IVFPQIndex:
             worst.copy_(over.max().reshape(1), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-        return _PendingSearch(self, q, k, query_block, return_vals, val, idx, over, worst, ev)
+        return _PendingSearch(self, q, k, query_block, return_vals, val, idx, over, worst, ev, cap)
 
     def _finish(self, h):
         q, k, query_block = h.q, h.k, h.query_block
         val, idx, over = h.val, h.idx, h.over
+        cap = h.cap                                                           # (not self.cand_cap: another search in flight may have raised it since)
         while over is not None:
             if h.ev is not None:
                 h.ev.synchronize()
-                if int(h.worst[0]) <= self.cand_cap:
+                if int(h.worst[0]) <= cap:
                     break
                 h.ev = None
-            bad = (over > self.cand_cap).nonzero().reshape(-1)                # host sync
+            bad = (over > cap).nonzero().reshape(-1)                          # host sync
             if bad.numel() == 0:
                 break
             n_under = int((over[bad] >= self.UNDERFLOW).sum().item())
+            n_cols = int((over[bad] == self.COLUMNS).sum().item())            # too many CANDIDATES for the selection's columns: searched again one by one
             if n_under > self.sample_fail_frac * q.shape[0] and self.threshold_sample > 1:   # the sample does not stand for its lists on this data: stop sampling
                 self.threshold_sample = 1
                 self.stats = _LazyStats(pairs=0, survivors=0, candidates=0, queries=q.shape[0], M=self.M, requeried=0)
-                val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
+                val, idx, over = self._search_once(q, k, query_block, self.dense_probes, cap)
                 continue
-            if (bad.numel() - n_under) * 8 > q.shape[0] and self.cand_cap < (1 << 18):
-                self.cand_cap *= 2
+            if (bad.numel() - n_under - n_cols) * 8 > q.shape[0] and cap < (1 << 18):
+                cap *= 2
+                self.cand_cap = max(self.cand_cap, cap)
                 self.stats = _LazyStats(pairs=0, survivors=0, candidates=0, queries=q.shape[0], M=self.M, requeried=0)
-                val, idx, over = self._search_once(q, k, query_block, self.dense_probes, self.cand_cap)
+                val, idx, over = self._search_once(q, k, query_block, self.dense_probes, cap)
                 continue
-            sub, cap2 = q[bad].contiguous(), self.cand_cap
+            sub, cap2 = q[bad].contiguous(), cap
             main = self.stats.clone()
             while True:                                                       # every probed list in the threshold / dense round
                 v2, i2, o2 = self._search_once(sub, k, query_block, self.nprobe, cap2)
@@ -515,6 +521,7 @@ class IVFPQIndex:
         d = _lib.gnnlm_ivfpq_scan8_t()
         d.sums_stride = stride
         d.tiles, d.list_off, d.M = self.tiles.data_ptr(), self.list_off.data_ptr(), self.M
+        d.nlist, d.max_list = self.nlist, self.max_list
         d.qlut, d.qmeta, d.coarse, d.ld_coarse = qlut.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0)
         d.grp_list, d.grp_q, d.n_groups, d.max_groups = groups[0].data_ptr(), groups[1].data_ptr(), groups[2].data_ptr(), groups[3]
         ctr = torch.zeros(8, 16, device=self.device, dtype=torch.int32)          # the persistent workgroups' work counters (one per XCD)
@@ -577,7 +584,7 @@ class IVFPQIndex:
         ops.topk_merge(cv, bv, bi, ids=ci, largest=True, init=True, row_ncols=cc.clamp(max=ccap))
         over = sc                                                              # every candidate is a survivor: sc >= cc
         if ccap < cap:                                                         # more candidates than columns: an overflow like any other
-            over = torch.where(cc > ccap, torch.full_like(sc, cap + 1), over)
+            over = torch.where(cc > ccap, torch.full_like(sc, self.COLUMNS), over)
         if S > 1:                                                              # the sampled threshold's proof: k candidates above it (or every key there is)
             avail = (self.list_off[1:] - self.list_off[:-1])[pi.clamp(min=0)].masked_fill(pi < 0, 0).sum(1)
             short = cc.to(torch.int64) < avail.clamp(max=k)

@@ -299,6 +299,7 @@ def label_tags(vals, build=True):
 
 
 _KNN_SCRATCH = {}                    # (device, stream) -> scratch of the routed look-ups (knn_bucket.hip)
+_KNN_SCRATCH_CAPTURED = []           # scratch buffers whose addresses live in captured HIP graphs: kept for good
 KNN_BUCKET_MIN_LOOKUPS = 1 << 20     # below this the one-pass kernel is as fast (three launches against one)
 
 
@@ -342,6 +343,10 @@ def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_sto
                     sc = _KNN_SCRATCH[key] = torch.empty(need, dtype=torch.uint8, device=dev)
                 if sc is not None and sc.numel() >= need:
                     d.scratch, d.scratch_bytes = sc.data_ptr(), sc.numel()
+                    if capturing and not any(t is sc for t in _KNN_SCRATCH_CAPTURED):
+                        # its address is baked into a HIP graph: a later, larger request replaces the dictionary entry, but this
+                        # buffer must outlive every replay (never freed)
+                        _KNN_SCRATCH_CAPTURED.append(sc)
     d.n, d.k = n, k
     d.temperature, d.lmbda = temperature, lmbda
     d.out_logp, d.out_pknn, d.out_recall = out.data_ptr(), pk.data_ptr(), rec.data_ptr()

@@ -372,6 +372,10 @@ typedef struct gnnlm_ivfpq_scan8 {
      * one counter per XCD, one 64-byte line each) a workgroup fetches its next group from its XCD's counter -- lists of very
      * different lengths stay balanced; NULL: static striding */
     int32_t* work_ctr;
+    /* ABI 9: the index's shape, checked -- a survivor record packs the row inside its list into 19 bits and the list into 18, so
+     * the filter covers indexes with nlist <= 2^18 lists of fewer than 2^19 keys (max_list = the longest list); longer / more
+     * lists are refused here (gnn-lm_amd/ivfpq.py sends such an index to the float32 scan) */
+    int32_t nlist;  int64_t max_list;
 } gnnlm_ivfpq_scan8_t;
 int gnnlm_ivfpq_scan8(const gnnlm_ivfpq_scan8_t* desc, void* stream);
 /* tau[q] = a lower bound of query q's k-th best score over its first D probed lists, from the threshold pass's histograms

@@ -100,6 +100,12 @@ def _run_filter(index, q, tau, p_lo, dev, cap):
     d.qlut, d.qmeta, d.coarse, d.ld_coarse, d.tau = qlut.data_ptr(), qmeta.data_ptr(), cs.data_ptr(), cs.stride(0), tau.data_ptr()
     d.grp_list, d.grp_q, d.n_groups, d.max_groups = grp_list.data_ptr(), grp_q.data_ptr(), n_groups.data_ptr(), G
     d.surv, d.surv_cnt, d.cap = surv.data_ptr(), sc.data_ptr(), cap
+    # ABI 9: the entry point itself refuses an index its survivor records cannot address (18 bits of list, 19 of row)
+    for nlist_, max_list_ in ((0, 0), (index.nlist, 1 << 19), ((1 << 18) + 1, index.max_list)):
+        d.nlist, d.max_list = nlist_, max_list_
+        with pytest.raises(_lib.GnnlmError, match="survivor records"):
+            _lib.call_desc("gnnlm_ivfpq_scan8", d)
+    d.nlist, d.max_list = index.nlist, index.max_list
     _lib.call_desc("gnnlm_ivfpq_scan8", d)
     torch.cuda.synchronize()
     return cs, pi, lut, qmeta, surv.cpu().numpy(), sc[:, 0].cpu().numpy(), (grp_list.cpu().numpy(), grp_q.cpu().numpy(), int(n_groups.item()))
