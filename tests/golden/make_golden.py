@@ -524,6 +524,39 @@ def gen_graph_invalid_context():
     np.savez_compressed(os.path.join(OUT, "graph_ctx.npz"), **out)
 
 
+def gen_graph_no_neighbours():
+    """A block in which NO token has a valid neighbour (every id -1): the one state in which an edge type of the graph would
+    have no edges at all (('ntgt','inter','tgt') and ('ntgt','intra','ntgt') both need an ntgt node).  The reference never
+    gets as far as DGL with it: new_build_graph stacks an empty list of neighbour rows (token_block_dataset.py:407-410) and
+    numpy raises.  Recorded as a fact of the reference -- what DGL's cross-type mean does with an edge type without edges is
+    therefore not on the path; this build scores such a block from the causal edges alone (tests pin that to the oracle)."""
+    GB = load_graph_builder()
+    rs = np.random.RandomState(314)
+    n_store, M = 60, 4
+    codes = rs.randint(0, 256, size=(n_store, M)).astype(np.uint8)
+    vals = rs.randint(0, 30, size=n_store).astype(np.int32)
+    out = {"codes": codes, "vals": vals}
+    for T, k, l, r in [(6, 3, 2, 2), (4, 2, 0, 0)]:
+        nb = np.full((T, k), -1, dtype=np.int64)
+        raised, where = 0, -1
+        try:
+            ref_build_graph(GB, nb, np.zeros(T, np.int64), codes, vals, l, r, n_store)
+        except ValueError as e:
+            import traceback
+            raised = 1
+            where = [f.lineno for f in traceback.extract_tb(e.__traceback__) if "token_block_dataset" in f.filename][-1]
+        tag = f"T{T}k{k}l{l}r{r}"
+        out[tag + ".nb"], out[tag + ".reference_raises_value_error"], out[tag + ".raised_at_line"] = nb, np.array([raised]), np.array([where])
+        # one valid neighbour is enough for the reference to build the graph again
+        nb1 = nb.copy()
+        nb1[T - 1, 0] = 7
+        g = ref_build_graph(GB, nb1, np.zeros(T, np.int64), codes, vals, l, r, n_store)
+        out[tag + ".one.nb"] = nb1
+        for et, (u, v) in g._edges.items():
+            out[tag + ".one." + "_".join(et)] = np.stack([u.numpy(), v.numpy()])
+    np.savez_compressed(os.path.join(OUT, "graph_empty.npz"), **out)
+
+
 def gen_hgt_adapters():
     """HGT with in_dim != hidden_dim != out_dim: the reference's own forward incl. `F.gelu(adapt_ws[ntype](feat))`
     (hgt.py:505-507) and the output Linear (:513).  Own random stream: the fixtures above do not move."""
@@ -659,6 +692,7 @@ if __name__ == "__main__":
     gen_adaptive_and_scorer()
     gen_hgt_adapters()
     gen_graph_invalid_context()
+    gen_graph_no_neighbours()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -59,6 +59,38 @@ def test_hgt_golden_reference_forward(dev, golden):
         np.testing.assert_allclose(out["ntgt"], g[key + f".ntgt_out{L - 1}"], atol=TOL, rtol=1e-4, err_msg=key)
 
 
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_block_without_any_neighbour_matches_oracle(dev, golden, L):
+    """Every neighbour id -1 (tests/golden/graph_empty.npz: the reference raises before it reaches DGL, so no reference output
+    exists): the HIP path scores the block from the causal edges alone, exactly as the float64 oracle on the graph without
+    ntgt nodes -- merged, un-merged and with the centre-state cache."""
+    g = golden("graph_empty")
+    from gnnlm_amd.hgt import HGT, NeighborGraph
+    d, H, M, dsub = 32, 2, 4, 4
+    rs = np.random.RandomState(9)
+    cen = (rs.randn(M, 256, dsub) * 0.5).astype(np.float32)
+    A = (rs.randn(M * dsub, d) / 4).astype(np.float32)
+    b = (rs.randn(M * dsub) * 0.1).astype(np.float32)
+    codes = g["codes"]
+    for tag in ("T6k3l2r2", "T4k2l0r0"):
+        l, r = _lr(tag)
+        nb = g[tag + ".nb"]
+        T = nb.shape[0]
+        tgt = rs.randn(T, d).astype(np.float16).astype(np.float32)
+        sd = {k: v.numpy() for k, v in ohgt.init_hgt_weights(L, d, H, seed=11).items()}
+        ref = oracle_hgt(sd, L, H, tgt, nb, codes, cen, A, b, codes.shape[0], l, r)["tgt"].numpy()
+        store = make_store(dev, codes, cen, A, b)
+        model = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=L, n_heads=H)
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+        G = NeighborGraph(ids=torch.from_numpy(nb).to(dev), n_blocks=1, T=T, left=l, right=r, store=store)
+        outs = []
+        for dedup, slots in ((True, None), (False, None), (True, 64)):
+            model.dedup_groups, model.state_cache, model.state_cache_slots = dedup, None, slots
+            model.state_cache_gib = 1.0 if slots else 0.0
+            outs.append(model(G, features={"tgt": torch.from_numpy(tgt).to(dev)})["tgt"].cpu().numpy())
+        assert np.abs(outs[0] - ref).max() < TOL and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def test_hgt_adapters_golden(dev, golden):
     """in_dim != hidden_dim != out_dim (hgt.py:476-492,505-513) against the reference's own forward."""
     from gnnlm_amd.hgt import HGT, NeighborGraph

@@ -155,6 +155,35 @@ def test_build_graph_invalid_neighbor_context(golden, tag):
     assert np.array_equal(valid2, valid) and np.array_equal(rows2, rows)
 
 
+@pytest.mark.parametrize("tag", ["T6k3l2r2", "T4k2l0r0"])
+def test_block_without_any_neighbour(golden, tag):
+    """The one state in which an edge type of the graph would have NO edges (what DGL's cross-type mean does then is the one
+    branch of the DGL stand-in nothing pins): every neighbour id of the block is -1.  The fixture records what the reference
+    does -- it never reaches DGL, new_build_graph raises ValueError stacking zero neighbour rows (token_block_dataset.py:407-410)
+    -- so the state is not on the reference's path.  This build's restatement yields a graph without ntgt nodes and scores the
+    block from the causal edges alone (the HIP path is pinned to that in tests/test_hgt_gpu.py); with ONE valid neighbour the
+    reference builds the graph again and the restatement agrees edge for edge."""
+    g = golden("graph_empty")
+    l, r = _lr(tag)
+    assert int(g[tag + ".reference_raises_value_error"][0]) == 1 and 405 <= int(g[tag + ".raised_at_line"][0]) <= 412
+    nb = g[tag + ".nb"]
+    assert (nb == -1).all()
+    n_store = g["codes"].shape[0]
+    gr = og.build_graph(nb, np.zeros(nb.shape[0], np.int64), n_store, l, r)
+    assert len(gr["ntgt_offsets"]) == 0 and len(gr["inter"][0]) == 0 and len(gr["intra_ntgt"][0]) == 0 and len(gr["intra_tgt"][0]) > 0
+    nb1 = g[tag + ".one.nb"]
+    gr1 = og.build_graph(nb1, np.zeros(nb1.shape[0], np.int64), n_store, l, r)
+    assert np.array_equal(np.stack(gr1["inter"]), g[tag + ".one.ntgt_inter_tgt"])
+    assert np.array_equal(np.stack(gr1["intra_ntgt"]), g[tag + ".one.ntgt_intra_ntgt"])
+    assert np.array_equal(np.stack(gr1["intra_tgt"]), g[tag + ".one.tgt_intra_tgt"])
+    # the oracle's forward on the empty graph: finite, and the tgt update is the causal branch's alone
+    d, H = 16, 2
+    sd = ohgt.init_hgt_weights(2, d, H, seed=3)
+    tgt = torch.from_numpy(np.random.RandomState(1).randn(nb.shape[0], d).astype(np.float32))
+    out = ohgt.hgt_forward(sd, 2, H, {"tgt": tgt, "ntgt": torch.zeros(0, d)}, gr)
+    assert torch.isfinite(out["tgt"]).all() and out["ntgt"].shape[0] == 0
+
+
 # ---------------------------------------------------------------- HGT (hgt.py under the DGL stand-in)
 def hgt_cases(g):
     keys = sorted({k.split(".tgt_in")[0] for k in g.files if k.endswith(".tgt_in")})
