@@ -571,6 +571,12 @@ int adaptive_impl(const gnnlm_adaptive_softmax_t& w, const float* x, int64_t ldx
         g.A = x; g.lda = ldx; g.W = w.head_w; g.ldw = w.d;
         g.lse_part = b.head_part; g.lse_pick = b.head_pick; g.lse_picked = b.head_picked;
         g.M = (int)n; g.N = head_n; g.K = w.d;
+        // tile walk: bands of 4 m-tiles, n slow inside a band.  An XCD's 32 concurrently running 256 x 256 tiles then form a 4 x 8
+        // block (4 A panels + 8 W panels in flight through its L2) instead of a 32 x 1 column (32 + 1): PMC FETCH_SIZE x 2 of the
+        // 8192 x 20004 x 1024 head 2.74 GB -> 0.97 GB per launch (tools/pmc_head_order.sh; GM = 8: 1.02, GM = 16: 1.53).  That is
+        // the floor of this tile size -- tiles x (1 MiB / 8 + 1 MiB / 4) = 0.95 GB: a panel is 1 MiB and the L2 4 MiB, nothing
+        // survives from one block of tiles to the next -- and the time does not move (2.457 ms either way: MFMA-bound)
+        if (n >= 1024) g.tile_order = 2 + 4;
         TRY(gemm_nt(g, s));     // logits are reduced in the epilogue, never written
     }
     TRY(lse_reduce(b.head_part, 2 * (int)cdiv(head_n, 128), n, nullptr, b.head_lse, s));
