@@ -597,8 +597,13 @@ def driver_path(args, eng, batches, dev):
     tabs = {"n_tok": n, "d": eng.hgt.hidden_dim, "vocab": None, "n_store": st.n_store, "feats": b0.tgt_feats[:n],
             "targets": b0.targets[:n].clamp(min=4), "nbrs": b0.ids[:n], "codes": st.codes, "no_pad": True}
     out = {}
-    for name, max_tokens, coalesce in (("one_block_per_batch", T, 0), ("bench_batch", nb, 0), ("one_block_batches_coalesced", T, -1)):
+    # one_block_per_batch: the recipe's literal batches, `--batch-blocks 0` -- successive batches in turn on 3 HIP streams (the driver's
+    # default for single-block batches: a batch is a chain of ~45 small dependent launches, 0.56 ms on the device for 0.2 ms of work);
+    # ..._one_stream: the same strictly one after the other; ..._graph_capture: forward + softmax replayed from HIP graphs on those streams
+    for name, max_tokens, coalesce in (("one_block_per_batch", T, 0), ("one_block_per_batch_one_stream", T, 0), ("one_block_per_batch_graph_capture", T, 0),
+                                       ("bench_batch", nb, 0), ("one_block_batches_coalesced", T, -1)):
         a = eval_lm.get_parser().parse_args(
+            (["--graph-capture"] if name.endswith("graph_capture") else ["--streams", "1"] if name.endswith("one_stream") else []) +
             ["-", "--path", "-", "--graph", "--use-precompute-feat", "--neighbor-context", "2", "--gcn-k", str(args.gcn_k),
              "--tokens-per-sample", str(T), "--max-tokens", str(max_tokens), "--knnlm", "--k", str(args.k), "--lmbda",
              str(args.lmbda), "--temperature", str(args.temperature), "--knn-keytype", "gcn_feat", "--softmax-batch",

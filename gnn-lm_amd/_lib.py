@@ -129,7 +129,7 @@ def lib():
         L.gnnlm_hgt_forward.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
         for nm in ("gnnlm_gemm_nt", "gnnlm_pq_gather_decode", "gnnlm_star_attn", "gnnlm_chain_attn",
                    "gnnlm_knn_interp", "gnnlm_topk_merge", "gnnlm_ivfpq_scan", "gnnlm_gather_rows_peer",
-                   "gnnlm_ivfpq_scan8", "gnnlm_ivfpq_rescore", "gnnlm_ivfpq_tau", "gnnlm_ivfpq_refine"):
+                   "gnnlm_ivfpq_scan8", "gnnlm_ivfpq_rescore", "gnnlm_ivfpq_tau", "gnnlm_ivfpq_refine", "gnnlm_group_assign"):
             getattr(L, nm).argtypes = [vp, vp]
         if L.gnnlm_target_arch() != b"gfx950" or L.gnnlm_abi_version() != ABI_VERSION:
             raise GnnlmError(f"libgnnlm_hip.so is not the gfx950 / ABI-{ABI_VERSION} build")
@@ -153,9 +153,21 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def stream():
+def raw_stream(device=None):
+    """The current HIP stream of ``device`` (default: the current device) as an integer handle.  torch's
+    ``current_stream().cuda_stream`` builds a Stream object per call (~9 us: a step asks for it a dozen times); the raw getter
+    is the same handle without the object."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        idx = device.index if hasattr(device, "index") and device.index is not None else \
+            (device if isinstance(device, int) else torch.cuda.current_device())
+        return int(torch._C._cuda_getCurrentRawStream(idx))
+    except (AttributeError, TypeError):                              # (a torch without the private getter)
+        return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def stream():
+    return ctypes.c_void_p(raw_stream())
 
 
 def call(name, *args):

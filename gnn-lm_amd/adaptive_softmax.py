@@ -60,7 +60,7 @@ class AdaptiveSoftmax:
         self._w.gemm_precision = self.gemm_precision
         L = _lib.lib()
         need = L.gnnlm_adaptive_workspace_bytes(ctypes.byref(self._w), n)
-        key = torch.cuda.current_stream().cuda_stream           # one arena per stream
+        key = _lib.raw_stream()                                 # one arena per stream
         if self._ws is None:
             self._ws = {}
         ws = self._ws.get(key)

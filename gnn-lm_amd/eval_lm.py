@@ -98,6 +98,18 @@ def get_parser():
                         "context sizes), rows fetched from their owners by an RCCL all-to-all, equal context groups merged BEFORE the "
                         "exchange; peer: range shards mapped into every rank (HIP IPC), the kernels read rows from their owner's HBM "
                         "over xGMI themselves.  auto: sharded when WORLD_SIZE > 1, else the one table")
+    p.add_argument("--graph-capture", action="store_true",
+                   help="(this build) replay the model's forward and its softmax from HIP graphs captured once per batch shape and stream.  "
+                        "Measured on the recipe's literal one-block batches: no gain -- the batch is bound by the DEVICE-side latency of its ~45 "
+                        "dependent launches, not by the host that enqueues them (456 k tokens/s eager, 446 k replayed); what helps is --streams "
+                        "(several batches in flight: 0.88 M tokens/s eager on 3 streams, 0.65 M replayed on 4).  Kept as an option; not with "
+                        "--store sharded; multi-layer models are captured un-merged")
+    p.add_argument("--streams", default=0, type=int,
+                   help="(this build) score successive batches on this many HIP streams in turn (blocks are independent; every stream has its own "
+                        "workspaces, graphs and score accumulator).  A one-block batch is a chain of ~45 small dependent launches -- 0.56 ms on the "
+                        "device for 0.2 ms of work, whoever enqueues them -- and several chains in flight overlap (measured: 0.45 M tokens/s on one stream, 0.70 on 2, 0.88 on 3, 0.71 on 4, 0.84 on 6).  0 (default): 3 when the "
+                        "batches are single blocks (the recipe's `--max-tokens 256` with --batch-blocks 0), else 1.  Not with --store sharded "
+                        "(collectives stay on one stream)")
     p.add_argument("--result-json", default=None,
                    help="(this build) write the run's figures (score_sum, count, ppl, tokens, seconds, per-rank sums, xGMI bytes) to this "
                         "file as JSON; in a multi-process run rank r writes PATH.rank<r> and rank 0 also PATH")
@@ -386,6 +398,9 @@ def main(args, tables=None, model=None):
     # neighbours inside the token's own context are dropped on the TRAIN split only (language_modeling.py:299,
     # token_block_dataset.py:360-362): the split whose GNN features the kNN index is built over (find_knn.sh:7)
     invalid_ctx = args.invalid_neighbor_context if args.gen_subset == "train" else 0
+    if getattr(args, "graph_capture", False) and fetcher is not None:
+        raise ValueError("--graph-capture needs the one-table or the peer-mapped store (the exchange of --store sharded synchronises)")
+    model.graph_capture = bool(getattr(args, "graph_capture", False))
     scorer = SequenceScorer(_Dict(), args.softmax_batch, args=args)
     knn_dstore = None
     if args.knnlm:
@@ -457,9 +472,20 @@ def main(args, tables=None, model=None):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fetcher.fixed_requests = int(t.item())
     deep = getattr(getattr(model, "hgt_decoder", None), "n_layers", 1) > 1
+    n_streams = args.streams if getattr(args, "streams", 0) > 0 else (3 if per_batch == 1 and fetcher is None and save is None else 1)
+    if n_streams > 1 and fetcher is not None:
+        raise ValueError("--streams > 1 is not available with --store sharded (the exchange's collectives stay on one stream)")
+    main_stream = torch.cuda.current_stream(device)
+    lanes = [main_stream] + [torch.cuda.Stream(device=device) for _ in range(n_streams - 1)]
+    accs = [acc] + [torch.zeros_like(acc) for _ in lanes[1:]]
+    for s_ in lanes[1:]:
+        s_.wait_stream(main_stream)
     torch.cuda.synchronize()
     wall0 = time.perf_counter()
-    for group in batches_:
+    for bi, group in enumerate(batches_):
+        if n_streams > 1:                                       # this batch's lane: its stream, its accumulator
+            torch.cuda.set_stream(lanes[bi % n_streams])
+            acc = accs[bi % n_streams]
         L = group[0][2] - group[0][0]
         if all(group[j + 1][0] == group[j][2] for j in range(len(group) - 1)):
             idx = slice(group[0][0], group[-1][2])           # back-to-back blocks (no --gcn-context-window): plain views, no gather
@@ -509,6 +535,12 @@ def main(args, tables=None, model=None):
         count += pos.numel()                                                                # :274
         if want_words or bpe_toks is not None:
             count -= word_outputs(args, hypos, sample["id"], symbols, bpe_toks, bpe_len, word_stats)     # skipped_toks (:274)
+    if n_streams > 1:
+        torch.cuda.set_stream(main_stream)
+        for s_, a_ in zip(lanes[1:], accs[1:]):
+            main_stream.wait_stream(s_)
+            accs[0] += a_
+        acc = accs[0]
     for _ in range(idle_steps):                                                             # no batch left here: serve the peers' requests
         if deep and getattr(model.hgt_decoder, "dedup_groups", False):
             fetcher.fetch_groups(torch.empty(0, dtype=torch.int64, device=device), left, right, torch.zeros(4, dtype=torch.int32, device=device))
@@ -523,6 +555,8 @@ def main(args, tables=None, model=None):
         logger.info(f"Saved {save['idx']} data to {save['dir']}")                           # :322-323
     wall = time.perf_counter() - wall0                                                      # the loop as a whole ("wps", :316)
     gen_time = sum(a.elapsed_time(b) for a, b in timers) / 1e3
+    if n_streams > 1:
+        gen_time = min(gen_time, wall)                                                      # (the batches' intervals overlap: their sum is not a duration)
     rank_score_sum, rank_tokens = score_sum, ntok
     score_sum_f32 = np.float32(0.0)
     if hyp_sums:

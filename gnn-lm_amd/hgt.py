@@ -236,7 +236,7 @@ class CentreStateCache:
         # rows the cache lacks are fetched from their owners)
         self.codes = torch.zeros(self.capacity, code_bytes, dtype=torch.uint8, device=device) if code_bytes else None
         self.state = torch.zeros(8, dtype=torch.int32, device=device)       # gnnlm_group_assign_t.cache_state
-        self.stream = torch.cuda.current_stream(device).cuda_stream          # slots are reused in stream order: one stream only
+        self.stream = _lib.raw_stream(device)                                # slots are reused in stream order: one stream only
         self._host = {"lookups": 0, "groups": 0, "clears": 0, "computed0": 0}
 
     @property
@@ -294,7 +294,7 @@ class HGT(nn.Module):
         self.adapt_ws = nn.ModuleList([nn.Linear(in_dim, hidden_dim) for _ in ntype2idx] if in_dim != hidden_dim else [])
         if hidden_dim != out_dim:
             self.out = nn.Linear(hidden_dim, out_dim)
-        self._prepared = None
+        self._prepared = self._plist = None
         self.gemm_precision = 0     # 0 exact f32 MFMA | 1 bf16x3 | 2 bf16x6 (opt-in split-bf16 emulation)
         self.dedup_groups = os.environ.get("GNNLM_DEDUP", "1") != "0"      # merge equal context groups of a batch (multi-layer models)
         self._last_groups = None                                             # (groups of the last batch, device counter of the computed ones)
@@ -313,7 +313,7 @@ class HGT(nn.Module):
         return n, (int(counters[0].item()) if torch.is_tensor(counters) else counters)
 
     def _load_from_state_dict(self, *a, **k):
-        self._prepared = None
+        self._prepared = self._plist = None
         return super()._load_from_state_dict(*a, **k)
 
     def prepare(self, store: CodeStore, device):
@@ -323,8 +323,10 @@ class HGT(nn.Module):
         # that neither an id() reuse nor an in-place edit can serve stale weights.  Table pointers (codes / vals)
         # are NOT part of the key: forward() refreshes them on every call.
         ver = lambda t: None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
+        if self._plist is None:                                   # (walking the module tree costs ~50 us per call: kept, dropped by load_state_dict)
+            self._plist = list(self.parameters())
         key = (str(device), ver(store.centroids), ver(store.A), ver(store.b),
-               tuple(ver(p) for p in self.parameters()))
+               tuple(ver(p) for p in self._plist))
         if self._prepared is not None and self._prepared["key"] == key:
             self._bind_store(self._prepared["model"], store)
             self._prepared["store"] = store
@@ -384,7 +386,7 @@ class HGT(nn.Module):
                 return None
             self.state_cache = c
             c.key = key
-        if c.stream != torch.cuda.current_stream(device).cuda_stream:
+        if c.stream != _lib.raw_stream(device):
             return None
         return c
 
@@ -394,7 +396,7 @@ class HGT(nn.Module):
         graph's private pool: a step captured on a stream that has not run an eager forward yet is captured UN-merged (same
         results).  To capture the merged step, run one eager forward on a stream and capture on it
         (`torch.cuda.graph(g, stream=that_stream)`)."""
-        key = (str(device), n_store, torch.cuda.current_stream(device).cuda_stream)
+        key = (str(device), n_store, _lib.raw_stream(device))
         t = self._merge_tables.get(key)
         if t is None:
             if torch.cuda.is_current_stream_capturing():
@@ -412,7 +414,7 @@ class HGT(nn.Module):
 
     def invalidate(self):
         """Drop the prepared (folded) weights, e.g. after swapping parameter tensors by hand."""
-        self._prepared = None
+        self._prepared = self._plist = None
 
     def forward(self, G: NeighborGraph, features: Dict[str, torch.Tensor] = None, etypes=None,
                 incremental_state=None, return_ntgt: bool = False):
@@ -522,7 +524,7 @@ class HGT(nn.Module):
         try:
             need = L.gnnlm_hgt_workspace_bytes(ctypes.byref(m), ctypes.byref(io))
             # one arena per stream: concurrent forwards on different streams must not share scratch
-            key = torch.cuda.current_stream().cuda_stream
+            key = _lib.raw_stream()
             if prep["ws"] is None:
                 prep["ws"] = {}
             ws = prep["ws"].get(key)

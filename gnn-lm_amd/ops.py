@@ -337,7 +337,7 @@ def knn_interp(lm_logp, sims, ids, targets, temperature, lmbda, vals=None, n_sto
             d.vals_tag = tag.data_ptr()
             if bucketed is True or (bucketed == "auto" and n * k >= KNN_BUCKET_MIN_LOOKUPS):
                 need = _lib.lib().gnnlm_knn_interp_scratch_bytes(n, k, vals.shape[0])
-                key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+                key = (str(dev), _lib.raw_stream(dev))
                 sc = _KNN_SCRATCH.get(key)
                 if (sc is None or sc.numel() < need) and not capturing and n <= (1 << 16) and vals.shape[0] <= (1 << 27):
                     sc = _KNN_SCRATCH[key] = torch.empty(need, dtype=torch.uint8, device=dev)

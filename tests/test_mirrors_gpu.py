@@ -268,6 +268,14 @@ def test_eval_lm_end_to_end(dev, tmp_path):
     for nb_ in ("0", "4"):
         res4 = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", nb_])
         assert res4["count"] == n_test and abs(res4["score_sum"] - res["score_sum"]) < 1e-6 * n_test
+    # --graph-capture (this build): forward and softmax of the recipe's literal one-block batches replayed from HIP graphs, one
+    # pair per batch shape (the 16-token blocks and the ragged 9-token one) -- the same scores to the bit, run after run
+    plain = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", "0"])
+    for extra in ([], ["--streams", "1"], ["--streams", "3"]):          # (default for one-block batches: 3 streams in turn)
+        cap = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", "0", "--graph-capture"] + extra)
+        assert cap["count"] == n_test and abs(cap["score_sum"] - plain["score_sum"]) <= 1e-12 * abs(plain["score_sum"])
+    three = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", "0", "--streams", "3"])       # streams without graphs
+    assert abs(three["score_sum"] - plain["score_sum"]) <= 1e-12 * abs(plain["score_sum"])
     # --num-shards / --shard-id partition the blocks (eval_lm.py:131-132)
     parts = [eval_lm.cli_main(base + ["--num-shards", "2", "--shard-id", str(i)]) for i in range(2)]
     assert sum(p["count"] for p in parts) == n_test
