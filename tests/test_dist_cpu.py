@@ -119,6 +119,30 @@ def _worker(rank, world, port, n_store, M, seed, q):
             got = payload.numpy()[index.numpy()]
             assert int(ovf) == 0 and np.array_equal(got[v], want) and not got[~v].any()
             assert payload.shape[0] == (world * cap + 1) * (1 + left + right)
+            # merged requests (round 5: equal context groups merged BEFORE the exchange): the requester sends its DISTINCT centre
+            # rows -- a 1-D list whose tail beyond the device-side count is -1 (fixed-capacity mode sends the whole list, the -1s
+            # are not requests), or exactly the counted prefix (exact mode); a rank whose groups were all cache hits asks nothing
+            flat = ids.reshape(-1)
+            distinct = np.unique(flat[(flat >= 0) & (flat < n_store)])
+            centres = np.full(flat.size, -1, np.int64)
+            centres[:len(distinct)] = distinct
+            ref_rows, ref_valid = og.slot_layout(distinct.reshape(-1, 1), n_store, left, right)
+            want_m = codes[ref_rows.reshape(-1)[ref_valid.reshape(-1)]]
+            asked.clear()
+            payload, index, _ = exchange_fetch_groups(torch.from_numpy(distinct), left, right, hs, gather_groups)   # exact: the prefix
+            got = payload.numpy()[index.numpy()]
+            assert np.array_equal(got[ref_valid.reshape(-1)], want_m) and not got[~ref_valid.reshape(-1)].any()
+            cap_m = bucket_capacity(len(distinct), world)                          # buckets sized from the distinct count, not from ids.size
+            payload, index, ovf = exchange_fetch_groups(torch.from_numpy(centres), left, right, hs, gather_groups, cap=cap_m)
+            got = payload.numpy()[index.numpy()].reshape(flat.size, 1 + left + right, M)
+            assert int(ovf) == 0 and not got[len(distinct):].any()                 # the -1 tail: zero rows, no request
+            got = got[:len(distinct)].reshape(-1, M)
+            assert np.array_equal(got[ref_valid.reshape(-1)], want_m) and not got[~ref_valid.reshape(-1)].any()
+            if rank == 0:                                                           # rank 0: every group a cache hit this step -- it still serves its peers
+                payload, index, _ = exchange_fetch_groups(torch.zeros(0, dtype=torch.int64), left, right, hs, gather_groups)
+                assert index.numel() == 0
+            else:
+                exchange_fetch_groups(torch.from_numpy(distinct[:3]), left, right, hs, gather_groups)
         # final reduction of (score_sum, count) as the eval driver does it
         t = torch.tensor([float(rank + 1), 10.0 * (rank + 1)], dtype=torch.float64)
         dist.all_reduce(t)
