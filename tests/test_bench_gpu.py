@@ -119,5 +119,8 @@ def test_bench_two_ranks_merge_before_the_exchange():
     assert n_all == 2 * 32 * 16 and 0 < n_req < 0.8 * n_all                     # searched neighbours repeat (1.45x on this tiny corpus; 2.6x at the bench's size)
     unmerged = int(n_all / 2) * 2 * (8 + 5 * 16)                                # one request per group, halo layout (M = 16)
     assert c["xgmi_bytes_per_step_per_rank"] <= unmerged * (n_req / n_all) * 1.05
-    assert res["padded"]["config"]["xgmi_bytes_per_step_per_rank"] < unmerged   # buckets sized from the measured distinct count
+    # fixed-capacity buckets: sized from the distinct count measured in the warm-up (x 1.15 + 1024, agreed by a MAX all-reduce) and never
+    # above the worst case -- at this toy size the constants decide, at the bench's size the count does
+    from gnnlm_amd.dist import bucket_capacity
+    assert res["padded"]["config"]["xgmi_bytes_per_step_per_rank"] <= bucket_capacity(n_all, 2) * 2 * (8 + 5 * 16)
     assert len({r["config"]["synthetic_ppl"] for r in res.values()}) == 1
