@@ -956,6 +956,9 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if os.environ.get("GNNLM_BENCH_WATCHDOG"):                   # debugging aid: dump every thread's Python stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["GNNLM_BENCH_WATCHDOG"]), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -379,6 +379,8 @@ class PeerMappedFetcher:
         else:
             everyone[0] = mine
         open_ = lambda h: None if h is None else h[0](*h[1])
+        # (seen on the one-GPU test transport only: two processes on ONE device mapping each other's 6.6-GB shards never return from
+        # hipIpcOpenMemHandle -- one at a time or both at once; 256-MB shards map at once.  Separate devices are the product's case.)
         self.peers = {k: [getattr(store, k) if g == shard.rank else open_(everyone[g][k]) for g in range(W)] for k in ("codes", "vals")}
         here = store.codes.device.index
         for g in range(W):
