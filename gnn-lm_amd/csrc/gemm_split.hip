@@ -275,8 +275,11 @@ bool gemm_split_eligible(const GemmParams& p) {
 int gemm_nt_split(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     const int NS = p.precision == 1 ? 2 : 3;
-    // 256x256 tiles when they still give every CU >= 2 workgroups over the launch; device-side M: 128
-    const bool big = !p.m_dev && cdiv(p.M, 256) * cdiv(p.N, 256) >= 512;
+    // 256x256 tiles when they still give every CU >= 2 workgroups over the launch.  A device-side M is a small fraction of its bound
+    // where the bound is a token count (the softmax tails: 128-tiles), and of the order of the bound where it counts the slot rows
+    // of a batch's context groups (ABI 9: the ntgt projections of a multi-layer step, M >= 2^17 -- merged groups are a good
+    // third of all groups or more): those keep the big tiles (round 5: 22.2 k -> 25 k tokens/s on the 3-layer recipe under bf16x3)
+    const bool big = (!p.m_dev || p.M >= (1 << 17)) && cdiv(p.M, 256) * cdiv(p.N, 256) >= 512;
     const int T = big ? 256 : 128;
     const int KS = (int)cdiv(p.K, SK * 2) * 2;           // 16-k steps, zero-padded to a whole number of stages
     const int64_t rbA = cdiv(p.M, T) * (T / 64), rbW = cdiv(p.N, T) * (T / 64);
