@@ -489,39 +489,39 @@ class HGT(nn.Module):
                     merged = False
                 else:
                     group_ids, _, group_index, counters = _group_assign(flat, st.n_store, table)
-        if merged:
-            io.group_ids, io.n_unique, io.group_index = group_ids.data_ptr(), flat.numel(), group_index.data_ptr()
-            io.n_unique_dev = counters.data_ptr()
-            keep += [group_ids, group_index, counters, hit]
-            self._last_groups = (flat.numel(), counters)
-            if fetcher is not None:                                           # every distinct centre row is requested ONCE
-                fetched = fetcher.fetch_groups(group_ids, G.left, G.right, counters) + (False,)
-        elif fetcher is not None and G.fetched_codes is None:
-            centres_only = self.n_layers == 1 and not return_ntgt
-            fetched = fetcher.fetch_codes(ids, G.left, G.right, centres_only) + (centres_only,)
-        if fetched[0] is not None:
-            # (an EMPTY answer -- every group of the batch was a cache hit -- has no address, and a null fetched_codes means "read the
-            # local table" to the C side: name real memory)
-            real = lambda t, dt: t if t.numel() else torch.zeros(16, dtype=dt, device=tgt.device)
-            fc, fv, fi = real(fetched[0], torch.uint8), fetched[1], fetched[2]
-            io.fetched_codes = fc.data_ptr()
-            if fv is not None:
-                fv = real(fv, torch.uint8)
-                io.fetched_valid = fv.data_ptr()
-            io.fetched_centres_only = int(fetched[3])
-            if fi is not None:
-                fi = real(fi, torch.int32)
-                io.fetched_index = fi.data_ptr()
-            keep.append((fc, fv, fi))
-        out_tgt = torch.empty_like(tgt)
-        io.out_tgt = out_tgt.data_ptr()
-        S = ids.shape[0] * G.kg * n_g
-        if return_ntgt:
-            out_ntgt = torch.empty(S, self.hidden_dim, device=tgt.device, dtype=torch.float32)
-            out_valid = torch.empty(S, device=tgt.device, dtype=torch.uint8)
-            io.out_ntgt, io.out_valid = out_ntgt.data_ptr(), out_valid.data_ptr()
         L = _lib.lib()
-        try:
+        try:                                  # (from here on a failure leaves assigned cache slots without states: the cache is cleared)
+            if merged:
+                io.group_ids, io.n_unique, io.group_index = group_ids.data_ptr(), flat.numel(), group_index.data_ptr()
+                io.n_unique_dev = counters.data_ptr()
+                keep += [group_ids, group_index, counters, hit]
+                self._last_groups = (flat.numel(), counters)
+                if fetcher is not None:                                           # every distinct centre row is requested ONCE
+                    fetched = fetcher.fetch_groups(group_ids, G.left, G.right, counters) + (False,)
+            elif fetcher is not None and G.fetched_codes is None:
+                centres_only = self.n_layers == 1 and not return_ntgt
+                fetched = fetcher.fetch_codes(ids, G.left, G.right, centres_only) + (centres_only,)
+            if fetched[0] is not None:
+                # (an EMPTY answer -- every group of the batch was a cache hit -- has no address, and a null fetched_codes means "read the
+                # local table" to the C side: name real memory)
+                real = lambda t, dt: t if t.numel() else torch.zeros(16, dtype=dt, device=tgt.device)
+                fc, fv, fi = real(fetched[0], torch.uint8), fetched[1], fetched[2]
+                io.fetched_codes = fc.data_ptr()
+                if fv is not None:
+                    fv = real(fv, torch.uint8)
+                    io.fetched_valid = fv.data_ptr()
+                io.fetched_centres_only = int(fetched[3])
+                if fi is not None:
+                    fi = real(fi, torch.int32)
+                    io.fetched_index = fi.data_ptr()
+                keep.append((fc, fv, fi))
+            out_tgt = torch.empty_like(tgt)
+            io.out_tgt = out_tgt.data_ptr()
+            S = ids.shape[0] * G.kg * n_g
+            if return_ntgt:
+                out_ntgt = torch.empty(S, self.hidden_dim, device=tgt.device, dtype=torch.float32)
+                out_valid = torch.empty(S, device=tgt.device, dtype=torch.uint8)
+                io.out_ntgt, io.out_valid = out_ntgt.data_ptr(), out_valid.data_ptr()
             need = L.gnnlm_hgt_workspace_bytes(ctypes.byref(m), ctypes.byref(io))
             # one arena per stream: concurrent forwards on different streams must not share scratch
             key = _lib.raw_stream()

@@ -474,3 +474,38 @@ def test_merged_multilayer_step_is_graph_capturable(dev):
                 for k in got:
                     assert torch.equal(got[k], ref[k]), (cache_slots, k)
         torch.cuda.current_stream().wait_stream(s)
+
+
+def test_cache_is_cleared_when_a_forward_fails(dev):
+    """Cache slots are assigned (on the device) BEFORE the rows' states are computed: a forward that fails in between -- here the
+    sharded store's fetch raises -- must not leave slots that later batches would read as hits.  The cache is emptied, the
+    error propagates, the next forward computes everything again and equals the un-cached result."""
+    from gnnlm_amd.hgt import HGT, NeighborGraph
+    d, H, M, dsub, T, kg, L = 64, 4, 8, 8, 8, 6, 2
+    rs = np.random.RandomState(3)
+    n_store = 300
+    codes = rs.randint(0, 256, size=(n_store, M)).astype(np.uint8)
+    cen = (rs.randn(M, 256, dsub) * 0.5).astype(np.float32)
+    A = (rs.randn(M * dsub, d) / 8).astype(np.float32)
+    b = (rs.randn(M * dsub) * 0.1).astype(np.float32)
+    store = make_store(dev, codes, cen, A, b)
+    sd = ohgt.init_hgt_weights(L, d, H, seed=2)
+    cached, plain = (HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=L, n_heads=H) for _ in range(2))
+    for mdl in (cached, plain):
+        mdl.load_state_dict(sd, strict=True)
+    plain.state_cache_gib, cached.state_cache_slots = 0.0, 512
+    nb = torch.from_numpy(rs.randint(0, n_store, size=(T, kg)).astype(np.int64)).to(dev)
+    x = torch.from_numpy(rs.randn(T, d).astype(np.float32)).to(dev)
+
+    class Broken:
+        def fetch_groups(self, *a):
+            raise RuntimeError("link down")
+
+    ref = plain(NeighborGraph(ids=nb, n_blocks=1, T=T, left=2, right=2, store=store), features={"tgt": x})["tgt"]
+    good = NeighborGraph(ids=nb, n_blocks=1, T=T, left=2, right=2, store=store)
+    assert torch.equal(cached(good, features={"tgt": x})["tgt"], ref) and cached.state_cache.used > 0
+    # (a graph with a fetcher has its own cache: code rows ride beside the states)
+    with pytest.raises(RuntimeError, match="link down"):
+        cached(NeighborGraph(ids=nb, n_blocks=1, T=T, left=2, right=2, store=store, fetcher=Broken()), features={"tgt": x})
+    assert cached.state_cache is not None and cached.state_cache.used == 0           # emptied, not left half-filled
+    assert torch.equal(cached(good, features={"tgt": x})["tgt"], ref) and cached.last_groups[1] > 0   # ... and everything computed again
