@@ -608,13 +608,17 @@ def test_pipeline_from_raw_keys(dev, tmp_path):
                       adaptive_softmax_cutoff="100,300", orig_prob_ratio=0.0, short_cut=False, quantizer_path="")
     torch.save({"args": margs, "model": sd}, str(tmp_path / "ckpt.pt"))
     lam, temp = 0.25, 1.0
-    res = eval_lm.cli_main(
-        [str(data), "--path", str(tmp_path / "ckpt.pt"), "--gen-subset", "test", "--graph", "--neighbor-context", "2", "--gcn-k", str(kg),
-         "--use-precompute-feat", "--sample-break-mode", "none", "--max-tokens", str(T), "--tokens-per-sample", str(T),
-         "--gcn-context-window", "0", "--knn-keytype", "gcn_feat", "--model-overrides",
-         "{'orig_prob_ratio': 0.0, 'quantizer_path': '%s'}" % str(data / "quantizer"),
-         "--knnlm", "--k", str(k), "--lmbda", str(lam), "--dstore-dir", str(data / "train_dstore"),
-         "--index-file", str(data / "train_dstore" / "faiss_store.cosine"), "--temperature", str(temp), "--knn-sim-func", "do_not_recomp_ip", "--probe", "8"])
+    cmd = [str(data), "--path", str(tmp_path / "ckpt.pt"), "--gen-subset", "test", "--graph", "--neighbor-context", "2", "--gcn-k", str(kg),
+           "--use-precompute-feat", "--sample-break-mode", "none", "--max-tokens", str(T), "--tokens-per-sample", str(T),
+           "--gcn-context-window", "0", "--knn-keytype", "gcn_feat", "--model-overrides",
+           "{'orig_prob_ratio': 0.0, 'quantizer_path': '%s'}" % str(data / "quantizer"),
+           "--knnlm", "--k", str(k), "--lmbda", str(lam), "--dstore-dir", str(data / "train_dstore"),
+           "--index-file", str(data / "train_dstore" / "faiss_store.cosine"), "--temperature", str(temp), "--knn-sim-func", "do_not_recomp_ip", "--probe", "8"]
+    res = eval_lm.cli_main(cmd)
+    # the recipe's literal one-block batches, in turn on three streams (the driver's default for them), each with its own IVF-PQ search
+    # in flight (two-phase search: pinned landing slots, events): the same scores
+    lit = eval_lm.cli_main(cmd + ["--batch-blocks", "0"])
+    assert lit["count"] == res["count"] and abs(lit["score_sum"] - res["score_sum"]) <= 1e-9 * abs(res["score_sum"])
     # the oracle over the produced files
     q = read_pq_quantizer(str(data / "quantizer"))
     z = np.load(str(data / "train_dstore" / "faiss_store.cosine.gnnlm.npz"))
