@@ -597,7 +597,7 @@ def driver_path(args, eng, batches, dev):
     tabs = {"n_tok": n, "d": eng.hgt.hidden_dim, "vocab": None, "n_store": st.n_store, "feats": b0.tgt_feats[:n],
             "targets": b0.targets[:n].clamp(min=4), "nbrs": b0.ids[:n], "codes": st.codes, "no_pad": True}
     out = {}
-    # one_block_per_batch: the recipe's literal batches, `--batch-blocks 0` -- successive batches in turn on 3 HIP streams (the driver's
+    # one_block_per_batch: the recipe's literal batches, `--batch-blocks 0` -- successive batches in turn on 6 HIP streams (the driver's
     # default for single-block batches: a batch is a chain of ~45 small dependent launches, 0.56 ms on the device for 0.2 ms of work);
     # ..._one_stream: the same strictly one after the other; ..._graph_capture: forward + softmax replayed from HIP graphs on those streams
     for name, max_tokens, coalesce in (("one_block_per_batch", T, 0), ("one_block_per_batch_one_stream", T, 0), ("one_block_per_batch_graph_capture", T, 0),
@@ -622,7 +622,7 @@ def driver_path(args, eng, batches, dev):
                      "tokens_per_s_wall": round(r["tokens"] / r["wall_seconds"], 1), "blocks_per_batch": max(max_tokens // T, 32 if coalesce < 0 else coalesce)}
         if len(runs) > 1:
             out[name]["tokens_per_s_wall_runs"] = [round(r_["tokens"] / r_["wall_seconds"]) for r_ in runs]
-            out[name]["streams"] = 1 if name.endswith("one_stream") else 3
+            out[name]["streams"] = 1 if name.endswith("one_stream") else 6
     return out
 
 

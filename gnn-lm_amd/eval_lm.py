@@ -102,13 +102,15 @@ def get_parser():
                    help="(this build) replay the model's forward and its softmax from HIP graphs captured once per batch shape and stream.  "
                         "Measured on the recipe's literal one-block batches: no gain -- the batch is bound by the DEVICE-side latency of its ~45 "
                         "dependent launches, not by the host that enqueues them (456 k tokens/s eager, 446 k replayed); what helps is --streams "
-                        "(several batches in flight: 0.88 M tokens/s eager on 3 streams, 0.65 M replayed on 4).  Kept as an option; not with "
+                        "(several batches in flight: 0.87 M tokens/s eager on 6 streams, 0.65 M replayed on 4).  Kept as an option; not with "
                         "--store sharded; multi-layer models are captured un-merged")
     p.add_argument("--streams", default=0, type=int,
                    help="(this build) score successive batches on this many HIP streams in turn (blocks are independent; every stream has its own "
                         "workspaces, graphs and score accumulator).  A one-block batch is a chain of ~45 small dependent launches -- 0.56 ms on the "
-                        "device for 0.2 ms of work, whoever enqueues them -- and several chains in flight overlap (measured: 0.45 M tokens/s on one stream, 0.70 on 2, 0.88 on 3, 0.71 on 4, 0.84 on 6).  0 (default): 3 when the "
-                        "batches are single blocks (the recipe's `--max-tokens 256` with --batch-blocks 0), else 1.  Not with --store sharded "
+                        "device for 0.2 ms of work, whoever enqueues them -- and several chains in flight overlap.  Measured at the full store "
+                        "(tokens/s, eight passes each): 1 stream 0.45 M; 3: 0.60 or 0.87 M and 4: 0.69 or 0.95 M depending on which hardware queues "
+                        "the streams of a call land on; 6: 0.85-0.88 M every time; 8: 0.82-0.98 M.  0 (default): 6 when the batches are single blocks "
+                        "(the recipe's `--max-tokens 256` with --batch-blocks 0), else 1.  Not with --store sharded "
                         "(collectives stay on one stream)")
     p.add_argument("--result-json", default=None,
                    help="(this build) write the run's figures (score_sum, count, ppl, tokens, seconds, per-rank sums, xGMI bytes) to this "
@@ -472,7 +474,7 @@ def main(args, tables=None, model=None):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fetcher.fixed_requests = int(t.item())
     deep = getattr(getattr(model, "hgt_decoder", None), "n_layers", 1) > 1
-    n_streams = args.streams if getattr(args, "streams", 0) > 0 else (3 if per_batch == 1 and fetcher is None and save is None else 1)
+    n_streams = args.streams if getattr(args, "streams", 0) > 0 else (6 if per_batch == 1 and fetcher is None and save is None else 1)
     if n_streams > 1 and fetcher is not None:
         raise ValueError("--streams > 1 is not available with --store sharded (the exchange's collectives stay on one stream)")
     main_stream = torch.cuda.current_stream(device)

@@ -271,7 +271,7 @@ def test_eval_lm_end_to_end(dev, tmp_path):
     # --graph-capture (this build): forward and softmax of the recipe's literal one-block batches replayed from HIP graphs, one
     # pair per batch shape (the 16-token blocks and the ragged 9-token one) -- the same scores to the bit, run after run
     plain = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", "0"])
-    for extra in ([], ["--streams", "1"], ["--streams", "3"]):          # (default for one-block batches: 3 streams in turn)
+    for extra in ([], ["--streams", "1"], ["--streams", "3"]):          # (default for one-block batches: 6 streams in turn)
         cap = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", "0", "--graph-capture"] + extra)
         assert cap["count"] == n_test and abs(cap["score_sum"] - plain["score_sum"]) <= 1e-12 * abs(plain["score_sum"])
     three = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", "0", "--streams", "3"])       # streams without graphs
@@ -615,7 +615,7 @@ def test_pipeline_from_raw_keys(dev, tmp_path):
            "--knnlm", "--k", str(k), "--lmbda", str(lam), "--dstore-dir", str(data / "train_dstore"),
            "--index-file", str(data / "train_dstore" / "faiss_store.cosine"), "--temperature", str(temp), "--knn-sim-func", "do_not_recomp_ip", "--probe", "8"]
     res = eval_lm.cli_main(cmd)
-    # the recipe's literal one-block batches, in turn on three streams (the driver's default for them), each with its own IVF-PQ search
+    # the recipe's literal one-block batches, in turn on six streams (the driver's default for them), each with its own IVF-PQ search
     # in flight (two-phase search: pinned landing slots, events): the same scores
     lit = eval_lm.cli_main(cmd + ["--batch-blocks", "0"])
     assert lit["count"] == res["count"] and abs(lit["score_sum"] - res["score_sum"]) <= 1e-9 * abs(res["score_sum"])

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
-sys.argv = [sys.argv[0], "--no-cpu-baseline", "--no-parity", "--no-extras", "--n-store", "4000000"]
+sys.argv = [sys.argv[0], "--no-cpu-baseline", "--no-parity", "--no-extras", "--n-store", os.environ.get("N_STORE", "4000000")]
 args = bench.parse()
 dev = torch.device("cuda:0")
 eng, shard, sharded, cpu_model, (d, vocab) = bench.build(args, dev, 0, 1)
@@ -35,7 +35,7 @@ class Knn:
 tabs = {"n_tok": n, "d": d, "vocab": None, "n_store": st.n_store, "feats": cat("tgt_feats"), "targets": cat("targets").clamp(min=4), "nbrs": cat("ids"),
         "codes": st.codes, "no_pad": True}
 VARIANTS = [[], ["--graph-capture"]] if not os.environ.get("SWEEP") else \
-    [["--streams", "1"], ["--streams", "2"], ["--streams", "3"], ["--streams", "4"], ["--streams", "6"], ["--streams", "8"], ["--graph-capture", "--streams", "1"], ["--graph-capture", "--streams", "4"]] * 2
+    ([["--streams", os.environ.get("NS", "3")]] * 8 if os.environ.get("SWEEP") == "3" else [["--streams", "1"], ["--streams", "2"], ["--streams", "3"], ["--streams", "4"], ["--streams", "6"], ["--streams", "8"], ["--graph-capture", "--streams", "1"], ["--graph-capture", "--streams", "4"]] * 2)
 for extra in VARIANTS:
     a = eval_lm.get_parser().parse_args(extra + ["-", "--path", "-", "--graph", "--use-precompute-feat", "--neighbor-context", "2", "--gcn-k", str(args.gcn_k),
                                                  "--tokens-per-sample", str(T), "--max-tokens", str(T), "--knnlm", "--k", str(args.k), "--lmbda", "0.25", "--temperature", "0.01",
