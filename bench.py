@@ -33,7 +33,11 @@ import torch
 
 PEAK = {"mfma_f32_tflops": 157.3, "mfma_bf16_tflops": 2500.0, "hbm_gbs": 8000.0}   # MI355X_MICROARCH.md chip table
 SPLIT_PRODUCTS = {"f32": 1, "bf16x3": 3, "bf16x6": 6}            # bf16 MFMA products issued per f32 multiply-add
-KERNEL_BOUND = {"gemm_nt_f32_kernel": "mfma", "causal_attn_kernel": "mfma"}     # everything else on this path: hbm
+KERNEL_BOUND = {"gemm_nt_f32_kernel": "mfma", "causal_attn_kernel": "mfma", "ivfpq_scan8_kernel": "mfma", "ivfpq_sums_kernel": "mfma"}     # everything else on this path: hbm
+# rocprof kernel names (profiles/pmc_traffic.json keys) behind a profile id of the library (csrc/common.h KernelId)
+PMC_FAMILIES = {"gemm_nt_f32_kernel": ["gemm_nt_f32", "gemm_lse_astationary"],
+                "ivfpq_scan8_kernel": ["ivfpq_scan8_kernel<false>", "search:ivfpq_scan8_kernel<false>"],
+                "ivfpq_sums_kernel": ["ivfpq_scan8_kernel<true>", "search:ivfpq_scan8_kernel<true>"]}
 
 
 def parse():
@@ -84,6 +88,15 @@ def parse():
                     help="graph-neighbour ids of the timed batches: i.i.d. uniform over the store (the headline: worst-case locality, no two "
                          "context groups coincide) or SEARCHED over a clustered synthetic corpus (searched_neighbour_ids: what the pipeline's own "
                          "kNN producer returns; equal context groups exist and are merged -- with a sharded store BEFORE the exchange)")
+    ap.add_argument("--search", choices=["device", "given"], default="device",
+                    help="device (default): the kNN search of every step's own queries runs on the device INSIDE the timed step (synthetic "
+                         "OPQ64_1024,IVF4096,PQ64 index over --n-store keys, nprobe 32, k = --k; one replica per rank), as it runs inside the "
+                         "reference's timer (fairseq_cli/eval_lm.py:214-219 -> knn_model.py:100); given: the batches carry precomputed search "
+                         "results (`value_search_given` of the default run).  --small / --graph / --shard-vals runs use `given`")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="--search device: batches in flight, each on its own HIP stream (the host looks at a search's survivor counts when it "
+                         "comes back to that batch; the latency-bound kernels of one batch's search run beside another batch's GEMMs). "
+                         "1 = one batch at a time on one stream.  A sharded store keeps 1 (the exchange's collectives stay on one stream)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the sharded-store exchange even with one rank (exercises the RCCL path on one GPU)")
     return ap.parse_args()
@@ -671,7 +684,7 @@ def search_check(idx, q, k, n_check):
     return out
 
 
-def knn_search(args, eng, batches, dev, step_ms, l3_ids=None):
+def knn_search(args, eng, batches, dev, step_ms, l3_ids=None, idx=None):
     """The kNN SEARCH the headline step leaves out (the reference runs it on the CPU with faiss inside its timer,
     knn_model.py:100 under fairseq_cli/eval_lm.py:214-219): the step's queries (the HGT features of one batch) through the
     on-device IVF-PQ search over a synthetic index of the reference's index shape (OPQ64_1024,IVF4096,PQ64, nprobe 32,
@@ -680,11 +693,13 @@ def knn_search(args, eng, batches, dev, step_ms, l3_ids=None):
     from dataclasses import replace
     from gnnlm_amd import _lib
     from gnnlm_amd.synthetic import synthetic_ivfpq_index
-    idx = synthetic_ivfpq_index(args.n_store, eng.hgt.hidden_dim, 4096, 64, dev, nprobe=32)
-    idx.attach_vals(eng.store.vals)                                       # index key ids = store rows: payload = id << 24 | label
+    built_here = idx is None
+    if built_here:
+        idx = synthetic_ivfpq_index(args.n_store, eng.hgt.hidden_dim, 4096, 64, dev, nprobe=32)
+        idx.attach_vals(eng.store.vals)                                   # index key ids = store rows: payload = id << 24 | label
     q = eng.features(batches[0])
     q = q / q.norm(dim=1, keepdim=True)                                   # knn_model.py:181-184 (cosine index)
-    check = search_check(idx, q, args.k, args.search_check) if args.search_check > 0 else None
+    check = search_check(idx, q, args.k, args.search_check) if (args.search_check > 0 and built_here) else None   # (the timed run's own gate otherwise)
     idx.search_device(q, args.k, return_vals=True)                        # same shapes as the timed call: no allocation inside it
     torch.cuda.synchronize()
     times = []
@@ -729,23 +744,7 @@ def knn_search(args, eng, batches, dev, step_ms, l3_ids=None):
     # through LDS (ds_read_b64 of 8 queries' bytes) and through the matrix core (a byte of the MFMA's A operand = 32 int8 ops)
     filt = prof.get("ivfpq_scan8_kernel", {"total_ms": 0.0, "launches": 0})
     thr = prof.get("ivfpq_sums_kernel", {"total_ms": 0.0, "launches": 0})
-    pairs_filter = st["pairs"]                                            # (query, key) pairs of all probed lists
-    lookups = pairs_filter * 64.0
-    sec = filt["total_ms"] / 1e3
-    roof = None
-    if sec > 0:
-        roof = {"kernel": "ivfpq_scan8_kernel (int8-MFMA filter over all probed lists)", "bound": "mfma",
-                "achieved": round(lookups * 32 / sec / 1e12, 1), "peak": 5000.0, "unit": "TOP/s (int8)", "frac": round(lookups * 32 / sec / 1e12 / 5000.0, 4),
-                "peak_note": "dense i8 MFMA = 2x bf16 (MI355X_MICROARCH.md); its measured 16x16x64 ceiling is 3944 TOP/s.  The sums run on "
-                             "v_smfmac_i32_16x16x128_i8 (the constant selector is the 2:4-sparse operand): `achieved` counts the dense-equivalent "
-                             "ops of the table bytes (32 per byte) and is priced against the DENSE peak",
-                "frac_of_measured_ceiling": round(lookups * 32 / sec / 1e12 / 3944.0, 4),
-                "lds_lookup_bytes_per_s_TB": round(lookups / sec / 1e12, 2), "lds_frac_of_150TBps": round(lookups / sec / 1e12 / 150.0, 4),
-                "list_bytes_GBps": round(pairs_filter / 8 * 64 / sec / 1e9, 1),
-                "avg_us": round(filt["total_ms"] * 1e3 / max(1, filt["launches"]), 1), "launches": filt["launches"],
-                "table_byte_lookups": lookups, "traffic": pmc_traffic("search:ivfpq_scan8_kernel<false>")[0],
-                "traffic_note": "HBM bytes of the launch (FETCH_SIZE x 2 + WRITE_SIZE from tools/profile_search.sh's own PMC passes, profiles/pmc_traffic.json): "
-                                "the list bytes above are what the groups request; most of them hit in the XCD's L2"}
+    roof = filter_roofline(filt["total_ms"], filt["launches"], st["pairs"], pmc_traffic("ivfpq_scan8_kernel")[0]) if filt["total_ms"] > 0 else None
     # THROUGH THE DROP-IN DRIVER: eval_lm.main -> SequenceScorer.generate -> KNNModel.interpolate with the search inside the
     # reference's own timer (fairseq_cli/eval_lm.py:214-219), 32 one-block batches per launch as in `driver_path`
     drv = None
@@ -856,6 +855,26 @@ def knn_search(args, eng, batches, dev, step_ms, l3_ids=None):
             "tokens_per_s_step_plus_search": round(n / (dt + step2), 1)}
 
 
+def filter_roofline(total_ms, launches, pairs, traffic=None):
+    """Roofline line of the search's dominant kernel, the int8-MFMA filter: one table byte per (query, key, sub-quantizer) goes
+    through LDS (ds_read_b64 of 8 queries' bytes) and through the matrix core (a byte of the MFMA's operand = 32 int8 ops).
+    `pairs`: (query, key) pairs of all probed lists over the `launches` launches (device-side list lengths)."""
+    lookups = pairs * 64.0
+    sec = max(total_ms, 1e-9) / 1e3
+    return {"kernel": "ivfpq_scan8_kernel (int8-MFMA filter over all probed lists)", "bound": "mfma",
+            "achieved": round(lookups * 32 / sec / 1e12, 1), "peak": 5000.0, "unit": "TOP/s (int8)", "frac": round(lookups * 32 / sec / 1e12 / 5000.0, 4),
+            "peak_note": "dense i8 MFMA = 2x bf16 (MI355X_MICROARCH.md); its measured 16x16x64 ceiling is 3944 TOP/s.  The sums run on "
+                         "v_smfmac_i32_16x16x128_i8 (the constant selector is the 2:4-sparse operand): `achieved` counts the dense-equivalent "
+                         "ops of the table bytes (32 per byte) and is priced against the DENSE peak",
+            "frac_of_measured_ceiling": round(lookups * 32 / sec / 1e12 / 3944.0, 4),
+            "lds_lookup_bytes_per_s_TB": round(lookups / sec / 1e12, 2), "lds_frac_of_150TBps": round(lookups / sec / 1e12 / 150.0, 4),
+            "list_bytes_GBps": round(pairs / 8 * 64 / sec / 1e9, 1),
+            "avg_us": round(total_ms * 1e3 / max(1, launches), 1), "launches": launches,
+            "table_byte_lookups": lookups, "traffic": traffic,
+            "traffic_note": "HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE from the PMC passes, profiles/pmc_traffic.json): "
+                            "the list bytes above are what the groups request; most of them hit in the XCD's L2"}
+
+
 def roofline_entry(name, e, precision="f32"):
     """One kernel's roofline line from its event-timed profile entry (launches, total_ms, algorithmic flops / bytes)."""
     bound = KERNEL_BOUND.get(name, "hbm")
@@ -929,8 +948,9 @@ def pmc_traffic(kernel):
     meta = t.pop("_meta", {})
     if meta.get("kernel_source_hash") != kernel_source_hash():
         return None, f"profiles/pmc_traffic.json ({meta.get('profile', 'unstamped')}) was measured on other kernel sources"
-    family = kernel[:-len("_kernel")] if kernel.endswith("_kernel") else kernel     # gemm_nt_f32_kernel + gemm_nt_f32_dma_kernel
-    rows = [v for k, v in t.items() if k.startswith(family)]
+    # the instantiations a profile id covers (csrc/common.h KernelId -> the kernels launched under it)
+    fams = PMC_FAMILIES.get(kernel) or [kernel[:-len("_kernel")] if kernel.endswith("_kernel") else kernel]
+    rows = [v for k, v in t.items() if any(k.startswith(f_) for f_ in fams)]
     n = sum(v["launches"] for v in rows)
     if not n:
         return None, "kernel not in the profile"
@@ -941,7 +961,8 @@ def launch_ranks(args):
     """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): start the N ranks ourselves -- one process
     per GPU under torch.distributed.run, the launch the driver's own command line names -- relay their output (rank 0 prints the
     JSON line) and return the launcher's exit code.  Runs BEFORE this process touches the GPU, and the ranks are CHILD
-    processes (never an exec of a process that initialised HIP).  `torch.cuda.device_count()` does not initialise the device."""
+    processes (never an exec of a process that initialised HIP; `torch.cuda.device_count()` may initialise the HIP runtime in this
+    parent -- harmless for child processes, and the reason nothing here may ever become an exec)."""
     import socket
     import subprocess
     one_gpu_test = os.environ.get("GNNLM_BENCH_BACKEND", "nccl") != "nccl"     # tests: N ranks on device 0 over gloo
@@ -999,6 +1020,7 @@ def main():
             dist.all_reduce(h, op=op)
             t.copy_(h)
 
+    transport = dist.get_backend() if dist.is_initialized() else None   # what the collectives really run on: "nccl" (= RCCL) or the tests' "gloo"
     from gnnlm_amd import _lib, ops
     from gnnlm_amd.dist import PeerMappedFetcher, ShardedFetcher
     eng, shard, sharded, cpu_model, (d, vocab) = build(args, dev, rank, world)
@@ -1037,6 +1059,15 @@ def main():
     elif sharded:
         fetcher = ShardedFetcher(eng.store, shard, mode=args.exchange)
     centres_only = args.layers == 1
+    # ---- --search device: the kNN index the step searches (one full replica per rank: 6.6 GB of codes + their tile image + the
+    # payloads next to a 13-GB code store; what is range-sharded over the ranks is the GRAPH's store, BASELINE.json configs[2])
+    search_mode = "given" if (args.small or args.graph or args.shard_vals or args.lmbda <= 0) else args.search
+    idx = None
+    if search_mode == "device":
+        from gnnlm_amd.synthetic import synthetic_ivfpq_index
+        idx = synthetic_ivfpq_index(args.n_store, eng.hgt.hidden_dim, 4096, 64, dev, nprobe=32)
+        idx.attach_vals(eng.store.vals)                           # index key ids = store rows: payload = id << 24 | label
+    n_lanes = max(1, args.lanes) if (idx is not None and fetcher is None and args.streams == 1) else 1
     # multi-layer model: the engine fetches inside the step, AFTER merging equal context groups -- one request per distinct centre
     # row of the batch (hgt.py; the one-layer step prefetches the next batch's centre rows on a side stream instead, below)
     fetch_in_step = fetcher is not None and args.layers > 1
@@ -1090,14 +1121,39 @@ def main():
                     t.record_stream(cur)
             b.fetched_codes, b.fetched_valid, b.fetched_index, b.knn_vals = codes, valid, index, kv
             b.fetched_centres_only = centres_only
-        out = eng.score(b, args.lmbda, args.temperature)
+        out = eng.score(b, args.lmbda, args.temperature, knn_index=idx, k=args.k)
         ops.masked_sum_f64(out["logp"], None, a)                  # score_sum (eval_lm.py:273)
         if fetch_in_step and len(merged_counts) < 64:
             merged_counts.append(eng.hgt._last_groups)            # (n, device counter) -- read after the run
         if fetcher is not None and not fetch_in_step and prefetch_next is not None:
             issue_fetch(prefetch_next)                            # host waits for the split sizes while the GPU computes
 
+    # --search device with --lanes > 1: batch i runs on lane i % lanes (its own stream, its own accumulator); the lane's previous
+    # batch is finished (the search's one host read, the interpolation) right before the lane's next batch is enqueued
+    lane_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_lanes - 1)]
+    lane_accs = [acc] + [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(n_lanes - 1)]
+    lane_pending = [None] * n_lanes
+    for s_ in lane_streams[1:]:
+        s_.wait_stream(lane_streams[0])
+
+    def finish_lane(j):
+        if lane_pending[j] is not None:
+            with torch.cuda.stream(lane_streams[j]):
+                out = eng.score_finish(lane_pending[j])
+                ops.masked_sum_f64(out["logp"], None, lane_accs[j])
+            lane_pending[j] = None
+
+    def drain_lanes():
+        for j in range(n_lanes):
+            finish_lane(j)
+
     def step(i, last=False):
+        if n_lanes > 1:
+            j = i % n_lanes
+            finish_lane(j)
+            with torch.cuda.stream(lane_streams[j]):
+                lane_pending[j] = eng.score_begin(batches[i % len(batches)], args.lmbda, args.temperature, knn_index=idx, k=args.k)
+            return
         main = torch.cuda.current_stream()
         for s_i in range(args.streams):
             bi = i * args.streams + s_i
@@ -1110,6 +1166,7 @@ def main():
                     score_one(bi, accs[s_i], None)
 
     def barrier():
+        drain_lanes()                                             # (batches still in flight on the lanes belong to the steps before the barrier)
         torch.cuda.synchronize()                                  # all streams of this device
         if world > 1:
             dist.barrier()
@@ -1144,15 +1201,24 @@ def main():
     # would otherwise be charged to whatever kernel they happen beside: event / pinned-slot pools, profiler tool start-up)
     step(0)
     barrier()
+    search_gate = None
+    if idx is not None and rank == 0 and args.search_check > 0 and not args.no_parity:
+        # the search the step is about to run, against the float64 oracle on the step's own queries (refuses to go on otherwise)
+        q0 = eng.features(batches[0])
+        search_gate = search_check(idx, (q0 / q0.norm(dim=1, keepdim=True)).contiguous(), args.k, args.search_check)
+        del q0
     for i in (1, 2):
         _lib.profile_begin()
         step(i)
+        drain_lanes()
         torch.cuda.synchronize()
         kern = _lib.profile_end()
     for i in range(max(0, args.warmup - 3)):
         step(i + 3)
     dominant = max(kern, key=lambda k_: kern[k_]["total_ms"])
-    names = [_lib.lib().gnnlm_kernel_name(i).decode() for i in range(12)]
+    names = []
+    while _lib.lib().gnnlm_kernel_name(len(names)) is not None:
+        names.append(_lib.lib().gnnlm_kernel_name(len(names)).decode())
     if fetch_in_step and isinstance(fetcher, ShardedFetcher) and args.exchange == "padded" and eng.hgt._last_groups is not None:
         # merged requests in the fixed-capacity exchange: buckets sized from the distinct-group count the warm-up measured (agreed
         # among the ranks by a MAX all-reduce, here, outside the timed region) instead of the worst case
@@ -1175,6 +1241,7 @@ def main():
                 step(nstep[0])
             nstep[0] += 1
         settle["sclk_mhz_under_load"] = read_sclk(local_rank, sysfs_only=True)     # the chunk is still running on the device
+        drain_lanes()
         torch.cuda.synchronize()
         el = time.perf_counter() - tc
         if world > 1:                                             # every rank must take the same decision: the steps hold collectives
@@ -1190,7 +1257,7 @@ def main():
     settle["seconds"] = round(settle["seconds"], 3)
     # ---- timed region: exactly K steps, the dominant kernel bracketed by HIP events on its stream; one more event per step
     # boundary on the same stream gives the per-step times (median / min / max beside the wall-clock mean)
-    for a in accs:
+    for a in accs + lane_accs:
         a.zero_()
     pending.clear()                                               # nothing fetched ahead of the timed region
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -1217,9 +1284,30 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         prof = _lib.profile_end()[dominant]
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if args.streams == 1 else []
-    for a in accs[1:]:
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if args.streams == 1 and n_lanes == 1 else []
+    for a in accs[1:] + lane_accs[1:]:
         acc += a
+    # ---- the same K steps with the search results GIVEN (the batches' precomputed sims / ids: rounds 1-5 quoted this as `value`)
+    given = None
+    search_stats = None
+    if idx is not None:
+        search_stats = {k_: (float(v_.item()) if torch.is_tensor(v_) else v_) for k_, v_ in idx.stats.items()}
+        if fetcher is None:
+            acc_g = torch.zeros(1, device=dev, dtype=torch.float64)
+            run_g = lambda i: ops.masked_sum_f64(eng.score(batches[i % len(batches)], args.lmbda, args.temperature)["logp"], None, acc_g)
+            for i in range(3):
+                run_g(i)
+            barrier()
+            t0g = time.perf_counter()
+            for i in range(args.steps):
+                run_g(i)
+            barrier()
+            dtg = time.perf_counter() - t0g
+            if world > 1:
+                ttg = torch.tensor([dtg], device=dev, dtype=torch.float64)
+                all_reduce(ttg, dist.ReduceOp.MAX)
+                dtg = ttg.item()
+            given = {"tokens_per_s": round(args.steps * args.blocks * args.tokens_per_sample * world / dtg, 1), "ms_per_step": round(dtg / args.steps * 1e3, 4)}
     link_bytes_per_step = replicated = None
     merged_groups = None
     if fetcher is not None:
@@ -1270,7 +1358,7 @@ def main():
         drv = driver_path(args, eng, batches, dev)
         l3_ids = recipe.pop("_l3_ids", None) if recipe is not None else None
         if args.precision == "f32":
-            search = knn_search(args, eng, batches, dev, dt / args.steps * 1e3, l3_ids)
+            search = knn_search(args, eng, batches, dev, dt / args.steps * 1e3, l3_ids, idx=idx)
         del l3_ids
     if recipe is not None and search is not None and recipe["tokens_per_step"] == 4096:
         # step + on-device search of the step's own queries (what the reference's timer spans), for the recipe's lines
@@ -1317,13 +1405,15 @@ def main():
         return out
 
     def roof(name, e):
+        if name == "ivfpq_scan8_kernel" and search_stats is not None:
+            return filter_roofline(e["total_ms"], e["launches"], search_stats["pairs"] * e["launches"], pmc_traffic(name)[0])
         r_ = roofline_entry(name, e, args.precision)
         if name == "knn_interp_kernel" and knn_ab is not None:
             r_["label_gather"] = knn_ab
         return r_
     knn_ab = knn_interp_ab() if rank == 0 else None
     if rank == 0:
-        r = roof(dominant, prof)
+        r = roof(dominant, prof)      # (the filter: `pairs` of idx.stats are the (query, key) pairs of ONE search -- every launch of the timed region scans as many)
         r["traffic"], r["traffic_source"] = pmc_traffic(dominant)
         r["launches_per_step"] = prof["launches"] / args.steps
         res = {
@@ -1336,21 +1426,34 @@ def main():
             "settle": settle, "sclk_mhz_timed_region": sclk_timed,
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "value_with_search": (search["tokens_per_s_step_plus_search"] if search is not None else None),
+            "value_includes_search": idx is not None,
+            "value_search_given": (given["tokens_per_s"] if given is not None else (round(tokens / dt, 1) if idx is None else None)),
+            "ms_per_step_search_given": (given["ms_per_step"] if given is not None else None),
             "dtype": "f32" if args.precision == "f32" else f"f32 via {args.precision} split-bf16 MFMA", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: WikiText-103 full PQ datastore in HBM, k_g={args.gcn_k}, "
                                    f"context 2+2, HGT {args.layers} layer{'s' if args.layers > 1 else ''}, kNN k={args.k} "
-                                   f"(`value`: search results given, SURVEY.md 8d; `value_with_search`: step + on-device IVF-PQ search of the same queries "
-                                   f"= what the reference's own timer spans, fairseq_cli/eval_lm.py:214-219), {args.tokens_per_sample}-token blocks",
+                                   + (f"(`value`: the step WITH the on-device IVF-PQ search of its own queries = what the reference's own timer spans, "
+                                      f"fairseq_cli/eval_lm.py:214-219 -> knn_model.py:100; `value_search_given`: the same steps with precomputed search "
+                                      f"results, SURVEY.md 8d), " if idx is not None else "(`value`: search results given, SURVEY.md 8d), ")
+                                   + f"{args.tokens_per_sample}-token blocks",
                        "n_store": args.n_store, "blocks_per_step_per_gpu": args.blocks, "streams": args.streams, "hip_graph": bool(args.graph), "tokens_per_block": args.tokens_per_sample,
                        "gcn_k": args.gcn_k, "knn_k": args.k, "hgt_layers": args.layers, "d": d, "vocab": vocab, "neighbour_ids": args.ids,
                        "lmbda": args.lmbda, "temperature": args.temperature,
-                       "store": ("range-sharded + RCCL all-to-all" if sharded else "replicated" if world > 1 else "single GPU"),
-                       "rccl_ranks": world if dist.is_initialized() else 0,
+                       "knn_search": ({"where": "on the device, inside the timed step", "index": "synthetic OPQ64_1024,IVF4096,PQ64 (one replica per rank)",
+                                       "keys": args.n_store, "nprobe": 32, "k": args.k, "lanes": n_lanes,
+                                       "pairs_per_query": round(search_stats["pairs"] / max(1, search_stats["queries"])),
+                                       "survivors_per_query": round(search_stats["survivors"] / max(1, search_stats["queries"])),
+                                       "queries_searched_again_last_step": search_stats.get("requeried", 0), "parity": search_gate}
+                                      if idx is not None else {"where": "results given with the batch"}),
+                       "store": (("range-sharded + RCCL all-to-all" if transport == "nccl" else f"range-sharded + host-staged {transport} all-to-all (test transport: no RCCL, no xGMI)")
+                                 if sharded else "replicated" if world > 1 else "single GPU"),
+                       "collective_backend": transport,
+                       "rccl_ranks": world if transport == "nccl" else 0,
                        "exchange": (args.exchange if sharded else None),
                        "exchange_requests": ((("one per DISTINCT context group of the batch (merged on the device before the exchange; halo layout)" if args.layers > 1 else "centre rows only")) if sharded else None),
                        "merged_groups": merged_groups,
-                       "xgmi_bytes_per_step_per_rank": (round(link_bytes_per_step) if link_bytes_per_step is not None else None),
+                       **({"xgmi_bytes_per_step_per_rank": round(link_bytes_per_step)} if (link_bytes_per_step is not None and transport == "nccl") else
+                          {"exchange_bytes_per_step_per_rank_host_staged": round(link_bytes_per_step)} if link_bytes_per_step is not None else {}),
                        "replicated_store": replicated,
                        "gemm_precision": args.precision, "max_abs_dlogp_vs_f32": dlogp,
                        "centre_state_cache": "off in the timed region (a cycled pool would be all hits); see recipe_L3 for the cached lines",

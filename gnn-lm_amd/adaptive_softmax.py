@@ -50,6 +50,12 @@ class AdaptiveSoftmax:
         proj = [None] + [sd[f"{prefix}embed_tokens.embeddings.{i}.1.weight"] for i in range(1, len(cut))]
         return cls(cut, emb, proj, sd[f"{prefix}adaptive_softmax.head.class_proj.weight"], device)
 
+    def release_stream_state(self, keep=()):
+        """Free the scratch arenas of every stream but `keep` (raw handles): see HGT.release_stream_state."""
+        if self._ws:
+            for k_ in [k_ for k_ in self._ws if k_ not in set(keep)]:
+                del self._ws[k_]
+
     def target_log_prob(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """x [n, d] f32, target [n] int64 -> log p(target | x) [n]."""
         n = x.shape[0]

@@ -40,18 +40,19 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr int QG = 8;                                   // queries per workgroup
 constexpr int TAB_BYTES = 2 * 256 * 32 * QG;            // [half][code][slot][query]: 128 KiB
 #ifndef GNNLM_IVF8_WAVE_CAP
-#define GNNLM_IVF8_WAVE_CAP 320
+#define GNNLM_IVF8_WAVE_CAP 240
 #endif
-constexpr int WAVE_CAP = GNNLM_IVF8_WAVE_CAP;                           // survivors a wave stages per task (all 8 queries of its group)
+constexpr int WAVE_CAP = GNNLM_IVF8_WAVE_CAP;           // KEY entries (8 bytes: a key of the tile with its four queries' excesses) a wave stages per task
 constexpr int SCAN_CTL = 768;                           // behind the tables: [16 waves][8] flush counters, then {counters, thresholds, queries}[8] of the group, twice (groups alternate)
-constexpr int SCAN_LDS = TAB_BYTES + SCAN_CTL + 16 * WAVE_CAP * 4;
+constexpr int SCAN_LDS = TAB_BYTES + SCAN_CTL + 16 * WAVE_CAP * 8;
+static_assert(SCAN_LDS <= 160 * 1024, "the filter's tables + staging regions exceed a CU's LDS");
 constexpr int HIST_BINS = 1024, HIST_SHIFT = 4;         // threshold pass: sum_u (0 .. 16320) >> 4
 constexpr int SUMS_LDS = TAB_BYTES + QG * HIST_BINS * 4;  // = 160 KiB: the whole LDS of a CU
 constexpr int SURV_CNT_STRIDE = 16;                     // survivor counters one per 64-byte line: they are hammered by atomics
 constexpr int QLUT_BYTES = 64 * 256;                    // one query's quantised table
-// a survivor record is {row, list | sum_u << 18}: the key's integer sum (14 bits; SURV_SUM_BIG = "at least threshold + 1023": the
-// wave's LDS staging entry only has 10 bits for the distance to the threshold) above an 18-bit list
-constexpr int SURV_ROW_BITS = 19, SURV_LIST_BITS = 18, SURV_EXCESS_MAX = 1023, SURV_SUM_BIG = 16383;
+// a survivor record is {row, list | sum_u << 18}: the key's integer sum (14 bits; SURV_SUM_BIG = "at least threshold + 254": the
+// wave's LDS staging entry has one byte per query for the distance to the threshold) above an 18-bit list
+constexpr int SURV_ROW_BITS = 19, SURV_LIST_BITS = 18, SURV_EXCESS_MAX = 254, SURV_SUM_BIG = 16383;
 
 // codes [N, 64] row-major -> tiles of 16 rows, [tile][g 0..3][i 0..15][p 0..15] = code[16 tile + i][16 g + (i + p) % 16];
 // rows beyond N are zero.  One thread per (row, g).
@@ -276,7 +277,8 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         advance_slow();
         continue;
     }
-    uint32_t* wbuf = reinterpret_cast<uint32_t*>(smem + TAB_BYTES + SCAN_CTL) + wave * WAVE_CAP;   // this wave's survivors: (row - lo) << 3 | query slot
+    // this wave's staged KEY entries: {(row - lo) << 3 | 4 (g & 1), the four queries' bytes min(255, excess + 1) (0: no survivor)}
+    uint2* wbuf = reinterpret_cast<uint2*>(smem + TAB_BYTES + SCAN_CTL) + __builtin_amdgcn_readfirstlane(wave) * WAVE_CAP;   // (a wave-uniform base: scalar)
     int* wc = reinterpret_cast<int*>(smem + TAB_BYTES) + wave * QG;          // this wave's per-slot counters / first positions (a flush in the middle of a group)
     // the group's [0..8) counters / first positions, [8..16) thresholds, [16..24) queries; two copies in turn: a wave that is done with a group
     // sets the next one up while others still write the records of this one
@@ -360,8 +362,9 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
         }
         if (lane < QG) { wgc[lane] = 0; wgc[8 + lane] = Tl; wgc[16 + lane] = qs_lane; }
     }
-    // the accumulators start at -T: register r then holds the key's EXCESS over query 4 g + r's threshold, a survivor is a non-negative one
-    const v4i negT = SUMS ? v4i{0, 0, 0, 0} : v4i{-T4[0], -T4[1], -T4[2], -T4[3]};
+    // the accumulators start at 1 - T: register r then holds the key's EXCESS over query 4 g + r's threshold PLUS ONE, a survivor is a
+    // positive one -- and v_sat_pk_u8_i16 turns the four registers into the entry's four bytes (0: not a survivor)
+    const v4i negT = SUMS ? v4i{0, 0, 0, 0} : v4i{1 - T4[0], 1 - T4[1], 1 - T4[2], 1 - T4[3]};
     __syncthreads();                                                       // the tables are in place
     phase(0);
 #if GNNLM_IVF8_EXP & 1024
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.tiles) + t_lo * 1024, 0, nt * 1024, 0x00020000);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int voff = lane * 16;
+    const uint32_t rs_lane = (uint32_t)((j - row_shift) * 8) + (uint32_t)(4 * (g & 1));   // the lane's part of an entry's row word: (row << 3 | slot base) - 128 u
     auto load_tile = [&](int u) -> v4u {
 #if GNNLM_IVF8_EXP & 1
         return v4u{(uint32_t)u * 2654435761u + lane, (uint32_t)u * 40503u ^ lane, (uint32_t)u + 77u * lane, (uint32_t)u * 3u + lane};
@@ -429,40 +433,45 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
             X[2 * e + 1] = (int)x.y;
         }
     };
-    // Survivors of one tile.  A wave stages its survivors in its OWN LDS region, {row - lo, query slot} packed in a dword, at
-    // positions it computes itself: a scalar count of what it has staged so far + scalar popcounts of the compare masks + the
-    // lane's rank inside its mask (v_mbcnt).  No LDS atomic, nothing to wait for: the look-ups of the next tile that are in
-    // flight stay in flight.  A full region is flushed by the wave alone, the regions left at the end of the group by the
-    // workgroup together: one global atomic per query slot for the first positions (below).
+    // Survivors of one tile.  A wave stages KEY entries in its OWN LDS region: a lane whose key survives for at least one of its
+    // four queries writes {local row, slot base; one byte per query: min(255, excess + 1), 0 = no survivor} at a position the wave
+    // computes itself: a scalar count of what it has staged so far + the lane's rank inside the tile's ONE compare mask (v_mbcnt).
+    // Straight-line code for every tile (round 5 appended per query register, each behind its own scalar test and branch: the
+    // compare / append phase of a tile took as long as its look-ups, tools/ivf8_phases.py); no LDS atomic, nothing to wait for.
+    // A full region is flushed by the wave alone, the regions left at the end of the group by the workgroup together: one global
+    // atomic per query slot for the first positions (below).
     int wcnt = 0;                                                            // (scalar) entries staged by this wave
-    uint32_t ent[WAVE_CAP / 64];                                             // the staged entries while they are written out
-    // A staged region -> the queries' lists, in three moves: (1) every entry takes its rank among the entries of its query slot with an LDS
-    // atomic on one of 8 counters (the wave's own for a flush in the middle of a group, the workgroup's at its end), (2) lanes 0..7 turn the
-    // counters into first positions with ONE global atomic per slot, (3) every entry goes to position first[slot] + rank.  (Round 3 sorted
-    // the region by slot with ballots: 8 slots x 5 chunks of compares, ~500 vector instructions per flush against ~120.)
-    int rk[WAVE_CAP / 64];
-    auto take_ranks = [&](int* ctr) __attribute__((always_inline)) {
-        const int n = wcnt;
+    // A staged region -> the queries' lists, in two passes over the region (it stays in LDS; nothing is carried in registers between
+    // them -- round 5 kept every entry and its rank in registers across the end-of-group barriers, 10 of the kernel's 128):
+    // (1) every (entry, query) survivor adds one to its query slot's counter, an LDS atomic WITHOUT return on one of 8 counters (the
+    // wave's own for a flush in the middle of a group, the workgroup's at its end); lanes 0..7 turn the totals into first positions
+    // with ONE global atomic per slot and leave them in the counters; (2) every survivor takes its position from its slot's counter
+    // (LDS atomic with return) and goes there.
+    auto count_entries = [&](int* ctr) __attribute__((always_inline)) {
+        for (int c = lane; c < wcnt; c += 64) {
+            const uint2 e = wbuf[c];
 #pragma unroll
-        for (int x = 0; x < WAVE_CAP / 64; ++x) {
-            const bool valid = lane + 64 * x < n;
-            ent[x] = valid ? wbuf[lane + 64 * x] : 0xffffffffu;
-            rk[x] = valid ? atomicAdd(&ctr[ent[x] & 7u], 1) : 0;
+            for (int r = 0; r < 4; ++r)
+                if (e.y >> (8 * r) & 255u) atomicAdd(&ctr[(e.x & 4u) + r], 1);
         }
     };
-    auto write_entries = [&](const int* first) __attribute__((always_inline)) {
+    auto write_entries = [&](int* pos) __attribute__((always_inline)) {
+        for (int c = lane; c < wcnt; c += 64) {
+            const uint2 e = wbuf[c];
+            const uint32_t row = (uint32_t)(lo + ((e.x >> 3) & ((1u << SURV_ROW_BITS) - 1u)));
 #pragma unroll
-        for (int x = 0; x < WAVE_CAP / 64; ++x) {
-            if (ent[x] == 0xffffffffu) continue;
-            const int sl = (int)(ent[x] & 7u);
-            const int64_t at = (int64_t)first[sl] + rk[x];
-            const int Tsl = wgc[8 + sl], qsl = wgc[16 + sl];
-            if (at < p.cap && qsl >= 0) {
-                // the key's integer sum sum_u = excess + T + 128 * 64 (0 .. 16320); SURV_SUM_BIG: more than the entry could hold
-                const int ex = (int)(ent[x] >> (SURV_ROW_BITS + 3));
-                const int su = ex >= SURV_EXCESS_MAX ? SURV_SUM_BIG : min(SURV_SUM_BIG - 1, max(0, ex + Tsl + 128 * 64));
-                surv[(int64_t)qsl * p.cap + at] = uint2{(uint32_t)(lo + ((ent[x] >> 3) & ((1u << SURV_ROW_BITS) - 1u))),
-                                                        (uint32_t)list | (uint32_t)su << SURV_LIST_BITS};
+            for (int r = 0; r < 4; ++r) {
+                const int b8 = (int)(e.y >> (8 * r) & 255u);
+                if (b8 == 0) continue;
+                const int sl = (int)(e.x & 4u) + r;
+                const int64_t at = atomicAdd(&pos[sl], 1);
+                const int Tsl = wgc[8 + sl], qsl = wgc[16 + sl];
+                if (at < p.cap && qsl >= 0) {
+                    // the key's integer sum sum_u = excess + T + 128 * 64 (0 .. 16320); SURV_SUM_BIG: more than the entry's byte could hold
+                    const int ex = b8 - 1;
+                    const int su = ex >= SURV_EXCESS_MAX ? SURV_SUM_BIG : min(SURV_SUM_BIG - 1, max(0, ex + Tsl + 128 * 64));
+                    surv[(int64_t)qsl * p.cap + at] = uint2{row, (uint32_t)list | (uint32_t)su << SURV_LIST_BITS};
+                }
             }
         }
         wcnt = 0;
@@ -471,27 +480,12 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     auto flush_wave = [&]() __attribute__((always_inline)) {
         if (wcnt == 0) return;
         if (lane < QG) wc[lane] = 0;
-        take_ranks(wc);
+        count_entries(wc);
         if (lane < QG) {
             const int tot = wc[lane];
             wc[lane] = (tot > 0 && qs_lane >= 0) ? atomicAdd(&p.surv_cnt[(int64_t)qs_lane * SURV_CNT_STRIDE], tot) : 0;
         }
         write_entries(wc);
-    };
-    // entry = excess << 22 | local row << 3 | query slot: `excess` = how far the key's integer sum lies above the query's integer
-    // threshold (clamped to 1023) -- ivfpq_refine_kernel turns it into a lower bound of the key's score (SURV_ROW_BITS = 19: lists
-    // of up to 524,287 rows; the launcher checks)
-    // (excess: the register's value; rowslot: local row << 3 | query slot of the register)
-    auto append = [&](uint64_t m, bool mine, int excess, uint32_t rowslot) {   // m: the wave's mask, mine: this lane's bit
-        if (m == 0ull) return;
-        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-#if !(GNNLM_IVF8_EXP & 64)
-        if (mine) wbuf[wcnt + rank] = (uint32_t)min(excess, SURV_EXCESS_MAX) << (SURV_ROW_BITS + 3) | rowslot;
-#endif
-        wcnt = __builtin_amdgcn_readfirstlane(wcnt + __builtin_popcountll(m));   // (scalar: the compiler's divergence analysis gives up on it)
-#if GNNLM_IVF8_EXP & 128
-        wcnt = 0;
-#endif
     };
     // Software pipeline at the grain of ONE matrix instruction: the four look-ups behind instruction q of tile i + 1 are issued right after
     // instruction q of tile i has read the same registers (one set of 32 look-up registers per lane; a second set, the next tile's look-ups
@@ -531,27 +525,26 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
                 if (hist_b) atomicAdd(&hist_b[(s1 + 128 * 64) >> HIST_SHIFT], 1u);
             }
         } else {
-            // four compares straight into scalar masks; a tile with survivors (about every second one) appends them mask by mask
-            if (wcnt + 128 > WAVE_CAP) flush_wave();                         // a tile adds at most 4 x 32 entries (8 queries x 16 keys)
+            // the entry's four bytes: registers 0, 1 and 2, 3 packed as int16 pairs (one v_perm_b32 each; |value| < 2^15), saturated to
+            // unsigned bytes (v_sat_pk_u8_i16: <= 0 -> 0, > 255 -> 255), one compare for the whole lane, one LDS write
+            if (wcnt + 32 > WAVE_CAP) flush_wave();                          // a tile adds at most 32 entries (lanes 0 .. 31: 2 x 16 keys' query halves)
             tick(1);
-            const uint32_t rs0 = (uint32_t)row << 3 | (uint32_t)(4 * (g & 1));   // (slot 4 (g & 1) + r: r goes into the two zero bits)
-            if (edge) {
-                const bool in = (unsigned)row < (unsigned)len;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool sr = acc[r] >= 0 && in;
-                    append(__builtin_amdgcn_ballot_w64(sr), sr, acc[r], rs0 | r);
-                }
-            } else {
-                const uint64_t m0 = __builtin_amdgcn_ballot_w64(acc[0] >= 0), m1 = __builtin_amdgcn_ballot_w64(acc[1] >= 0),
-                               m2 = __builtin_amdgcn_ballot_w64(acc[2] >= 0), m3 = __builtin_amdgcn_ballot_w64(acc[3] >= 0);
-                if ((m0 | m1 | m2 | m3) != 0ull) {
-                    append(m0, acc[0] >= 0, acc[0], rs0 | 0u);
-                    append(m1, acc[1] >= 0, acc[1], rs0 | 1u);
-                    append(m2, acc[2] >= 0, acc[2], rs0 | 2u);
-                    append(m3, acc[3] >= 0, acc[3], rs0 | 3u);
-                }
-            }
+            uint32_t lo8, hi8;
+            const uint32_t p01 = GNNLM_PERM((uint32_t)acc[1], (uint32_t)acc[0], 0x05040100u), p23 = GNNLM_PERM((uint32_t)acc[3], (uint32_t)acc[2], 0x05040100u);
+            asm("v_sat_pk_u8_i16 %0, %1" : "=v"(lo8) : "v"(p01));
+            asm("v_sat_pk_u8_i16 %0, %1" : "=v"(hi8) : "v"(p23));
+            const uint32_t ex4 = GNNLM_PERM(hi8, lo8, 0x05040100u);             // (the low halves of both: whatever the instruction leaves in the upper ones)
+            // rows outside the list (the edge tiles, steps past the list's end) fail ONE unsigned compare of the entry's row word against a
+            // scalar limit: (row << 3 | slot) < lim, lim = len << 3 on an edge tile, everything elsewhere (a negative row is a huge word)
+            const uint32_t rowslot = ((uint32_t)(16 * u) << 3) + rs_lane;
+            const uint32_t lim = edge ? (uint32_t)len << 3 : 0xffffffffu;
+            uint32_t ex4r = rowslot < lim ? ex4 : 0u;
+            asm("" : "+v"(ex4r));                                            // (opaque: left alone, the compiler turns the select back into an AND of two compares and
+            const bool keep = ex4r != 0u;                                    //  re-materialises the mask through a VGPR for the ballot)
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (keep) wbuf[wcnt + rank] = uint2{rowslot, ex4r};
+            wcnt = __builtin_amdgcn_readfirstlane(wcnt + __builtin_popcountll(m));   // (scalar: the compiler's divergence analysis gives up on it)
             tick(2);
         }
     };
@@ -597,7 +590,7 @@ __global__ __launch_bounds__(NTH) void ivfpq_scan8_kernel(gnnlm_ivfpq_scan8_t p)
     // ---- end of the group: the 16 waves' regions -> the queries' lists with ONE global atomic per query slot for the whole
     // workgroup (the counters are contended: 30 lists x their groups add to every query's): the entries take their ranks on the
     // workgroup's 8 LDS counters (zeroed when the group was set up)
-    take_ranks(wgc);
+    count_entries(wgc);
     if (tid == 0) *next_s = next_index();                                    // (the next group's index rides on the same two barriers)
     phase(3);
     __syncthreads();

@@ -184,16 +184,20 @@ __global__ __launch_bounds__(256, 2) void star_dense_kernel(StarAttnParams p) {
 
 }  // namespace
 
+static size_t star_dense_lds_bytes(const StarAttnParams& p) {
+    return (size_t)(HB * p.D + 4 * HB * 2) * sizeof(float) + (size_t)p.kg * sizeof(int64_t);
+}
+
+// (the LDS bound is part of eligibility: a shape with a very large k_g keeps the generic two-pass kernel instead of failing here)
 bool star_attn_dense_eligible(const StarAttnParams& p) {
     static const bool off = getenv("GNNLM_STAR_GENERIC") != nullptr;      // A/B runs: the two-pass kernel of attn.hip
     return !off && p.X && !p.codes && !p.shards && p.H <= HB && (p.D == 256 || p.D == 512 || p.D == 1024) && p.ldx % 4 == 0 &&
-           (uintptr_t)p.X % 16 == 0 && (uintptr_t)p.U % 16 == 0 && (uintptr_t)p.Z % 16 == 0;
+           (uintptr_t)p.X % 16 == 0 && (uintptr_t)p.U % 16 == 0 && (uintptr_t)p.Z % 16 == 0 && p.kg >= 0 && star_dense_lds_bytes(p) <= 64 * 1024;
 }
 
 int star_attn_dense(const StarAttnParams& p, hipStream_t stream) {
     GNNLM_REQUIRE(star_attn_dense_eligible(p), "star_attn_dense: shape not supported");
-    const size_t lds = (size_t)(HB * p.D + 4 * HB * 2) * sizeof(float) + (size_t)p.kg * sizeof(int64_t);
-    GNNLM_REQUIRE(lds <= 64 * 1024, "star_attn_dense: k_g too large");
+    const size_t lds = star_dense_lds_bytes(p);
     dim3 grid(p.T), block(256);
     if (p.D == 1024) hipLaunchKernelGGL(star_dense_kernel<4>, grid, block, lds, stream, p);
     else if (p.D == 512) hipLaunchKernelGGL(star_dense_kernel<2>, grid, block, lds, stream, p);

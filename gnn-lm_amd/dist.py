@@ -358,6 +358,46 @@ class ShardedFetcher:
         return exchange_fetch(rows, self.shard, self._gather_vals, self.group, bucket=bucket_hip).reshape(knn_ids.shape)
 
 
+class _MapWatchdog:
+    """Fail fast instead of hanging while the peers' shards are mapped: `hipIpcOpenMemHandle` of a multi-GB shard has been seen
+    never to return (two processes on ONE device), inside a C call no Python timeout can interrupt.  A
+    helper CHILD process (plain Python, never touches the GPU; a child, not an exec of this GPU-initialised process) sleeps
+    `seconds`, then says why on stderr and kills this rank: the launcher sees a non-zero exit and takes the other ranks down.
+    Leaving the block in time stops the helper.  GNNLM_PEER_MAP_TIMEOUT (seconds, default 120; 0: no watchdog)."""
+
+    def __init__(self, what, seconds=None):
+        import os
+        self.what = what
+        self.seconds = float(os.environ.get("GNNLM_PEER_MAP_TIMEOUT", "120")) if seconds is None else float(seconds)
+        self.proc = None
+
+    def __enter__(self):
+        if self.seconds > 0:
+            import os
+            import subprocess
+            import sys
+            code = ("import os, signal, sys, time\n"
+                    "pid, secs, what = int(sys.argv[1]), float(sys.argv[2]), sys.argv[3]\n"
+                    "t0 = time.time()\n"
+                    "while time.time() - t0 < secs:\n"
+                    "    time.sleep(0.2)\n"
+                    "    if os.getppid() != pid:\n"
+                    "        sys.exit(0)\n"
+                    "sys.stderr.write('gnnlm_amd.dist: %s did not finish within %.0f s -- the peer-mapped store (--exchange peer) is not usable on this "
+                    "transport; use --exchange padded|exact.  Killing rank process %d.\\n' % (what, secs, pid))\n"
+                    "sys.stderr.flush()\n"
+                    "os.kill(pid, signal.SIGKILL)\n")
+            self.proc = subprocess.Popen([sys.executable, "-c", code, str(os.getpid()), str(self.seconds), self.what],
+                                         stdin=subprocess.DEVNULL, close_fds=True)
+        return self
+
+    def __exit__(self, *exc):
+        if self.proc is not None:
+            self.proc.kill()
+            self.proc.wait()
+        return False
+
+
 class PeerMappedFetcher:
     """The alternative to the exchange: every rank maps its peers' shards into its own address space (HIP
     IPC handles, passed round once with all_gather_object) and gathers the rows it needs itself -- ONE kernel
@@ -381,7 +421,11 @@ class PeerMappedFetcher:
         open_ = lambda h: None if h is None else h[0](*h[1])
         # (seen on the one-GPU test transport only: two processes on ONE device mapping each other's 6.6-GB shards never return from
         # hipIpcOpenMemHandle -- one at a time or both at once; 256-MB shards map at once.  Separate devices are the product's case.)
-        self.peers = {k: [getattr(store, k) if g == shard.rank else open_(everyone[g][k]) for g in range(W)] for k in ("codes", "vals")}
+        # -> under a watchdog: the rank exits non-zero with a message instead of hanging (_MapWatchdog)
+        with _MapWatchdog(f"mapping the peers' shards into rank {shard.rank} (hipIpcOpenMemHandle)"):
+            self.peers = {k: [getattr(store, k) if g == shard.rank else open_(everyone[g][k]) for g in range(W)] for k in ("codes", "vals")}
+            if store.codes.is_cuda:
+                torch.cuda.synchronize(store.codes.device)
         here = store.codes.device.index
         for g in range(W):
             if g != shard.rank and everyone[g]["device"] != here:

@@ -7,7 +7,7 @@ batch of independent token blocks:
 
     TokenGraphTransformerDecoder.forward          fairseq/models/transformer.py:943-1009
     AdaptiveSoftmax.get_log_prob + gather         fairseq/modules/adaptive_softmax.py:170-206
-    KNNModel.get_knn_prob (search results given)  knn/knn_model.py:179-217
+    KNNModel.get_knn_prob                         knn/knn_model.py:87-101 (search: on the device with ``knn_index``), 179-217
     combine_knn_and_vocab_probs                   fairseq/sequence_scorer.py:55-68
 
 Everything runs on the current HIP stream through libgnnlm_hip.so; nothing synchronises.
@@ -59,12 +59,36 @@ class GnnLmEngine:
                           max_intra_context=self.max_intra_context, fetcher=self.fetcher if batch.fetched_codes is None else None)
         return self.hgt(G, features={"tgt": tgt})["tgt"]
 
-    def score(self, batch: BlockBatch, lmbda: float = 0.0, temperature: float = 1.0):
-        """Per-token log-probabilities.  Returns dict(gcn_feat, lm_logp, logp[, p_knn, recall])."""
+    def score(self, batch: BlockBatch, lmbda: float = 0.0, temperature: float = 1.0, knn_index=None, k: int = 0):
+        """Per-token log-probabilities.  Returns dict(gcn_feat, lm_logp, logp[, p_knn, recall]).
+
+        ``knn_index`` (an ``ivfpq.IVFPQIndex`` with the labels attached): the kNN search of the step's own queries -- the
+        L2-normalised gcn_feat rows, knn_model.py:100,181-184 -- runs on the device inside the step, as it runs inside the
+        reference's timer (fairseq_cli/eval_lm.py:214-219 around sequence_scorer.py:115-120); the batch's ``knn_*`` fields are
+        then not read.  The softmax is enqueued between the search and the host's one look at its survivor counts."""
+        return self.score_finish(self.score_begin(batch, lmbda, temperature, knn_index, k))
+
+    def score_begin(self, batch: BlockBatch, lmbda: float = 0.0, temperature: float = 1.0, knn_index=None, k: int = 0):
+        """Enqueue the step up to the search's host read (features, search, softmax) and return a handle for ``score_finish``:
+        several batches can be in flight (one per stream), the host looks at a search's survivor counts only when it comes back
+        to that batch."""
         x = self.features(batch)
+        pending = None
+        if lmbda > 0.0 and knn_index is not None:
+            qn = x / (x ** 2).sum(-1, keepdim=True).sqrt()
+            pending = knn_index.search_begin(qn.contiguous(), k, return_vals=True)
         lm_logp = self.asm.target_log_prob(x, batch.targets)
+        return batch, lmbda, temperature, x, lm_logp, pending
+
+    def score_finish(self, handle):
+        batch, lmbda, temperature, x, lm_logp, pending = handle
         out = {"gcn_feat": x, "lm_logp": lm_logp, "logp": lm_logp}
-        if lmbda > 0.0:                                          # sequence_scorer.py:102
+        if pending is not None:
+            sims, ids, vals = pending.result()
+            logp, p_knn, recall = ops.knn_interp(lm_logp, sims, ids, batch.targets, temperature, lmbda,
+                                                 n_store=self.store.n_store, knn_vals=vals)
+            out.update(logp=logp, p_knn=p_knn, recall=recall, knn_sims=sims, knn_ids=ids, knn_vals=vals)
+        elif lmbda > 0.0:                                        # sequence_scorer.py:102
             if batch.knn_sims is None or batch.knn_ids is None:
                 raise ValueError("lmbda > 0 needs knn_sims / knn_ids (results of the kNN search)")
             knn_vals = batch.knn_vals

@@ -359,6 +359,11 @@ class HGT(nn.Module):
         if self.state_cache_gib <= 0 or self.n_layers < 2:
             return None
         store = G.store
+        # every cached group is taken for a VALID neighbour (the cached path carries no per-group validity): cache only when every
+        # in-range row can be read -- the whole table resident, its shards mapped, or a fetcher that brings what is not local.  A
+        # partial local table without any of these runs un-cached, where rows that are not local are excluded from the star softmax.
+        if G.fetcher is None and shards_device_ptr(store) is None and not (store.row0 == 0 and store.codes.shape[0] >= store.n_store):
+            return None
         c = self.state_cache
         # everything the cached states are a function of: the folded weights (prep key: parameters + codec), the GEMM arithmetic,
         # the context shape, and the code table itself (identity AND in-place version)
@@ -415,6 +420,17 @@ class HGT(nn.Module):
     def invalidate(self):
         """Drop the prepared (folded) weights, e.g. after swapping parameter tensors by hand."""
         self._prepared = self._plist = None
+
+    def release_stream_state(self, keep=()):
+        """Free what is held PER STREAM (the row -> group merge tables, 4 bytes per datastore row each, and the forward's scratch
+        arenas) for every stream but `keep` (raw handles): a driver that scores on its own side streams calls this when its run
+        ends -- torch hands out 32 pooled stream handles, a 103 M-row store would otherwise pin 0.4 GB per handle ever used."""
+        keep = set(keep)
+        for k_ in [k_ for k_ in self._merge_tables if k_[2] not in keep]:
+            del self._merge_tables[k_]
+        if self._prepared is not None and self._prepared.get("ws"):
+            for k_ in [k_ for k_ in self._prepared["ws"] if k_ not in keep]:
+                del self._prepared["ws"][k_]
 
     def forward(self, G: NeighborGraph, features: Dict[str, torch.Tensor] = None, etypes=None,
                 incremental_state=None, return_ntgt: bool = False):

@@ -60,14 +60,25 @@ class GnnLmModel(torch.nn.Module):
             self._forward(src_tokens, static)                     # eager once: one-time allocations happen outside the capture
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # captured ON THE LANE'S OWN STREAM: the workspaces of the HGT and of the softmax are keyed by the stream the kernels are
+            # enqueued on (hgt.py, adaptive_softmax.py) -- torch's default capture stream is one stream for every capture, i.e. every
+            # lane's graph would get the SAME scratch addresses and the graphs, replayed concurrently on different lanes, would race
+            cap = self._capture_stream()
+            with torch.cuda.graph(g, stream=cap):
                 out = self._forward(src_tokens, static)
-            e = self._graphs[key] = {"graph": g, "ids": ids, "feats": feats, "out": out, "static": static}
+            e = self._graphs[key] = {"graph": g, "ids": ids, "feats": feats, "out": out, "static": static, "capture_stream": cap}
             self._static_x.add(out[0].data_ptr())
         e["ids"].copy_(graph.ids)
         e["feats"].copy_(graph.tgt_h)
         e["graph"].replay()
         return e["out"]
+
+    @staticmethod
+    def _capture_stream():
+        """The stream a lane's graphs are captured on: the lane's own stream -- or, for the lane that runs on the default stream
+        (which cannot capture), a private stream of that lane: either way no two lanes' captures see the same stream handle."""
+        cur = torch.cuda.current_stream()
+        return torch.cuda.Stream(device=cur.device) if cur == torch.cuda.default_stream(cur.device) else cur
 
     def _forward(self, src_tokens, graph):
         bsz, tgt_len = src_tokens.shape
@@ -98,9 +109,10 @@ class GnnLmModel(torch.nn.Module):
                 self.adaptive_softmax.target_log_prob(x.reshape(-1, d).contiguous(), tgt)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                cap = self._capture_stream()
+                with torch.cuda.graph(g, stream=cap):                          # (the lane's own stream: see _forward_replayed)
                     out = self.adaptive_softmax.target_log_prob(x.reshape(-1, d).contiguous(), tgt).view(bsz, T)
-                e = self._graphs[key] = {"graph": g, "target": tgt, "out": out, "x": x}
+                e = self._graphs[key] = {"graph": g, "target": tgt, "out": out, "x": x, "capture_stream": cap}
             e["target"].copy_(target.reshape(-1))
             e["graph"].replay()
             return e["out"]

@@ -47,6 +47,26 @@ def test_bench_contract(extra):
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "tokens/s" and cb["sample"]
 
 
+def test_bench_search_inside_the_step():
+    """The default mode of the bench at a reduced store: the IVF-PQ search of every step's own queries runs on the device inside the
+    timed step (`value`), checked against the float64 oracle first; the search-given figure rides beside it; one lane and three
+    lanes (batches in flight on separate streams) add up the same scores."""
+    common = ("--n-store", "3000000", "--blocks", "4", "--steps", "4", "--warmup", "3", "--gcn-k", "16", "--k", "64", "--settle-s", "0.05",
+              "--no-cpu-baseline", "--no-extras", "--search-check", "8")
+    out = {}
+    for lanes in ("1", "3"):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *common, "--lanes", lanes]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        r = out[lanes] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+        assert r["value_includes_search"] is True and r["value"] > 0 and r["value_search_given"] > r["value"]
+        ks = r["config"]["knn_search"]
+        assert ks["where"].startswith("on the device") and ks["lanes"] == int(lanes) and ks["parity"]["ok"] is True
+        assert ks["pairs_per_query"] > 0 and r["roofline"]["bound"] in ("hbm", "mfma")
+        assert any(k_["kernel"].startswith("ivfpq_scan8") for k_ in r["kernels"])
+    assert out["1"]["config"]["synthetic_ppl"] == out["3"]["config"]["synthetic_ppl"]
+
+
 def test_bench_modes_agree():
     """The sharded-store exchange and the HIP-graph replay reproduce the direct path's score sum."""
     a = run_bench("--no-cpu-baseline")
@@ -74,7 +94,9 @@ def test_bench_two_ranks_on_one_gpu(extra):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "weak"
     c = r["config"]
-    assert c["rccl_ranks"] == 2 and c["store"].startswith("range-sharded") and c["xgmi_bytes_per_step_per_rank"] > 0
+    # the transport is named for what it is: gloo staged through the host moved no byte over RCCL / xGMI
+    assert c["collective_backend"] == "gloo" and c["rccl_ranks"] == 0 and "xgmi_bytes_per_step_per_rank" not in c
+    assert c["store"].startswith("range-sharded") and "host-staged" in c["store"] and c["exchange_bytes_per_step_per_rank_host_staged"] > 0
     if "--shard-vals" not in extra:                                    # (the comparison run needs the full label table)
         assert c["replicated_store"]["tokens_per_s"] > 0
 
@@ -91,8 +113,8 @@ def test_bench_plain_launch_starts_its_own_ranks():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["value"] > 0 and r["config"]["rccl_ranks"] == 2
-    assert r["config"]["xgmi_bytes_per_step_per_rank"] > 0 and r["config"]["replicated_store"]["tokens_per_s"] > 0
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["config"]["rccl_ranks"] == 0 and r["config"]["collective_backend"] == "gloo"
+    assert r["config"]["exchange_bytes_per_step_per_rank_host_staged"] > 0 and r["config"]["replicated_store"]["tokens_per_s"] > 0
     # more ranks than GPUs without the one-GPU test transport: refused before anything is launched
     env.pop("GNNLM_BENCH_BACKEND")
     p = subprocess.run(cmd[:2] + ["--gpus", "64", "--small"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
@@ -118,9 +140,9 @@ def test_bench_two_ranks_merge_before_the_exchange():
     n_all, n_req = mg["context_groups_per_step"], mg["distinct_requested_per_step_mean"]
     assert n_all == 2 * 32 * 16 and 0 < n_req < 0.8 * n_all                     # searched neighbours repeat (1.45x on this tiny corpus; 2.6x at the bench's size)
     unmerged = int(n_all / 2) * 2 * (8 + 5 * 16)                                # one request per group, halo layout (M = 16)
-    assert c["xgmi_bytes_per_step_per_rank"] <= unmerged * (n_req / n_all) * 1.05
+    assert c["exchange_bytes_per_step_per_rank_host_staged"] <= unmerged * (n_req / n_all) * 1.05
     # fixed-capacity buckets: sized from the distinct count measured in the warm-up (x 1.15 + 1024, agreed by a MAX all-reduce) and never
     # above the worst case -- at this toy size the constants decide, at the bench's size the count does
     from gnnlm_amd.dist import bucket_capacity
-    assert res["padded"]["config"]["xgmi_bytes_per_step_per_rank"] <= bucket_capacity(n_all, 2) * 2 * (8 + 5 * 16)
+    assert res["padded"]["config"]["exchange_bytes_per_step_per_rank_host_staged"] <= bucket_capacity(n_all, 2) * 2 * (8 + 5 * 16)
     assert len({r["config"]["synthetic_ppl"] for r in res.values()}) == 1

@@ -169,6 +169,86 @@ def test_exchange_fetch_gloo(world, n_store):
     assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
+def _virtual_rows(rows, M):
+    """Content of the (virtual) code table at global rows: a function of the row alone, so that every rank can both serve its
+    shard and check what it receives without anybody holding 103 M rows."""
+    r = np.asarray(rows, dtype=np.int64)
+    return (((r[..., None] * 2654435761 + np.arange(M, dtype=np.int64) * 40503) >> 7) & 255).astype(np.uint8)
+
+
+def _worker_full_size(rank, world, port, q):
+    """BASELINE.json configs[2] at its REAL shard arithmetic on 8 ranks: N = 103,227,021 keys in 8 key ranges with a halo of
+    l = r = 2 rows (`Shard(..., halo_left=2, halo_right=2)`: per = 12,903,378, the last range 3 rows short), k_g = 1024 graph
+    neighbours per token, one request per context group answered by the centre's owner -- exact and fixed-capacity exchange,
+    uniform ids plus every row within 3 of a range boundary, the store's two ends and -1.  The table is virtual (`_virtual_rows`)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, M, left, right, kg, T = 103_227_021, 8, 2, 2, 1024, 8
+        hs = Shard(N, world, rank, halo_left=left, halo_right=right)
+        assert hs.per == 12_903_378 and hs.row0 == rank * hs.per
+        assert hs.n_local == (hs.per if rank < world - 1 else N - (world - 1) * hs.per) and (rank < world - 1 or hs.n_local == hs.per - 3)
+        assert hs.store_row0 == max(0, hs.row0 - left) and hs.store_row0 + hs.store_rows == min(N, hs.row0 + hs.n_local + right)
+        hlo, hhi = hs.store_row0, hs.store_row0 + hs.store_rows
+        delta = np.array([0] + list(range(-left, 0)) + list(range(1, right + 1)))
+        served = []
+
+        def gather_groups(centres):
+            c = centres.numpy()
+            served.append(len(c))
+            rows = c[:, None] + delta[None, :]
+            ok = (c[:, None] >= 0) & (rows >= 0) & (rows < N)
+            assert ((c < 0) | ((c >= hs.row0) & (c < hs.row0 + hs.n_local))).all(), "a centre this rank does not own"
+            assert ((rows[ok] >= hlo) & (rows[ok] < hhi)).all(), "a slot outside the shard and its halo"
+            out = np.zeros(rows.shape + (M,), np.uint8)
+            out[ok] = _virtual_rows(rows[ok], M)
+            return torch.from_numpy(out)
+
+        rs = np.random.RandomState(1000 + rank)
+        ids = rs.randint(0, N, size=(T, kg)).astype(np.int64)
+        edges = np.concatenate([np.arange(b - 3, b + 4) for b in range(hs.per, N, hs.per)] + [np.arange(0, 4), np.arange(N - 4, N), [-1, -1]])    # (ids are rows of the train datastore or -1: nothing beyond N - 1)
+        ids.reshape(-1)[:len(edges)] = edges                                # every boundary of every range, from every rank
+        own = hs.owner(torch.from_numpy(ids.reshape(-1))).numpy()
+        inr = (ids.reshape(-1) >= 0) & (ids.reshape(-1) < N)
+        assert np.array_equal(own[inr], np.minimum(ids.reshape(-1)[inr] // hs.per, world - 1)) and (own[~inr] == rank).all()
+        ref_rows, ref_valid = og.slot_layout(ids, N, left, right)
+        v = ref_valid.reshape(-1)
+        want = _virtual_rows(ref_rows.reshape(-1)[v], M)
+        payload, index, ovf = exchange_fetch_groups(torch.from_numpy(ids), left, right, hs, gather_groups)              # exact splits
+        got = payload.numpy()[index.numpy()]
+        assert ovf is None and np.array_equal(got[v], want) and not got[~v].any()
+        cap = bucket_capacity(ids.size, world)                                                                           # fixed capacity: 2 equal-split all-to-alls
+        assert cap % 64 == 0 and cap >= 1.25 * ids.size / world
+        payload, index, ovf = exchange_fetch_groups(torch.from_numpy(ids), left, right, hs, gather_groups, cap=cap)
+        got = payload.numpy()[index.numpy()]
+        assert int(ovf) == 0 and payload.shape[0] == (world * cap + 1) * (1 + left + right)
+        assert np.array_equal(got[v], want) and not got[~v].any()
+        # what the links carry per rank and step at this shape (DESIGN.md section 8): 8-B requests out, (1 + l + r) M-byte groups back, 7/8 remote
+        t = torch.tensor([float(sum(served))], dtype=torch.float64)
+        dist.all_reduce(t)
+        assert t.item() >= 2 * world * inr.sum() * 0.99                    # every in-range group was served once per exchange, somewhere
+        q.put((rank, "ok"))
+    except Exception as e:                                                   # pragma: no cover
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_world8_at_the_full_store_shard_arithmetic():
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_full_size, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
 def test_bucket_padded_layout():
     s = Shard(1000, 3, 1)
     rows = torch.tensor([5, 999, -1, 400, 1000, 333, 334, 700, 2], dtype=torch.int64)
@@ -189,3 +269,22 @@ def test_shard_geometry():
     s = Shard(100, 4, 1)
     rows = torch.tensor([-1, 0, 24, 25, 49, 50, 99, 100, 1000])
     assert s.owner(rows).tolist() == [1, 0, 0, 1, 1, 2, 3, 1, 1]
+
+
+def test_peer_map_watchdog_kills_a_stuck_rank_and_spares_a_finished_one():
+    """`--exchange peer` must fail fast, never hang: the watchdog around the shard mapping is a helper child process that kills the
+    rank (non-zero exit, a message on stderr) when the mapping does not return in time, and goes away when it does."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stuck = ("import sys, time; sys.path.insert(0, %r); from gnnlm_amd.dist import _MapWatchdog\n"
+             "with _MapWatchdog('mapping (test)', seconds=1.0):\n    time.sleep(60)\nprint('not reached')" % root)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", stuck], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and time.time() - t0 < 30 and "not reached" not in p.stdout
+    assert "did not finish within 1 s" in p.stderr and "--exchange padded|exact" in p.stderr
+    fine = ("import sys, time; sys.path.insert(0, %r); from gnnlm_amd.dist import _MapWatchdog\n"
+            "with _MapWatchdog('mapping (test)', seconds=1.0) as w:\n    pass\ntime.sleep(2.0); assert w.proc.poll() is not None; print('alive')" % root)
+    p = subprocess.run([sys.executable, "-c", fine], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "alive" in p.stdout and p.stderr.strip() == ""

@@ -81,3 +81,46 @@ def test_gemm_hand_placed_loop_repeatable_under_load():
         subprocess.run([sys.executable, "-c", code, f], check=True, env=dict(os.environ, GNNLM_GEMM_SCHED="0"), timeout=600, cwd=ROOT)
         ref = torch.load(f)
     assert (C0.cpu() - ref).abs().max().item() < 2e-3             # same products, another summation order inside a stage
+
+
+def test_graph_capture_lanes_have_private_workspaces():
+    """`eval_lm --graph-capture` with several lanes: every lane's graphs are captured on the lane's own stream, so their HGT / softmax
+    workspaces (keyed by the stream) are private -- graphs of different lanes replayed CONCURRENTLY at the recipe's real batch shape
+    (one 256-token block, k_g = 128, d = 1024) return, batch by batch, the bits of the eager single-stream forward.  (Captured on
+    torch's shared default capture stream they all got the same scratch addresses and raced: ADVICE r05.)"""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from gnnlm_amd.hgt import NeighborGraph
+    from gnnlm_amd.model import GnnLmModel
+    argv = sys.argv
+    sys.argv = ["bench.py", "--n-store", "2000000", "--blocks", "1", "--pool", "12"]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    dev = torch.device("cuda:0")
+    eng, _, _, _, (d, vocab) = bench.build(args, dev, 0, 1)
+    batches = bench.make_batches(args, dev, 0, d, vocab)
+    model = GnnLmModel(eng.hgt, eng.asm, None)
+
+    def run(b):
+        g = NeighborGraph(ids=b.ids, n_blocks=1, T=b.T, left=2, right=2, store=eng.store, tgt_h=b.tgt_feats)
+        tgt = b.targets.view(1, b.T)
+        out = model.forward(tgt, graph=g)
+        return out[0].clone(), model.target_log_probs(out, tgt).clone()
+    ref = [run(b) for b in batches]                                # eager, one stream
+    torch.cuda.synchronize()
+    model.graph_capture = True
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for s_ in lanes:
+        s_.wait_stream(torch.cuda.current_stream())
+    for rep in range(6):
+        got = []
+        for i, b in enumerate(batches):
+            with torch.cuda.stream(lanes[i % 3]):
+                got.append(run(b))
+        torch.cuda.synchronize()
+        for i, ((x, lp), (x0, lp0)) in enumerate(zip(got, ref)):
+            assert torch.equal(x, x0) and torch.equal(lp, lp0), (rep, i)
+    assert len({k_[-1] for k_ in model._graphs if k_[0] == "fwd"}) == 3     # one set of graphs per lane stream
