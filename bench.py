@@ -981,6 +981,14 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+_T0 = time.perf_counter()
+
+
+def stage(name):
+    """Progress on stderr (rank 0's JSON line owns stdout): which leg of the run a crash or a time-out belongs to."""
+    print(f"[bench.py {time.perf_counter() - _T0:7.1f} s] {name}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     if os.environ.get("GNNLM_BENCH_WATCHDOG"):                   # debugging aid: dump every thread's Python stack and exit after N seconds
@@ -1023,6 +1031,8 @@ def main():
     transport = dist.get_backend() if dist.is_initialized() else None   # what the collectives really run on: "nccl" (= RCCL) or the tests' "gloo"
     from gnnlm_amd import _lib, ops
     from gnnlm_amd.dist import PeerMappedFetcher, ShardedFetcher
+    if rank == 0:
+        stage("build: store, model")
     eng, shard, sharded, cpu_model, (d, vocab) = build(args, dev, rank, world)
     batches = make_batches(args, dev, rank, d, vocab)
     # --exchange peer: no collective and no fetch step for the codes -- the peers' shards are mapped into this process (HIP
@@ -1187,6 +1197,8 @@ def main():
 
     # ---- parity gate FIRST (7 s of CPU-only oracle with the GPU idle: nothing timed may follow it closely): the engine that is
     # about to be timed against the oracle on a prefix of its first block
+    if rank == 0:
+        stage("parity gate")
     parity = None
     if rank == 0 and fetcher is None and not args.no_parity:
         parity = verify_block(eng, batches[0], args, cpu_model, min(args.tokens_per_sample, 256 if args.layers == 1 else 64))
@@ -1199,6 +1211,8 @@ def main():
         dlogp = (got.double() - ref.double()).abs().max().item()
     # ---- warm-up: one plain step, then two profiled ones of which the second is kept (the first absorbs one-time costs that
     # would otherwise be charged to whatever kernel they happen beside: event / pinned-slot pools, profiler tool start-up)
+    if rank == 0:
+        stage("warm-up")
     step(0)
     barrier()
     search_gate = None
@@ -1228,6 +1242,8 @@ def main():
     # ---- settle (untimed): keep stepping back to back until at least `--settle-s` seconds of GPU work have run and two
     # successive chunks agree within 2 % -- the driver's 20-step window is 0.1 s long, and 0.1 s right after seconds of host-only
     # work is timed at whatever clock / power state the part is still ramping through (BENCH_r03: 5.58 ms against 4.73)
+    if rank == 0:
+        stage("settle")
     settle = {"seconds": 0.0, "steps": 0, "chunks_ms_per_step": []}
     chunk_n = max(10, min(args.steps, 50))
     nstep = [args.warmup]
@@ -1260,6 +1276,8 @@ def main():
     for a in accs + lane_accs:
         a.zero_()
     pending.clear()                                               # nothing fetched ahead of the timed region
+    if rank == 0:
+        stage("timed region")
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     if args.graph:
@@ -1288,6 +1306,8 @@ def main():
     for a in accs[1:] + lane_accs[1:]:
         acc += a
     # ---- the same K steps with the search results GIVEN (the batches' precomputed sims / ids: rounds 1-5 quoted this as `value`)
+    if rank == 0:
+        stage("search-given leg")
     given = None
     search_stats = None
     if idx is not None:
@@ -1351,11 +1371,16 @@ def main():
                 dtr = ttr.item()
             replicated = {"tokens_per_s": round(args.steps * args.blocks * args.tokens_per_sample * world / dtr, 1),
                           "ms_per_step": round(dtr / args.steps * 1e3, 4)}
+    if rank == 0:
+        stage("extras")
     recipe = drv = search = None
     if rank == 0 and world == 1 and fetcher is None and not args.small and args.extras:
         if args.layers == 1 and args.precision == "f32":
+            stage("extras: recipe_L3")
             recipe = recipe_l3(args, eng, batches, dev)
+        stage("extras: driver_path")
         drv = driver_path(args, eng, batches, dev)
+        stage("extras: knn_search")
         l3_ids = recipe.pop("_l3_ids", None) if recipe is not None else None
         if args.precision == "f32":
             search = knn_search(args, eng, batches, dev, dt / args.steps * 1e3, l3_ids, idx=idx)
@@ -1470,6 +1495,7 @@ def main():
         if search is not None:
             res["knn_search"] = search
         if world == 1 and not args.no_cpu_baseline:
+            stage("cpu_baseline")
             res["cpu_baseline"] = cpu_baseline(args, cpu_model)
         print(json.dumps(res))
     if dist.is_initialized():

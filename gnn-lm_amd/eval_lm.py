@@ -545,9 +545,9 @@ def main(args, tables=None, model=None):
         acc = accs[0]
         # what the model keeps per stream (merge tables of n_store x 4 bytes, scratch arenas) goes with the side lanes: the next
         # call makes new streams, and torch's pool hands out up to 32 different handles
-        for mod in (getattr(model, "hgt_decoder", None), getattr(model, "adaptive_softmax", None)):
-            if hasattr(mod, "release_stream_state"):
-                mod.release_stream_state(keep=(main_stream.cuda_stream,))
+        # (the model drops the HIP graphs it captured for those lanes with them: their launches have the workspace addresses baked in)
+        if hasattr(model, "release_stream_state"):
+            model.release_stream_state(keep=(main_stream.cuda_stream,))
     for _ in range(idle_steps):                                                             # no batch left here: serve the peers' requests
         if deep and getattr(model.hgt_decoder, "dedup_groups", False):
             fetcher.fetch_groups(torch.empty(0, dtype=torch.int64, device=device), left, right, torch.zeros(4, dtype=torch.int32, device=device))

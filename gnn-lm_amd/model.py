@@ -73,6 +73,23 @@ class GnnLmModel(torch.nn.Module):
         e["graph"].replay()
         return e["out"]
 
+    def release_stream_state(self, keep=()):
+        """Drop what is held per stream for every stream but `keep` (raw handles): the HIP graphs captured for those lanes FIRST (their
+        launches have the lanes' workspace addresses baked in), then the workspaces and merge tables themselves
+        (HGT.release_stream_state).  Called by a driver whose side lanes are gone (eval_lm.main); the caller has joined the lanes."""
+        keep = set(keep)
+        if self._graphs:
+            torch.cuda.synchronize()
+            gone = [k_ for k_ in self._graphs if k_[0] == "fwd" and k_[-1] not in keep]
+            xs = {self._graphs[k_]["out"][0].data_ptr() for k_ in gone}
+            gone += [k_ for k_ in self._graphs if k_[0] == "asm" and k_[1] in xs]
+            for k_ in gone:
+                del self._graphs[k_]
+            self._static_x = set(self._static_x) - xs
+        for mod in (self.hgt_decoder, self.adaptive_softmax):
+            if hasattr(mod, "release_stream_state"):
+                mod.release_stream_state(keep=keep)
+
     @staticmethod
     def _capture_stream():
         """The stream a lane's graphs are captured on: the lane's own stream -- or, for the lane that runs on the default stream
