@@ -1218,7 +1218,8 @@ def main():
     search_gate = None
     if idx is not None and rank == 0 and args.search_check > 0 and not args.no_parity:
         # the search the step is about to run, against the float64 oracle on the step's own queries (refuses to go on otherwise)
-        q0 = eng.features(batches[0])
+        # (with a sharded store the HGT forward is a collective step: rank 0 alone checks the search on the block's input features)
+        q0 = eng.features(batches[0]) if fetcher is None else batches[0].tgt_feats.float()
         search_gate = search_check(idx, (q0 / q0.norm(dim=1, keepdim=True)).contiguous(), args.k, args.search_check)
         del q0
     for i in (1, 2):

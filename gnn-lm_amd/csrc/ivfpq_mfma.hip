@@ -686,19 +686,21 @@ __global__ __launch_bounds__(1024) void ivfpq_tau_kernel(gnnlm_ivfpq_tau_t p) {
 #ifndef GNNLM_REFINE_NT
 #define GNNLM_REFINE_NT 1024     // threads per query (A/B: 512 was slower, 0.46 against 0.40 ms)
 #endif
+// (a workgroup's refinement as a function: its own kernel below, and the prologue of the fused refine + re-score launch.  `hist`:
+// 2048 ints of LDS the caller lends.  Returns the records left and the threshold to every thread.)
 template <int EPT>
-__global__ __launch_bounds__(GNNLM_REFINE_NT) void ivfpq_refine_kernel(gnnlm_ivfpq_refine_t p) {
+__device__ __forceinline__ void refine_wg(const gnnlm_ivfpq_refine_t& p, const int64_t q, int* hist, int& n_left, float& tau_left) {
     constexpr int NT = GNNLM_REFINE_NT, NB = 2048, NWV = NT / 64;
-    __shared__ int hist[NB];
     __shared__ int wtot[NWV];
     __shared__ int dig_s, base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t q = blockIdx.x;
     const int n = min(p.surv_cnt[q * SURV_CNT_STRIDE], p.cap);
     uint2* surv = reinterpret_cast<uint2*>(p.surv) + q * p.cap;
     const float tau0 = p.tau[q];
+    n_left = n;
+    tau_left = tau0;
     if (n < p.k || !(tau0 > -INFINITY)) {                                    // fewer survivors than k, or no threshold at all (the sums say nothing)
-        if (tid == 0) p.out_cnt[q * SURV_CNT_STRIDE] = n;
+        if (tid == 0 && p.out_cnt) p.out_cnt[q * SURV_CNT_STRIDE] = n;
         return;
     }
     const float delta = p.qmeta[q * 4], sum_lo = p.qmeta[q * 4 + 1], amax = p.qmeta[q * 4 + 2];
@@ -840,9 +842,19 @@ __global__ __launch_bounds__(GNNLM_REFINE_NT) void ivfpq_refine_kernel(gnnlm_ivf
         total = base_s;
     }
     if (tid == 0) {
-        p.out_cnt[q * SURV_CNT_STRIDE] = total;
+        if (p.out_cnt) p.out_cnt[q * SURV_CNT_STRIDE] = total;
         p.tau[q] = tau1;
     }
+    n_left = total;
+    tau_left = tau1;
+}
+
+template <int EPT>
+__global__ __launch_bounds__(GNNLM_REFINE_NT) void ivfpq_refine_kernel(gnnlm_ivfpq_refine_t p) {
+    __shared__ int hist[2048];
+    int n_left;
+    float tau_left;
+    refine_wg<EPT>(p, (int64_t)blockIdx.x, hist, n_left, tau_left);
 }
 
 // Exact float32 scores of the survivors, in the summation order of the f32 scan (ivfpq.hip scan_rot: look-up s of half h
@@ -851,14 +863,14 @@ __global__ __launch_bounds__(GNNLM_REFINE_NT) void ivfpq_refine_kernel(gnnlm_ivf
 #ifndef GNNLM_RESCORE_NT
 #define GNNLM_RESCORE_NT 1024   // threads per query (A/B, medians of 7: 1024: 1.14 ms, 512: 1.13, 256 with two workgroups per CU: 1.34)
 #endif
-template <int M>
-__global__ __launch_bounds__(GNNLM_RESCORE_NT) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore_t p) {
-    extern __shared__ __attribute__((aligned(16))) float rtab[];            // [M][256] f32, then the threads' code rows [M / 4 dwords][NT]
+// (a workgroup's re-score as a function: `n` records of query q against the threshold `tau`; TAB_READY: the query's table is already
+// on its way into rtab by LDS-DMA -- the fused launch below -- and the caller has waited for it)
+template <int M, bool TAB_READY>
+__device__ __forceinline__ void rescore_wg(const gnnlm_ivfpq_rescore_t& p, const int64_t q, const int n, const float tau, float* rtab) {
     __shared__ int ccnt;
     constexpr int NT = GNNLM_RESCORE_NT;                                    // 16 waves: the survivors' code rows are random 64-B reads
     uint32_t* cdw = reinterpret_cast<uint32_t*>(rtab + M * 256);            // dword k of thread t at [k][t]: bank = t mod 32 for stores and byte reads alike
     const int tid = threadIdx.x;
-    const int64_t q = blockIdx.x;
 #ifdef GNNLM_RESCORE_DBG
     // instrumented build (tools/rescore_phases.py): thread 0's clock64 deltas per phase in the last 8 slots of the query's candidate row
     long long dbg_t = clock64(); int dbg_i = 0;
@@ -866,7 +878,6 @@ __global__ __launch_bounds__(GNNLM_RESCORE_NT) void ivfpq_rescore_kernel(gnnlm_i
 #else
     auto dbg = [&]() {};
 #endif
-    const int n = min(p.surv_cnt[q * SURV_CNT_STRIDE], p.cap);
     if (tid == 0) ccnt = 0;
     const uint2* surv = reinterpret_cast<const uint2*>(p.surv) + q * p.cap;
     // Three loads deep, in an order that never drains the queue (s_waitcnt vmcnt counts in issue order): survivor i's code row and
@@ -888,9 +899,11 @@ __global__ __launch_bounds__(GNNLM_RESCORE_NT) void ivfpq_rescore_kernel(gnnlm_i
     float bias0 = 0.f, bias1 = 0.f;
     uint32_t rid0 = 0u, rid1 = 0u;
     if (n > 0) {
-        const float4* src = reinterpret_cast<const float4*>(p.lut + q * p.ld_lut);
-        float4* dst = reinterpret_cast<float4*>(rtab);
-        for (int e = tid; e < M * 64; e += NT) dst[e] = src[e];
+        if (!TAB_READY) {
+            const float4* src = reinterpret_cast<const float4*>(p.lut + q * p.ld_lut);
+            float4* dst = reinterpret_cast<float4*>(rtab);
+            for (int e = tid; e < M * 64; e += NT) dst[e] = src[e];
+        }
         uint2 r0, r1;
         record(tid, r0);
         record(tid + NT, r1);
@@ -903,7 +916,6 @@ __global__ __launch_bounds__(GNNLM_RESCORE_NT) void ivfpq_rescore_kernel(gnnlm_i
     dbg();                                                                   // 0: table copy, first records and rows issued
     __syncthreads();
     dbg();                                                                   // 1: barrier
-    const float tau = p.tau[q];
     const uint8_t* cb = reinterpret_cast<const uint8_t*>(cdw + tid);        // byte m of the row: cb[(m >> 2) * 4 * NT + (m & 3)]
     // one survivor: its row (set `cr`) -> LDS, the next loads issued (record i + 3 into rec_new, then row i + 2 -- named by rec_old,
     // which arrived a step ago -- into the set just freed), then the 64 look-ups
@@ -965,6 +977,51 @@ __global__ __launch_bounds__(GNNLM_RESCORE_NT) void ivfpq_rescore_kernel(gnnlm_i
     // phase and added requests: 1.22 against 1.14 ms -- the kernel runs at ~0.7 of the memory system's request rate, ~3 per record)
     for (int e = tid; e < nc; e += NT) p.cand_id[q * p.cand_cap + e] = p.payload[p.cand_id[q * p.cand_cap + e]];
     dbg();                                                                   // 4: payloads
+}
+
+template <int M>
+__global__ __launch_bounds__(GNNLM_RESCORE_NT) void ivfpq_rescore_kernel(gnnlm_ivfpq_rescore_t p) {
+    extern __shared__ __attribute__((aligned(16))) float rtab[];            // [M][256] f32, then the threads' code rows [M / 4 dwords][NT]
+    const int64_t q = blockIdx.x;
+    rescore_wg<M, false>(p, q, min(p.surv_cnt[q * SURV_CNT_STRIDE], p.cap), p.tau[q], rtab);
+}
+
+// Refinement + re-score of a query in ONE launch (round 6; gnnlm_ivfpq_rescore with `qmeta`).  The two kernels were one workgroup
+// per query each, both waiting on memory most of their time (the re-score 40 % of its 35 us for its 64-KiB table to arrive: copied
+// through registers behind a barrier -- tools/rescore_phases.py).  Here the table is requested FIRST, by LDS-DMA (no registers, nothing
+// waits for it), the refinement runs while it arrives (its histogram in the code rows' staging area), and the re-score starts on the
+// records the refinement has just compacted (in place, in the query's survivor list: this workgroup's own writes, ordered by the
+// barrier).  Same arithmetic, same order: the candidates are those of the two-launch path.
+static_assert(GNNLM_REFINE_NT == GNNLM_RESCORE_NT, "the fused refine + re-score launch runs both on one workgroup shape");
+template <int EPT>
+__global__ __launch_bounds__(GNNLM_RESCORE_NT) void ivfpq_refine_rescore_kernel(gnnlm_ivfpq_rescore_t p) {
+    constexpr int M = 64;
+    extern __shared__ __attribute__((aligned(16))) float rtab[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q = blockIdx.x;
+    const int n0 = min(p.surv_cnt[q * SURV_CNT_STRIDE], p.cap);
+    if (n0 > 0) {
+        // [64][256] f32 = 64 pieces of 1 KiB: wave w brings pieces 4 w .. 4 w + 3 (global_load_lds_dwordx4: 16 B per lane, lane order;
+        // M0 = the piece's LDS byte address).  From inline asm: the compiler's counters do not see them -- its own waits only ever
+        // get more conservative by that -- and would otherwise guard every LDS read of the refinement with vmcnt(0)
+        const float* src = p.lut + q * p.ld_lut + (4 * wave) * 256 + 4 * lane;
+        const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)rtab + (unsigned)(4 * __builtin_amdgcn_readfirstlane(wave)) * 1024u;
+        unsigned keep_;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep_) : "v"(src), "s"(dst) : "memory");
+    }
+    gnnlm_ivfpq_refine_t r;
+    r.surv = const_cast<uint32_t*>(p.surv);  r.surv_cnt = p.surv_cnt;  r.out_cnt = p.out_cnt;  r.cap = p.cap;
+    r.tau = const_cast<float*>(p.tau);  r.qmeta = p.qmeta;  r.coarse = p.coarse;  r.ld_coarse = p.ld_coarse;  r.n = p.n;  r.k = p.k;
+    int n_left;
+    float tau_left;
+    refine_wg<EPT>(r, q, reinterpret_cast<int*>(rtab + M * 256), n_left, tau_left);   // (histogram: where the code rows are staged afterwards)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's table pieces have landed (and its compacted records have left)
+    __syncthreads();                                                         // ... everybody's
+    rescore_wg<M, true>(p, q, n_left, tau_left, rtab);
 }
 
 }  // namespace
@@ -1079,6 +1136,13 @@ int ivfpq_rescore(const gnnlm_ivfpq_rescore_t& d, hipStream_t stream) {
                   "ivfpq_rescore: need M = 32 or 64, 16-byte aligned tables");
     ProfScope prof(K_RESCORE, stream, 0.0, 0.0);
     const size_t lds = (size_t)d.M * 256 * 4 + GNNLM_RESCORE_NT * (size_t)d.M;
+    if (d.qmeta) {                                                          // refinement + re-score in one launch (ABI 10)
+        GNNLM_REQUIRE(d.M == 64 && d.k > 0, "ivfpq_rescore: the fused refinement needs M = 64 and k > 0");
+        GNNLM_LDS_OPT_IN(&ivfpq_refine_rescore_kernel<8>, lds);
+        hipLaunchKernelGGL(ivfpq_refine_rescore_kernel<8>, dim3((unsigned)d.n), dim3(GNNLM_RESCORE_NT), lds, stream, d);
+        GNNLM_LAUNCH_CHECK();
+        return OK;
+    }
     if (d.M == 64) {
         GNNLM_LDS_OPT_IN(&ivfpq_rescore_kernel<64>, lds);
         hipLaunchKernelGGL(ivfpq_rescore_kernel<64>, dim3((unsigned)d.n), dim3(GNNLM_RESCORE_NT), lds, stream, d);

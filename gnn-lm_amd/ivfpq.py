@@ -233,6 +233,7 @@ class IVFPQIndex:
         if self.cand_cap is None:
             self.cand_cap = 32768 if self.tiles is not None else 16384
         self.refine_tau = os.environ.get("GNNLM_IVF_REFINE", "1") != "0"     # gnnlm_ivfpq_refine between the filter and the re-score (A/B: 0)
+        self.fuse_refine = os.environ.get("GNNLM_IVF_FUSED", "1") != "0"     # ... inside the re-score's launch (A/B: 0 = two launches)
         self.stats = {}                                                      # device-side work counters of the last search (bench.py)
 
     def attach_vals(self, vals):
@@ -564,7 +565,11 @@ class IVFPQIndex:
         sc = sc16[:, 0]
         # a tighter threshold from the survivors' own integer sums (all lists, un-binned), and only the survivors that can beat it
         rc16 = sc16
-        if self.refine_tau:
+        fused = self.refine_tau and self.fuse_refine                          # refinement inside the re-score's launch (ABI 10)
+        if fused:
+            rc16 = torch.empty_like(sc16)
+            self.stats.add("rescored", lambda rc=rc16: rc[:, 0].sum().double())
+        elif self.refine_tau:
             rc16 = torch.empty_like(sc16)
             f = _lib.gnnlm_ivfpq_refine_t()
             f.surv, f.surv_cnt, f.out_cnt, f.cap = surv.data_ptr(), sc16.data_ptr(), rc16.data_ptr(), cap
@@ -574,8 +579,10 @@ class IVFPQIndex:
         r = _lib.gnnlm_ivfpq_rescore_t()
         r.codes, r.payload, r.M = self.list_codes.data_ptr(), self.payload.data_ptr(), self.M
         r.lut, r.ld_lut, r.coarse, r.ld_coarse, r.tau = lut.data_ptr(), lut.stride(0), cs.data_ptr(), cs.stride(0), tau.data_ptr()
-        r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), rc16.data_ptr(), cap, nq
+        r.surv, r.surv_cnt, r.cap, r.n = surv.data_ptr(), (sc16 if fused else rc16).data_ptr(), cap, nq
         r.cand_val, r.cand_id, r.cand_cnt, r.cand_cap = cv.data_ptr(), ci.data_ptr(), cc.data_ptr(), ccap
+        if fused:
+            r.qmeta, r.k, r.out_cnt = qmeta.data_ptr(), k, rc16.data_ptr()
         _lib.call_desc("gnnlm_ivfpq_rescore", r)
         self.stats.add("survivors", lambda sc=sc: sc.sum().double())
         self.stats.add("candidates", lambda cc=cc: cc.sum().double())

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNLM_ABI_VERSION 9
+#define GNNLM_ABI_VERSION 10
 #define GNNLM_OK 0
 #define GNNLM_E_INVALID (-22)
 #define GNNLM_E_NOMEM (-12)
@@ -413,6 +413,10 @@ typedef struct gnnlm_ivfpq_rescore {
     const uint32_t* surv;  const int32_t* surv_cnt;  int32_t cap;
     int64_t n;
     float* cand_val;  int64_t* cand_id;  int32_t* cand_cnt;  int32_t cand_cap;
+    /* ABI 10: with `qmeta` (M = 64, k > 0) the refinement of gnnlm_ivfpq_refine runs inside the same launch, ahead of the re-score
+     * and under the arrival of the query's table: surv is compacted in place, tau[q] raised in place (both are written through
+     * these pointers), out_cnt [n, 16] int32 (column 0; optional) = records left, as there.  NULL: the re-score alone. */
+    const float* qmeta;  int32_t k;  int32_t* out_cnt;
 } gnnlm_ivfpq_rescore_t;
 int gnnlm_ivfpq_rescore(const gnnlm_ivfpq_rescore_t* desc, void* stream);
 

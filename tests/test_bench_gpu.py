@@ -101,6 +101,23 @@ def test_bench_two_ranks_on_one_gpu(extra):
         assert c["replicated_store"]["tokens_per_s"] > 0
 
 
+def test_bench_two_ranks_search_inside_the_step():
+    """The driver's scaling run in miniature: `bench.py --gpus 2` at real model shapes (reduced store), range-sharded graph store with
+    the exchange, and every rank's OWN replica of the kNN index searched inside its timed step (weak scaling: no collective on the
+    search).  Both ranks on device 0 over gloo."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n-store", "3000000", "--blocks", "4", "--steps", "3", "--warmup", "3",
+           "--gcn-k", "16", "--k", "64", "--settle-s", "0.05", "--no-cpu-baseline", "--no-extras", "--search-check", "8"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GNNLM_BENCH_BACKEND="gloo", GNNLM_BENCH_DEVICE="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c = r["config"]
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["value_includes_search"] is True and r["scaling"] == "weak"
+    assert c["knn_search"]["where"].startswith("on the device") and c["knn_search"]["lanes"] == 1 and c["knn_search"]["parity"]["ok"] is True
+    assert c["store"].startswith("range-sharded") and c["collective_backend"] == "gloo" and c["rccl_ranks"] == 0
+
+
 def test_bench_plain_launch_starts_its_own_ranks():
     """`python bench.py --gpus 2` with NO launcher around it (what the driver's scaling run types): the script starts the two
     ranks itself as child processes, relays rank 0's one JSON line and the exit code.  Both ranks on device 0 over gloo."""
