@@ -45,7 +45,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--blocks", type=int, default=32, help="256-token blocks per step per GPU")
+    ap.add_argument("--blocks", type=int, default=None,
+                    help="256-token blocks per step per GPU; default 128 for the 1-layer model, 16 for deeper ones (their workspace is 3.3 GB per block).  "
+                         "(rounds 1-5: 32; with the search inside the step a batch of 128 blocks = 32768 queries fills "
+                         "the search's 8-query groups and keeps a list's bytes in L2 across them: 548 k tokens/s against 513 k at 32, 535 k at 64, 547 k at 256)")
     ap.add_argument("--layers", type=int, default=1, help="HGT layers (configs[1]: 1; the shipped recipe: 3)")
     ap.add_argument("--n-store", type=int, default=103227021)
     ap.add_argument("--gcn-k", type=int, default=128)
@@ -93,13 +96,16 @@ def parse():
                          "OPQ64_1024,IVF4096,PQ64 index over --n-store keys, nprobe 32, k = --k; one replica per rank), as it runs inside the "
                          "reference's timer (fairseq_cli/eval_lm.py:214-219 -> knn_model.py:100); given: the batches carry precomputed search "
                          "results (`value_search_given` of the default run).  --small / --graph / --shard-vals runs use `given`")
-    ap.add_argument("--lanes", type=int, default=3,
+    ap.add_argument("--lanes", type=int, default=2,
                     help="--search device: batches in flight, each on its own HIP stream (the host looks at a search's survivor counts when it "
                          "comes back to that batch; the latency-bound kernels of one batch's search run beside another batch's GEMMs). "
                          "1 = one batch at a time on one stream.  A sharded store keeps 1 (the exchange's collectives stay on one stream)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the sharded-store exchange even with one rank (exercises the RCCL path on one GPU)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.blocks is None:
+        args.blocks = 128 if args.layers == 1 else 16
+    return args
 
 
 def build(args, dev, rank, world):
@@ -753,7 +759,7 @@ def knn_search(args, eng, batches, dev, step_ms, l3_ids=None, idx=None):
         import io
         from gnnlm_amd import eval_lm, ops
         from gnnlm_amd.model import GnnLmModel
-        T, nblk = args.tokens_per_sample, min(args.blocks, 32)
+        T, nblk = args.tokens_per_sample, args.blocks
         nb = nblk * T
         pool = torch.cat([b_.tgt_feats[:nb] for b_ in batches]), torch.cat([b_.targets[:nb] for b_ in batches]), torch.cat([b_.ids[:nb] for b_ in batches])
         st_ = eng.store
@@ -779,14 +785,15 @@ def knn_search(args, eng, batches, dev, step_ms, l3_ids=None, idx=None):
         a = eval_lm.get_parser().parse_args(
             ["-", "--path", "-", "--graph", "--use-precompute-feat", "--neighbor-context", "2", "--gcn-k", str(args.gcn_k),
              "--tokens-per-sample", str(T), "--max-tokens", str(T), "--knnlm", "--k", str(args.k), "--lmbda", str(args.lmbda),
-             "--temperature", str(args.temperature), "--knn-keytype", "gcn_feat", "--softmax-batch", str(nb + 1), "--device", str(dev)])
+             "--temperature", str(args.temperature), "--knn-keytype", "gcn_feat", "--softmax-batch", str(nb + 1), "--device", str(dev),
+             "--batch-blocks", str(nblk)])
         a.knn_model = SearchKnn()
         with contextlib.redirect_stdout(io.StringIO()):
             eval_lm.main(a, tables=tabs, model=model)                          # warm-up
             r_ = eval_lm.main(a, tables=tabs, model=model)
         drv = {"tokens": r_["tokens"], "tokens_per_s_generate_timer": round(r_["tokens"] / r_["seconds"], 1),
                "tokens_per_s_wall": round(r_["tokens"] / r_["wall_seconds"], 1), "blocks_per_batch": nblk,
-               "what": "eval_lm.main with the recipe's --max-tokens 256 (one-block batches, 32 per launch), kNN search on the device inside generate"}
+               "what": f"eval_lm.main with the recipe's --max-tokens 256 (one-block batches, --batch-blocks {nblk} per launch), kNN search on the device inside generate"}
         # the 3-layer recipe through the same driver with the search inside generate, on the searched-neighbour id sets of
         # recipe_L3's sensitivity points: within-batch merge only, and a cold pass of the cross-batch cache
         l3_drv = None

@@ -458,7 +458,9 @@ class IVFPQIndex:
         val = torch.empty(n, k, device=dev, dtype=torch.float32)
         idx = torch.empty(n, k, device=dev, dtype=torch.int64)
         if query_block is None:                                               # groups of 8 queries per list want many queries per block
-            query_block = 8192 if self.tiles is not None else 1024
+            # (the int8 filter groups 8 queries per list: the more queries a block holds, the fuller its groups and the longer a list's bytes
+            # stay in the XCD's L2 -- per 8192 queries 12.2 ms in blocks of 8192, 11.4 of 16384, 11.0 of 32768; ~18 GB of temporaries at 32768)
+            query_block = int(os.environ.get("GNNLM_IVF_QUERY_BLOCK", "32768")) if self.tiles is not None else 1024
         # the dense round's score rows: query_block * dense * max_list floats, bounded (a skewed index has long lists)
         qb = query_block if self.tiles is not None else max(1, min(query_block, self.score_bytes // max(1, 4 * dense * max(self.max_list, 1))))
         over = None
