@@ -1363,7 +1363,7 @@ def main():
                 b_.fetched_codes = b_.fetched_valid = b_.fetched_index = b_.knn_vals = None
                 b_.fetched_centres_only = False
             acc_r = torch.zeros(1, device=dev, dtype=torch.float64)
-            run_r = lambda i: ops.masked_sum_f64(eng_r.score(batches[i % len(batches)], args.lmbda, args.temperature)["logp"], None, acc_r)
+            run_r = lambda i: ops.masked_sum_f64(eng_r.score(batches[i % len(batches)], args.lmbda, args.temperature, knn_index=idx, k=args.k)["logp"], None, acc_r)   # (the same step: search inside, one batch at a time)
             run_r(0)
             barrier()
             _lib.profile_begin()                                  # as in the timed region above: the per-launch events cost ~2 % of a step
