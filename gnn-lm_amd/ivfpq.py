@@ -28,6 +28,7 @@ orthonormal R gives a valid index).  It runs on the GPU with torch ops -- offlin
 
 PARITY UNPINNED against faiss itself (not in the image, no version pinned): the pin is the numpy restatement
 ``oracle/ivfpq.py`` over the SAME index arrays (tests/test_knn_search_gpu.py)."""
+import contextlib
 import ctypes
 import os
 
@@ -234,6 +235,8 @@ class IVFPQIndex:
             self.cand_cap = 32768 if self.tiles is not None else 16384
         self.refine_tau = os.environ.get("GNNLM_IVF_REFINE", "1") != "0"     # gnnlm_ivfpq_refine between the filter and the re-score (A/B: 0)
         self.fuse_refine = os.environ.get("GNNLM_IVF_FUSED", "1") != "0"     # ... inside the re-score's launch (A/B: 0 = two launches)
+        self.fork_tables = os.environ.get("GNNLM_IVF_FORK", "1") != "0"      # ADC tables on a side stream beside the coarse scores (A/B: 0)
+        self._side_streams = {}                                              # raw stream -> its side stream
         self.stats = {}                                                      # device-side work counters of the last search (bench.py)
 
     def attach_vals(self, vals):
@@ -474,6 +477,9 @@ class IVFPQIndex:
         dev = self.device
         nq = qs.shape[0]
         qr = ops.gemm_nt(qs, self.R)                                            # q' = R q
+        # the ADC tables (a store-bound batched GEMM, 2 KB per query and sub-quantizer) and their 8-bit images depend on q' alone: they
+        # are built on a side stream beside the coarse scores / probe selection / task table of this stream (GNNLM_IVF_FORK=0: in line)
+        lut, tables, side = self._tables_begin(qr)
         cs = ops.gemm_nt(qr, self.coarse)                                       # <q', c_l>
         pv = torch.empty(nq, nprobe, device=dev, dtype=torch.float32)
         pi = torch.empty(nq, nprobe, device=dev, dtype=torch.int64)
@@ -483,12 +489,8 @@ class IVFPQIndex:
         else:
             ops.topk_merge(cs, pv, pi, largest=True, init=True)                 # the nprobe best lists, best first
         self.stats.add("pairs", lambda pi=pi: (self.list_off[1:] - self.list_off[:-1])[pi.clamp(min=0)].masked_fill(pi < 0, 0).sum().double())
-        lut = torch.empty(nq, self.M * 256, device=dev, dtype=torch.float32)    # lut[q][m][c] = <q'_m, p_mc>: M small GEMMs
-        g = _lib.gnnlm_gemm_t()
-        g.A, g.lda, g.W, g.ldw, g.C, g.ldc = qr.data_ptr(), qr.stride(0), self.pq.data_ptr(), self.dsub, lut.data_ptr(), self.M * 256
-        g.M, g.N, g.K, g.batch1 = nq, 256, self.dsub, self.M
-        g.sA1, g.sW1, g.sC1 = self.dsub, 256 * self.dsub, 256
-        _lib.call_desc("gnnlm_gemm_nt", g)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)                       # (lut / tables were allocated on THIS stream: no record_stream needed)
         # (the int8 path: `cap` bounds a query's SURVIVORS of the filter; what scores above the refined threshold afterwards is a fraction of them
         # and gets 16384 columns at most -- the width the one-chunk k-selection takes)
         ccap = min(cap, 16384) if self.tiles is not None else cap
@@ -496,7 +498,7 @@ class IVFPQIndex:
         ci = torch.empty(nq, ccap, device=dev, dtype=torch.int64)
         cc = torch.zeros(nq, device=dev, dtype=torch.int32)
         if self.tiles is not None:
-            return self._search_block_mfma(k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc, cap)
+            return self._search_block_mfma(k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc, cap, tables)
         lut_s = lut
         if self.packed_codes is not None:
             lut_s = torch.empty_like(lut)
@@ -537,14 +539,39 @@ class IVFPQIndex:
             d.tau, d.surv, d.surv_cnt, d.cap = tau.data_ptr(), surv[0].data_ptr(), surv[1].data_ptr(), surv[0].shape[1]
         _lib.call_desc("gnnlm_ivfpq_scan8", d)
 
-    def _search_block_mfma(self, k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc, cap):
+    def _tables_begin(self, qr):
+        """lut[q][m][c] = <q'_m, p_mc> (M small GEMMs) and, for the int8 filter, its byte image: enqueued on a side stream of the
+        current one when the filter will run (the caller joins before the first consumer).  -> (lut, (qlut, qmeta) | None, side | None)"""
+        nq, dev = qr.shape[0], self.device
+        lut = torch.empty(nq, self.M * 256, device=dev, dtype=torch.float32)
+        tables = None
+        if self.tiles is not None:
+            tables = (torch.empty(nq, 2, 256, 32, dtype=torch.uint8, device=dev), torch.empty(nq, 4, dtype=torch.float32, device=dev))
+        side = None
+        if self.tiles is not None and self.fork_tables and not torch.cuda.is_current_stream_capturing():
+            cur = torch.cuda.current_stream()
+            side = self._side_streams.get(cur.cuda_stream)
+            if side is None:
+                side = self._side_streams[cur.cuda_stream] = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            g = _lib.gnnlm_gemm_t()
+            g.A, g.lda, g.W, g.ldw, g.C, g.ldc = qr.data_ptr(), qr.stride(0), self.pq.data_ptr(), self.dsub, lut.data_ptr(), self.M * 256
+            g.M, g.N, g.K, g.batch1 = nq, 256, self.dsub, self.M
+            g.sA1, g.sW1, g.sC1 = self.dsub, 256 * self.dsub, 256
+            _lib.call_desc("gnnlm_gemm_nt", g)
+            if tables is not None:
+                _lib.call("gnnlm_ivfpq_quantize_lut", _lib.ptr(lut), lut.stride(0), nq, self.M, _lib.ptr(tables[0]), _lib.ptr(tables[1]), _lib.stream())
+        return lut, tables, side
+
+    def _search_block_mfma(self, k, bv, bi, nprobe, dense, cs, pv, pi, lut, cv, ci, cc, cap, tables=None):
         """M = 64: everything on the int8 matrix cores (csrc/ivfpq_mfma.hip).  (1) threshold pass: histograms of the integer sums of the
         first `dense` lists -> a lower bound tau of the query's k-th best score (no per-key output, no selection); (2) filter: every probed
         list, keys whose integer sum can reach tau; (3) exact float32 scores of the survivors, score > tau -> candidates;
         (4) one k-selection over the candidates."""
         dev = self.device
         nq, ccap = pv.shape[0], cv.shape[1]
-        qlut, qmeta = ops.ivfpq_quantize_lut(lut, self.M)
+        qlut, qmeta = tables if tables is not None else ops.ivfpq_quantize_lut(lut, self.M)
         hist = torch.empty(nq, dense, 1024, device=dev, dtype=torch.int32)      # per (query, list): sum_u >> 4 counted on the device
         # The threshold pass histograms a SAMPLE of its lists' keys (every S-th tile of 16) when they hold plenty of them: tau is then the
         # bound of rank k / S + 4.5 sigma of the sample (sigma = sqrt(k (S - 1)) / S: the k best land in the sample binomially), i.e. with
