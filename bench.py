@@ -508,6 +508,34 @@ def recipe_l3(args, eng1, batches, dev):
     out["searched_neighbours"]["sensitivity"] = dict(sorted(sens.items()), context_groups_per_batch=n * args.gcn_k,
                                                      note="same corpus (4000 clusters, noise 0.9), same pool size; only the probability that a token stays "
                                                           "in its predecessor's cluster changes.  uniform_ids above is the limit of no overlap at all")
+    # ---- the structure real kNN-LM retrieval shows on top of topical overlap: when token t retrieves datastore position p (a matching
+    # context), token t + 1 tends to retrieve p + 1.  Then hardly two CENTRES coincide (p + 1 is a slot of t's group, not its centre): the
+    # group-level merge and the centre-state cache find almost nothing, although neighbouring groups share 4 of their 5 ROWS
+    # (token_block_dataset.py:378-400: a group is the +-2 window of its centre).  Layer 0's Q / K / V of a slot are a function of its code row
+    # alone, so a merge keyed by ROW would compute them once per distinct row: NOT BUILT -- this line measures the
+    # regime and what such a merge would have to work with
+    g2 = torch.Generator(device=dev)
+    g2.manual_seed(97)
+    kgc, p_follow = args.gcn_k, 0.8
+    fresh = torch.randint(0, args.n_store - 1, (n_srch, kgc), generator=g2, device=dev, dtype=torch.int64)
+    follow = torch.rand(n_srch, kgc, generator=g2, device=dev) < p_follow
+    follow[::T] = False                                                   # a block's first token starts every run
+    pos = torch.arange(n_srch, device=dev).view(-1, 1).expand(-1, kgc)
+    start = torch.where(follow, torch.zeros_like(pos), pos).cummax(0).values
+    ids_c = (torch.gather(fresh, 0, start) + (pos - start)).clamp_(max=args.n_store - 1)
+    bs = [batch_at(i, ids_c) for i in range(n_pool)]
+    m_c = timed(bs, 0.0, settle_s=0.3, steps=10)
+    f0 = ids_c[:n].reshape(-1)
+    slot_rows = (f0.view(-1, 1) + torch.arange(-eng.left, eng.right + 1, device=dev).view(1, -1)).reshape(-1)
+    slot_rows = slot_rows[(slot_rows >= 0) & (slot_rows < args.n_store)]
+    out["consecutive_retrieval"] = {
+        "neighbour_ids": f"runs: neighbour j of token t + 1 = neighbour j of token t, plus one, with probability {p_follow} (else a fresh uniform id); runs restart at block starts",
+        "context_groups_per_batch": n * kgc, "distinct_context_groups_first_batch": int(torch.unique(f0).numel()),
+        "slot_rows_first_batch": int(slot_rows.numel()), "distinct_slot_rows_first_batch": int(torch.unique(slot_rows).numel()),
+        "within_batch_merge_tokens_per_s": m_c["tokens_per_s"], "groups_computed_per_step_mean": m_c["groups_computed_per_step_mean"],
+        "note": "group-level merging (what is built) has nothing to merge here, and the centre-state cache nothing to hit (measured once: 16.15 k tokens/s from a "
+                "cold cache against 16.12 k without); the distinct slot ROWS are what a row-keyed merge of layer 0's projections would compute (not built)"}
+    del ids_c, fresh, follow, pos, start, bs
     out["_l3_ids"] = l3_ids                                               # (popped by main: knn_search runs them through eval_lm with the search inside)
     hgt.state_cache = None
     torch.cuda.empty_cache()
