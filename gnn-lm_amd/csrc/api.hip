@@ -122,16 +122,30 @@ struct HgtBufs {
     int32_t *rows_out, *rows_kv;     // slot subsets of the elided ntgt updates
     int32_t *win_counts;             // device-side group count (ABI 9): rows per GEMM window x multiplier
     int32_t *nb_row;                 // merged groups on fetched codes: code row of every neighbour's centre
+    // ABI 11, layer 0's K / V keyed by datastore row: the slots' rows, the distinct ones, slot -> position, their count, validity, decoded rows
+    int64_t *slot_row, *urows;
+    int32_t *slot_u, *row_cnt, *win_counts_u;
+    uint8_t* uvalid;
+    float* xu;
     int64_t Tp;
 };
 constexpr int MAX_WINDOWS = 128;
 
 bool needs_ntgt(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io) { return m.n_layers > 1 || io.out_ntgt != nullptr; }
+// layer 0's K / V projections once per distinct datastore ROW of the batch's slots (ABI 11): merged groups on a local or mapped
+// store, rotation-folded layer-0 weights, and a model whose layer 0 computes a subset of the slots (the un-elided forward with
+// out_ntgt keeps the slot-keyed path)
+bool row_keyed_kv(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io) {
+    if (!io.row_table || !io.group_ids || io.fetched_codes || io.ntgt_feats || io.out_ntgt || m.n_layers < 2 || !m.opq_at) return false;
+    const gnnlm_hgt_layer_t& w0 = m.layers[0];
+    return w0.wq_n0 && w0.bq_n0 && w0.wk_n0 && w0.bk_n0 && w0.wv_n0 && w0.bv_n0 && m.n_layers - 2 < std::max(m.left, m.right);
+}
 
 void carve_hgt(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, Carver& c, HgtBufs& b) {
     const int64_t Tt = (int64_t)io.n_blocks * io.T, d = m.d, H = m.n_heads;
     const int64_t dpq = (int64_t)m.M * m.dsub, dmax = std::max<int64_t>(dpq, d);
     b.Tp = (io.T + 3) & ~3;
+    b.slot_row = b.urows = nullptr; b.slot_u = b.row_cnt = b.win_counts_u = nullptr; b.uvalid = nullptr; b.xu = nullptr;
     b.ht[0] = c.take<float>(Tt * d);
     b.ht[1] = c.take<float>(Tt * d);
     b.q = c.take<float>(Tt * d);
@@ -156,6 +170,15 @@ void carve_hgt(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, Carver& c, HgtBuf
         b.valid = c.take<uint8_t>(S);
         b.rows_out = c.take<int32_t>(S);
         b.rows_kv = c.take<int32_t>(S);
+        if (row_keyed_kv(m, io)) {
+            b.slot_row = c.take<int64_t>(S);
+            b.urows = c.take<int64_t>(S);
+            b.slot_u = c.take<int32_t>(S);
+            b.row_cnt = c.take<int32_t>(4);
+            b.win_counts_u = c.take<int32_t>(MAX_WINDOWS * 8);
+            b.uvalid = c.take<uint8_t>(S);
+            b.xu = c.take<float>(S * dpq);
+        }
     } else {
         b.hn[0] = b.hn[1] = b.nq = b.nk = b.nv = nullptr;
         b.valid = nullptr;
@@ -328,6 +351,20 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
         hn_cur = b.hn[0];
         valid = b.valid;
         if (io.out_valid) GNNLM_HIP(hipMemcpyAsync(io.out_valid, b.valid, (size_t)S, hipMemcpyDeviceToDevice, s));
+        if (fold0 && row_keyed_kv(m, io)) {
+            // ABI 11: the distinct ROWS among the slots (a claim pass over the slots' rows against the caller's second row table, handed
+            // back clean), decoded once; their count stays on the device (row_cnt[0]).  The slots' own decode above stays: layer 0's Q
+            // and the LayerNorm residual are per slot
+            TRY(slot_rows(io.group_ids, G, gdev, m.left, m.right, m.n_layers - 1, m.n_store, b.slot_row, s));   // (layer 0's K / V reach: n_layers - 2 + 1 positions)
+            gnnlm_group_assign_t ra{};
+            ra.ids = b.slot_row; ra.n = S; ra.n_store = m.n_store; ra.slot_of = io.row_table;
+            ra.group_ids = b.urows; ra.group_index = b.slot_u; ra.counters = b.row_cnt;
+            TRY(group_assign(ra, s));
+            GatherParams gu = g;
+            gu.ids = b.urows; gu.n_groups = S; gu.left = 0; gu.right = 0; gu.n_groups_dev = b.row_cnt;
+            gu.out_valid = b.uvalid; gu.out_x = b.xu; gu.ld_x = dpq;
+            TRY(gather_decode(gu, s));
+        }
     }
     // V^T buffer of the GEMM path: its padding columns (t >= T) are read by the P.V GEMM against zero probabilities
     if (!causal_attn_fused_ok(T, dk)) GNNLM_HIP(hipMemsetAsync(b.vt, 0, sizeof(float) * (size_t)nb * d * Tp, s));
@@ -497,14 +534,25 @@ int hgt_forward_impl(const gnnlm_hgt_t& m, const gnnlm_hgt_io_t& io, void* ws, s
                 const int64_t R_out = G * n_out;
                 if (f0) TRY(linear_rows_windows(win, b.hn[1], dpq, m.opq_at, m.opq_nba, b.hn[0], d, b.rows_out, n_out, d, dpq, s));   // residual rows only
                 TRY(linear_rows_windows(win, pin, ld_pin, Wq, Bq, b.nq, d, b.rows_out, n_out, d, kin, s));
-                TRY(linear_rows_windows(win, pin, ld_pin, Wk, Bk, b.nk, d, b.rows_kv, n_kv, d, kin, s));
-                TRY(linear_rows_windows(win, pin, ld_pin, Wv, Bv, b.nv, d, b.rows_kv, n_kv, d, kin, s));
+                const bool by_row = f0 && b.xu != nullptr;                     // (ABI 11) K / V of layer 0 once per distinct datastore row
+                if (by_row) {
+                    GroupWindows winu(S, 1, 4 * (int64_t)std::max(d, dpq));
+                    GNNLM_REQUIRE(winu.n_windows() <= MAX_WINDOWS, "hgt: too many GEMM windows for the row-keyed projections");
+                    TRY(window_counts(b.row_cnt, S, winu.per, (int)winu.n_windows(), b.win_counts_u, s));
+                    winu.counts = b.win_counts_u;
+                    TRY(linear_windows(winu, b.xu, dpq, Wk, Bk, b.nk, d, kin, s));
+                    TRY(linear_windows(winu, b.xu, dpq, Wv, Bv, b.nv, d, kin, s));
+                } else {
+                    TRY(linear_rows_windows(win, pin, ld_pin, Wk, Bk, b.nk, d, b.rows_kv, n_kv, d, kin, s));
+                    TRY(linear_rows_windows(win, pin, ld_pin, Wv, Bv, b.nv, d, b.rows_kv, n_kv, d, kin, s));
+                }
                 ChainAttnParams ca{};
                 ca.Q = b.nq; ca.K = b.nk; ca.V = b.nv; ca.ld = d; ca.valid = valid;
                 ca.n_groups = G; ca.left = m.left; ca.right = m.right; ca.H = H; ca.dk = dk;
                 ca.out = b.nq; ca.ldo = d;
                 ca.radius_p1 = rad + 1;
                 ca.n_groups_dev = gdev;
+                if (by_row) ca.kv_index = b.slot_u;
                 TRY(chain_attn(ca, s));
                 TRY(linear_rows_windows(win, b.nq, d, w.wa_n, w.ba_n, b.nk, d, b.rows_out, n_out, d, d, s));
                 TRY(layernorm(b.nk, d, w.ln_g_n, w.ln_b_n, hn_out, d, R_out, d, m.ln_eps, valid, s, hn_cur, ld_hn, b.rows_out, gdev, n_out));

@@ -514,9 +514,11 @@ __global__ __launch_bounds__(256) void chain_attn_kernel(ChainAttnParams p) {
                 const int e = lane + 64 * t;
                 const bool in = ok[pos] && e < dk;
                 const int64_t off = s * p.ld + h * dk + (in ? e : 0);
+                // (ABI 11: K / V keyed by datastore row -- slot s reads row kv_index[s]; a valid slot always has one)
+                const int64_t off_kv = p.kv_index ? (int64_t)(ok[pos] ? p.kv_index[s] : 0) * p.ld + h * dk + (in ? e : 0) : off;
                 q[pos][t] = in && dst[pos] ? p.Q[off] : 0.f;
-                k[pos][t] = in ? p.K[off] : 0.f;
-                v[pos][t] = in ? p.V[off] : 0.f;
+                k[pos][t] = in ? p.K[off_kv] : 0.f;
+                v[pos][t] = in ? p.V[off_kv] : 0.f;
             }
         }
     }

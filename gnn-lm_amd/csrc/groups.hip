@@ -141,7 +141,33 @@ __global__ __launch_bounds__(256) void scatter_code_rows_kernel(const uint8_t* s
     }
 }
 
+// ABI 11 (row-keyed K / V of layer 0).  Slot s = g * n_g + c of the first *n_dev groups -> its datastore row, by gather_decode's own
+// rule (centre first, then o - left .. o - 1, then o + 1 .. o + right; -1: no such row, or a group beyond the count)
+__global__ __launch_bounds__(256) void slot_rows_kernel(const int64_t* centres, int64_t G, const int32_t* n_dev, int left, int right, int reach, int64_t n_store, int64_t* out) {
+    const int n_g = 1 + left + right;
+    const int64_t live = n_dev ? min(G, (int64_t)*n_dev) : G;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < G * n_g; s += (int64_t)gridDim.x * 256) {
+        const int64_t g = s / n_g;
+        const int c = (int)(s - g * n_g);
+        int64_t row = -1;
+        if (g < live) {
+            const int64_t centre = centres[g];
+            const int delta = c == 0 ? 0 : (c <= left ? c - 1 - left : c - left);
+            row = centre + delta;
+            if (!(centre >= 0 && row >= 0 && row < n_store) || delta > reach || -delta > reach) row = -1;      // (`reach`: only the slots whose K / V a later layer reads)
+        }
+        out[s] = row;
+    }
+}
 }  // namespace
+
+int slot_rows(const int64_t* centres, int64_t G, const int32_t* n_dev, int left, int right, int reach, int64_t n_store, int64_t* out, hipStream_t stream) {
+    if (G == 0) return OK;
+    hipLaunchKernelGGL(slot_rows_kernel, dim3((unsigned)std::min<int64_t>(cdiv(G * (1 + left + right), (int64_t)256), 4096)), dim3(256), 0, stream,
+                       centres, G, n_dev, left, right, reach, n_store, out);
+    GNNLM_LAUNCH_CHECK();
+    return OK;
+}
 
 int group_assign(const gnnlm_group_assign_t& p, hipStream_t stream) {
     GNNLM_REQUIRE(p.n >= 0 && p.n < (1ll << 31) && p.n_store > 0 && p.slot_of && p.counters, "group_assign: bad arguments");

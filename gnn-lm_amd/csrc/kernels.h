@@ -123,6 +123,8 @@ int scatter_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, c
 
 // group assignment on the device (groups.hip, ABI 9)
 int group_assign(const gnnlm_group_assign_t& d, hipStream_t stream);
+// (ABI 11: row-keyed K / V of layer 0) slot -> datastore row of the first *n_dev groups, for the slots within `reach` of their centre
+int slot_rows(const int64_t* centres, int64_t G, const int32_t* n_dev, int left, int right, int reach, int64_t n_store, int64_t* out, hipStream_t stream);
 // counts[w * 8 + mult - 1] = rows of window w (groups [w * per, (w + 1) * per) of min(*n_dev, cap)) times mult, mult = 1 .. 8
 int window_counts(const int32_t* n_dev, int64_t cap, int64_t per, int n_win, int32_t* counts, hipStream_t stream);
 // out[e] = row of the fetched buffer that holds the centre code of neighbour e's group (-1: none)

@@ -297,6 +297,7 @@ class HGT(nn.Module):
         self._prepared = self._plist = None
         self.gemm_precision = 0     # 0 exact f32 MFMA | 1 bf16x3 | 2 bf16x6 (opt-in split-bf16 emulation)
         self.dedup_groups = os.environ.get("GNNLM_DEDUP", "1") != "0"      # merge equal context groups of a batch (multi-layer models)
+        self.dedup_rows = os.environ.get("GNNLM_DEDUP_ROWS", "1") != "0"   # ... and project layer 0's K / V once per distinct datastore ROW (ABI 11)
         self._last_groups = None                                             # (groups of the last batch, device counter of the computed ones)
         self._merge_tables = {}                                              # (device, n_store, stream) -> row -> group table of the within-batch merge
         # centre states of context groups kept ACROSS batches (CentreStateCache): HBM budget in GiB, 0 = off
@@ -409,6 +410,17 @@ class HGT(nn.Module):
             t = self._merge_tables[key] = torch.full((n_store,), -1, dtype=torch.int32, device=device)
         return t
 
+    def _row_table(self, n_store, device):
+        """Second row table (int32 per datastore row, all -1 between calls) of the ROW-keyed layer-0 K / V projections (ABI 11):
+        like the merge table, one per stream and never born inside a capture."""
+        key = (str(device), n_store, _lib.raw_stream(device), "rows")
+        t = self._merge_tables.get(key)
+        if t is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            t = self._merge_tables[key] = torch.full((n_store,), -1, dtype=torch.int32, device=device)
+        return t
+
     @staticmethod
     def _bind_store(m, store):
         """(Re)point the descriptor at the store's tables: cheap, done on every forward."""
@@ -510,6 +522,12 @@ class HGT(nn.Module):
             if merged:
                 io.group_ids, io.n_unique, io.group_index = group_ids.data_ptr(), flat.numel(), group_index.data_ptr()
                 io.n_unique_dev = counters.data_ptr()
+                if self.dedup_rows and fetcher is None and (G.left or G.right):
+                    # layer 0's K / V once per distinct datastore ROW among the groups' slots (neighbouring groups share rows)
+                    rt = self._row_table(st.n_store, tgt.device)
+                    if rt is not None:
+                        io.row_table = rt.data_ptr()
+                        keep.append(rt)
                 keep += [group_ids, group_index, counters, hit]
                 self._last_groups = (flat.numel(), counters)
                 if fetcher is not None:                                           # every distinct centre row is requested ONCE

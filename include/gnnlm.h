@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GNNLM_ABI_VERSION 10
+#define GNNLM_ABI_VERSION 11
 #define GNNLM_OK 0
 #define GNNLM_E_INVALID (-22)
 #define GNNLM_E_NOMEM (-12)
@@ -177,6 +177,7 @@ typedef struct gnnlm_chain_attn {
     int32_t radius_p1;         /* ABI 4.  0: every slot is computed; r + 1 > 0: only the slots within r positions of the centre
                                   are (Q is read for them, K / V up to r + 1 positions away; the other rows of `out` stay untouched) */
     const int32_t* n_groups_dev;   /* ABI 9, optional (DEVICE int32): only the first min(n_groups, *n_groups_dev) groups */
+    const int32_t* kv_index;       /* ABI 11, optional [n_slots]: slot s reads row kv_index[s] of K and V (Q, valid and out stay slot-indexed) */
 } gnnlm_chain_attn_t;
 int gnnlm_chain_attn(const gnnlm_chain_attn_t* desc, void* stream);
 
@@ -503,6 +504,14 @@ typedef struct gnnlm_hgt_io {
      * Layer 0's star edges read the PQ code of EVERY neighbour; with a sharded store only the groups the cache lacks are
      * fetched, so the code row of a centre is kept beside its states (128 B per slot). */
     uint8_t* code_cache;
+    /* ABI 11 (optional): layer 0's K / V projections of the ntgt slots keyed by datastore ROW.  A slot's layer-0 K and V are a
+     * function of its code row alone, and neighbouring context groups share rows (a group is the window [o - left, o + right]
+     * of its centre, token_block_dataset.py:378-400: centres p and p + 1 share 4 of 5 rows -- what consecutive tokens of real
+     * kNN-LM retrieval produce).  With `row_table` (DEVICE int32[n_store], all -1 between calls, owned by the caller; needs
+     * group_ids and a local or mapped code store) the distinct slot rows of the batch are found on the device
+     * (gnnlm_group_assign's claim pass over the slots' rows), decoded and projected ONCE, and the chain attention reads K / V
+     * through the slot -> row map.  Same kernels per row: the output is bit-identical. */
+    int32_t* row_table;
 } gnnlm_hgt_io_t;
 
 /* ------------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ from gnnlm_amd import _lib
 def test_library_loads_and_is_gfx950():
     L = _lib.lib()
     assert L.gnnlm_target_arch() == b"gfx950"
-    assert L.gnnlm_abi_version() == _lib.ABI_VERSION == 10
+    assert L.gnnlm_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_every_declared_symbol_is_exported():

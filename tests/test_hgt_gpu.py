@@ -255,6 +255,57 @@ def test_hgt_dedup_context_groups(dev, L):
 
 
 @pytest.mark.parametrize("L", [2, 3])
+def test_hgt_row_keyed_layer0_kv(dev, L):
+    """Layer 0's K / V of the ntgt slots once per distinct datastore ROW (gnnlm_hgt_io_t.row_table, ABI 11): neighbour lists in RUNS --
+    neighbour j of token t + 1 is neighbour j of token t plus one, what consecutive tokens of real kNN-LM retrieval produce -- so
+    hardly two centres coincide (nothing for the group-level merge) while neighbouring groups share 4 of their 5 rows; runs that
+    walk over both ends of the store, -1 ids, a second call (the row table comes back clean).  Bit-identical to the slot-keyed
+    projections (same kernels per row), with and without the centre-state cache, and equal to the un-merged float64 oracle."""
+    from gnnlm_amd.hgt import HGT, NeighborGraph
+    d, H, M, dsub, T, kg, l, r, nblk = 128, 8, 16, 8, 16, 6, 2, 2, 2
+    rs = np.random.RandomState(90 + L)
+    n_store = 3000
+    codes = rs.randint(0, 256, size=(n_store, M)).astype(np.uint8)
+    cen = (rs.randn(M, 256, dsub) * 0.5).astype(np.float32)
+    A = (rs.randn(M * dsub, d) / np.sqrt(M * dsub)).astype(np.float32)
+    b = (rs.randn(M * dsub) * 0.1).astype(np.float32)
+    start = rs.randint(0, n_store - T, size=(nblk, 1, kg))
+    start[0, 0, 0], start[0, 0, 1], start[1, 0, 0] = 0, n_store - T, n_store - T - 1          # runs along both ends of the store
+    nb = (start + np.arange(T).reshape(1, T, 1)).reshape(nblk * T, kg).astype(np.int64)
+    brk = rs.rand(*nb.shape) < 0.1
+    nb[brk] = rs.randint(0, n_store, size=int(brk.sum()))                                       # a run broken here and there
+    nb[3, 2] = -1
+    nb[9] = -1
+    tgt = rs.randn(nblk * T, d).astype(np.float16).astype(np.float32)
+    sd = {k: v.numpy() for k, v in ohgt.init_hgt_weights(L, d, H, seed=6).items()}
+    store = make_store(dev, codes, cen, A, b)
+    model = HGT(in_dim=d, hidden_dim=d, out_dim=d, n_layers=L, n_heads=H)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    model.state_cache_gib = 0.0
+    G = NeighborGraph(ids=torch.from_numpy(nb).to(dev), n_blocks=nblk, T=T, left=l, right=r, store=store)
+    x = torch.from_numpy(tgt).to(dev)
+    assert model.dedup_groups and model.dedup_rows
+    by_row = model(G, features={"tgt": x})["tgt"].cpu().numpy()
+    n_all, n_distinct = model.last_groups
+    slot_rows = (nb[nb >= 0].reshape(-1, 1) + np.arange(-l, r + 1).reshape(1, -1)).reshape(-1)
+    slot_rows = slot_rows[(slot_rows >= 0) & (slot_rows < n_store)]
+    assert n_distinct > 0.7 * (nb >= 0).sum() and len(np.unique(slot_rows)) < 0.5 * len(slot_rows)    # the regime: distinct centres, shared rows
+    again = model(G, features={"tgt": x})["tgt"].cpu().numpy()                # (the row table was handed back clean)
+    model.dedup_rows = False
+    by_slot = model(G, features={"tgt": x})["tgt"].cpu().numpy()
+    assert np.array_equal(by_row, by_slot) and np.array_equal(by_row, again)
+    ref = np.concatenate([oracle_hgt(sd, L, H, tgt[i * T:(i + 1) * T], nb[i * T:(i + 1) * T], codes, cen, A, b, n_store, l, r)["tgt"].numpy()
+                          for i in range(nblk)])
+    assert np.abs(by_row - ref).max() < 1e-4
+    # ... and under the centre-state cache (cold, then all hits)
+    model.dedup_rows = True
+    model.state_cache_gib, model.state_cache_slots, model.state_cache = 1.0, 4096, None
+    cold = model(G, features={"tgt": x})["tgt"].cpu().numpy()
+    warm = model(G, features={"tgt": x})["tgt"].cpu().numpy()
+    assert model.state_cache is not None and np.array_equal(cold, by_row) and np.array_equal(warm, by_row)
+
+
+@pytest.mark.parametrize("L", [2, 3])
 def test_hgt_centre_state_cache(dev, L):
     """The cross-batch cache of context groups' centre states (gnnlm_hgt_io_t.state_cache, ABI 7; slots assigned on the device,
     gnnlm_group_assign, ABI 9): a sequence of batches with overlapping neighbour rows -- cold, partly cached, fully cached,
