@@ -508,14 +508,18 @@ __global__ __launch_bounds__(256) void chain_attn_kernel(ChainAttnParams p) {
             const int dist = pos < p.left ? p.left - pos : pos - p.left;
             slot_of[pos] = s;
             dst[pos] = dist <= rad;
+            // (ABI 11: K / V keyed by datastore row -- slot s reads row kv_index[s]; a valid slot always has one.  The index is loaded
+            // BESIDE the validity byte, not behind it: gated by `ok` it was a third dependent round trip per task and the layer-0 launch of
+            // the 3-layer recipe took 20 ms instead of 10)
+            const int32_t kvr = (p.kv_index && dist <= rad + 1) ? p.kv_index[s] : 0;
             ok[pos] = dist <= rad + 1 && p.valid[s] != 0;
+            const int64_t row_kv = p.kv_index ? (int64_t)max(kvr, 0) : s;
 #pragma unroll
             for (int t = 0; t < MAX_EPT; ++t) {
                 const int e = lane + 64 * t;
                 const bool in = ok[pos] && e < dk;
                 const int64_t off = s * p.ld + h * dk + (in ? e : 0);
-                // (ABI 11: K / V keyed by datastore row -- slot s reads row kv_index[s]; a valid slot always has one)
-                const int64_t off_kv = p.kv_index ? (int64_t)(ok[pos] ? p.kv_index[s] : 0) * p.ld + h * dk + (in ? e : 0) : off;
+                const int64_t off_kv = row_kv * p.ld + h * dk + (in ? e : 0);
                 q[pos][t] = in && dst[pos] ? p.Q[off] : 0.f;
                 k[pos][t] = in ? p.K[off_kv] : 0.f;
                 v[pos][t] = in ? p.V[off_kv] : 0.f;
