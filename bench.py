@@ -512,8 +512,8 @@ def recipe_l3(args, eng1, batches, dev):
     # context), token t + 1 tends to retrieve p + 1.  Then hardly two CENTRES coincide (p + 1 is a slot of t's group, not its centre): the
     # group-level merge and the centre-state cache find almost nothing, although neighbouring groups share 4 of their 5 ROWS
     # (token_block_dataset.py:378-400: a group is the +-2 window of its centre).  Layer 0's Q / K / V of a slot are a function of its code row
-    # alone, so a merge keyed by ROW would compute them once per distinct row: NOT BUILT -- this line measures the
-    # regime and what such a merge would have to work with
+    # alone: layer 0's K / V are keyed by ROW (gnnlm_hgt_io_t.row_table, ABI 11; GNNLM_DEDUP_ROWS=0 switches it off) -- this line measures
+    # the regime
     g2 = torch.Generator(device=dev)
     g2.manual_seed(97)
     kgc, p_follow = args.gcn_k, 0.8
@@ -533,8 +533,10 @@ def recipe_l3(args, eng1, batches, dev):
         "context_groups_per_batch": n * kgc, "distinct_context_groups_first_batch": int(torch.unique(f0).numel()),
         "slot_rows_first_batch": int(slot_rows.numel()), "distinct_slot_rows_first_batch": int(torch.unique(slot_rows).numel()),
         "within_batch_merge_tokens_per_s": m_c["tokens_per_s"], "groups_computed_per_step_mean": m_c["groups_computed_per_step_mean"],
-        "note": "group-level merging (what is built) has nothing to merge here, and the centre-state cache nothing to hit (measured once: 16.15 k tokens/s from a "
-                "cold cache against 16.12 k without); the distinct slot ROWS are what a row-keyed merge of layer 0's projections would compute (not built)"}
+        "layer0_kv_keyed_by_row": bool(hgt.dedup_rows),
+        "note": "group-level merging has nothing to merge here and the centre-state cache nothing to hit (16.0-16.1 k tokens/s either way with slot-keyed "
+                "projections, GNNLM_DEDUP_ROWS=0); layer 0's K / V are computed once per distinct slot ROW (ABI 11): 10 of a group's 27 row-GEMMs shrink "
+                "by distinct_slot_rows / slot_rows"}
     del ids_c, fresh, follow, pos, start, bs
     out["_l3_ids"] = l3_ids                                               # (popped by main: knn_search runs them through eval_lm with the search inside)
     hgt.state_cache = None
