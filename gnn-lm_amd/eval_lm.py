@@ -474,7 +474,12 @@ def main(args, tables=None, model=None):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fetcher.fixed_requests = int(t.item())
     deep = getattr(getattr(model, "hgt_decoder", None), "n_layers", 1) > 1
-    n_streams = args.streams if getattr(args, "streams", 0) > 0 else (6 if per_batch == 1 and fetcher is None and save is None else 1)
+    # lanes: 6 for the recipe's literal one-block batches (launch-bound); 2 for coalesced batches scored WITH a device-side kNN search
+    # (the host comes back to a batch's search when the next batch is enqueued: generate_begin / generate_finish); else 1
+    pipelined = bool(args.knnlm) and hasattr(scorer, "generate_begin") and hasattr(knn_dstore, "interpolate_begin") and fetcher is None and save is None
+    n_streams = args.streams if getattr(args, "streams", 0) > 0 else \
+        (6 if per_batch == 1 and fetcher is None and save is None else (2 if pipelined and per_batch > 1 and not deep else 1))   # (a multi-layer model's centre-state cache and its 3-GB-per-block workspace belong to ONE stream)
+    pipelined = pipelined and n_streams > 1
     if n_streams > 1 and fetcher is not None:
         raise ValueError("--streams > 1 is not available with --store sharded (the exchange's collectives stay on one stream)")
     main_stream = torch.cuda.current_stream(device)
@@ -482,6 +487,40 @@ def main(args, tables=None, model=None):
     accs = [acc] + [torch.zeros_like(acc) for _ in lanes[1:]]
     for s_ in lanes[1:]:
         s_.wait_stream(main_stream)
+    in_flight, order = [None] * n_streams, [0] * n_streams
+    state = {"ntok": 0, "count": 0}
+
+    def consume(hypos, sample, acc, ev0, ev1):
+        """What the loop does with a batch's hypotheses (a handle of generate_begin is finished first), on the batch's own stream."""
+        if isinstance(hypos, dict):
+            hypos = scorer.generate_finish(hypos)
+        ev1.record()
+        timers.append((ev0, ev1))
+        state["ntok"] += sample["ntokens"]
+        if save is not None:                                     # one device -> host copy per batch (this run is a writer anyway)
+            kd = hypos[0][0]["dstore_keys"].shape[-1]
+            if kd != save["dim"]:
+                raise ValueError(f"--save-knnlm-dstore: the scorer returned {kd}-dimensional keys, the datastore was opened for {save['dim']}")
+            keys = torch.cat([h[0]["dstore_keys"].reshape(-1, kd) for h in hypos])
+            toks = torch.cat([h[0]["tokens"].reshape(-1) for h in hypos])
+            n_new = min(keys.shape[0], save["size"] - save["idx"])
+            if n_new < keys.shape[0]:
+                logger.warning("exceed offset at sample " + str(i))          # :227-230
+            sl = slice(save["idx"], save["idx"] + n_new)
+            save["keys"][sl] = keys[:n_new].to(torch.float16 if save["keys"].dtype == np.float16 else torch.float32).cpu().numpy()
+            save["vals"][sl, 0] = toks[:n_new].cpu().numpy().astype(save["vals"].dtype)
+            save["idx"] += n_new
+        pos = torch.cat([h[0]["positional_scores"].float().reshape(-1) for h in hypos])     # one launch per batch
+        ops.masked_sum_f64(pos, None, acc)                                                  # score_sum (:273), in f64
+        # ... and as the reference adds it up: one float32 sum per hypothesis (`pos_scores.sum()`), accumulated in a float32 scalar
+        # (`score_sum += ...cpu()`, :273) -- the per-hypothesis sums are kept on the device and chained on the host at the end
+        lens = [h[0]["positional_scores"].numel() for h in hypos]
+        hyp_sums.append(pos.view(len(hypos), -1).sum(dim=1) if len(set(lens)) == 1 and lens[0] > 0 else
+                        torch.stack([h[0]["positional_scores"].float().sum() for h in hypos]))
+        state["count"] += pos.numel()                                                                # :274
+        if want_words or bpe_toks is not None:
+            state["count"] -= word_outputs(args, hypos, sample["id"], symbols, bpe_toks, bpe_len, word_stats)     # skipped_toks (:274)
+
     torch.cuda.synchronize()
     wall0 = time.perf_counter()
     for bi, group in enumerate(batches_):
@@ -508,35 +547,23 @@ def main(args, tables=None, model=None):
         if args.batch_blocks > 0:
             sample["blockwise_knn"] = True                       # kNN pairing of one-block batches (sequence_scorer.py)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if pipelined:
+            lane = bi % n_streams
+            if in_flight[lane] is not None:
+                consume(*in_flight[lane])                                   # (this lane's previous batch: its search has had a whole batch of head start)
+            ev0.record()
+            in_flight[lane] = (scorer.generate_begin([model], sample, knn_dstore=knn_dstore, temperature=args.temperature), sample, acc, ev0, ev1)
+            order[lane] = bi
+            continue
         ev0.record()
         hypos = scorer.generate([model], sample, knn_dstore=knn_dstore, temperature=args.temperature) if args.knnlm \
             else scorer.generate([model], sample)
-        ev1.record()
-        timers.append((ev0, ev1))
-        ntok += sample["ntokens"]
-        if save is not None:                                     # one device -> host copy per batch (this run is a writer anyway)
-            kd = hypos[0][0]["dstore_keys"].shape[-1]
-            if kd != save["dim"]:
-                raise ValueError(f"--save-knnlm-dstore: the scorer returned {kd}-dimensional keys, the datastore was opened for {save['dim']}")
-            keys = torch.cat([h[0]["dstore_keys"].reshape(-1, kd) for h in hypos])
-            toks = torch.cat([h[0]["tokens"].reshape(-1) for h in hypos])
-            n_new = min(keys.shape[0], save["size"] - save["idx"])
-            if n_new < keys.shape[0]:
-                logger.warning("exceed offset at sample " + str(i))          # :227-230
-            sl = slice(save["idx"], save["idx"] + n_new)
-            save["keys"][sl] = keys[:n_new].to(torch.float16 if save["keys"].dtype == np.float16 else torch.float32).cpu().numpy()
-            save["vals"][sl, 0] = toks[:n_new].cpu().numpy().astype(save["vals"].dtype)
-            save["idx"] += n_new
-        pos = torch.cat([h[0]["positional_scores"].float().reshape(-1) for h in hypos])     # one launch per batch
-        ops.masked_sum_f64(pos, None, acc)                                                  # score_sum (:273), in f64
-        # ... and as the reference adds it up: one float32 sum per hypothesis (`pos_scores.sum()`), accumulated in a float32 scalar
-        # (`score_sum += ...cpu()`, :273) -- the per-hypothesis sums are kept on the device and chained on the host at the end
-        lens = [h[0]["positional_scores"].numel() for h in hypos]
-        hyp_sums.append(pos.view(len(hypos), -1).sum(dim=1) if len(set(lens)) == 1 and lens[0] > 0 else
-                        torch.stack([h[0]["positional_scores"].float().sum() for h in hypos]))
-        count += pos.numel()                                                                # :274
-        if want_words or bpe_toks is not None:
-            count -= word_outputs(args, hypos, sample["id"], symbols, bpe_toks, bpe_len, word_stats)     # skipped_toks (:274)
+        consume(hypos, sample, acc, ev0, ev1)
+    for lane in sorted((l_ for l_ in range(n_streams) if in_flight[l_] is not None), key=lambda l_: order[l_]):   # what is still in flight, in batch order
+        torch.cuda.set_stream(lanes[lane])
+        consume(*in_flight[lane])
+        in_flight[lane] = None
+    ntok, count = ntok + state["ntok"], count + state["count"]
     if n_streams > 1:
         torch.cuda.set_stream(main_stream)
         for s_, a_ in zip(lanes[1:], accs[1:]):

@@ -32,6 +32,13 @@ class SequenceScorer(object):
 
     @torch.no_grad()
     def generate(self, models, sample, **kwargs):
+        return self.generate_finish(self.generate_begin(models, sample, **kwargs))
+
+    @torch.no_grad()
+    def generate_begin(self, models, sample, **kwargs):
+        """(this build) ``generate`` up to the kNN search's one host read: forward, search and softmax are enqueued, the handle goes to
+        ``generate_finish``.  A driver with several batches in flight (eval_lm --streams) comes back to a batch when the others are
+        enqueued: the host never waits on a search while the device has nothing else to do."""
         if len(models) != 1:
             raise ValueError("Only knn *log* probs are supported.")        # :108-109 (ensembles unused on this path)
         model = models[0]
@@ -55,8 +62,19 @@ class SequenceScorer(object):
             if hasattr(knn_model, "interpolate_begin"):
                 pending = knn_model.interpolate_begin(queries.contiguous().view(-1, hidden))
         probs = model.target_log_probs(decoder_out, orig_target.clamp(min=0))
+        return dict(sample=sample, decoder_out=decoder_out, probs=probs, use_knn=use_knn, pending=pending, lmbda=lmbda, temperature=temperature,
+                    knn_model=kwargs.get("knn_dstore"), queries=(queries if use_knn else None))
+
+    @torch.no_grad()
+    def generate_finish(self, h):
+        sample, decoder_out, probs, use_knn, pending = h["sample"], h["decoder_out"], h["probs"], h["use_knn"], h["pending"]
+        lmbda, temperature, knn_model = h["lmbda"], h["temperature"], h["knn_model"]
+        orig_target = sample["target"]
+        bsz, tsz = orig_target.shape
         recall = None
         if use_knn:
+            queries = h["queries"]
+            seq_len, b2, hidden = queries.shape
             # as written (:117): targets in [B, T] order against queries in [T, B] order -- only right for B = 1, the recipe.
             # The driver's --batch-blocks (several of the recipe's one-block batches per launch) asks for the pairing those
             # one-block batches have: targets in the queries' order.
