@@ -62,7 +62,8 @@ def get_parser():
                    help="(this build) score this many of the batches' blocks per launch whatever --max-tokens says: blocks are "
                         "independent, so the hypotheses, their order and the scores are those of the one-block batches of the "
                         "recipe (`--max-tokens 256`), which alone are launch-bound on this part.  -1 (default): 32 when "
-                        "--max-tokens gives one block per batch (4 for models with more than one HGT layer), else off; 0: off")
+                        "--max-tokens gives one block per batch (128 with --knnlm: the on-device search likes big query blocks; 16 for models with "
+                        "more than one HGT layer), else off; 0: off")
     p.add_argument("--softmax-batch", default=sys.maxsize, type=int)
     p.add_argument("--context-window", default=0, type=int)
     p.add_argument("--model-overrides", default="{}")
@@ -395,7 +396,9 @@ def main(args, tables=None, model=None):
         # at the recipe's shapes if nothing merges; measured: 16.1 k tokens/s against 15.9 k at 4 blocks on i.i.d. ids, 39.8 k
         # against 35.1 k on searched neighbours)
         deep = getattr(getattr(model, "hgt_decoder", None), "n_layers", 1) > 1
-        args.batch_blocks = (16 if deep else 32) if per_batch == 1 else 0
+        # with the kNN search on the device (--knnlm) 128: 32768 queries per search fill its 8-query groups and keep a list's bytes in L2
+        # (11.0 ms per 8192 queries against 12.2 in batches of 32 blocks; ~18 GB of search temporaries per batch in flight)
+        args.batch_blocks = (16 if deep else (128 if args.knnlm else 32)) if per_batch == 1 else 0
     per_batch = max(per_batch, args.batch_blocks)
     # neighbours inside the token's own context are dropped on the TRAIN split only (language_modeling.py:299,
     # token_block_dataset.py:360-362): the split whose GNN features the kNN index is built over (find_knn.sh:7)

@@ -51,7 +51,9 @@ class SequenceScorer(object):
         use_knn = "knn_dstore" in kwargs and lmbda > 0.0
         pending = None
         if use_knn:
-            assert bsz * tsz < self.softmax_batch, "kNN scoring needs B*T < --softmax-batch (sequence_scorer.py:105)"
+            # (the reference's precondition is about ITS batch: with the driver's --batch-blocks the launch holds several of the recipe's
+            # one-block batches, each of which must fit -- the recipe passes --softmax-batch 3072 for 256-token batches)
+            assert (tsz if sample.get("blockwise_knn") else bsz * tsz) < self.softmax_batch, "kNN scoring needs B*T < --softmax-batch (sequence_scorer.py:105)"
             knn_model = kwargs["knn_dstore"]
             extra = decoder_out[1]
             kt = getattr(self.args, "knn_keytype", None)

@@ -268,6 +268,10 @@ def test_eval_lm_end_to_end(dev, tmp_path):
     for nb_ in ("0", "4"):
         res4 = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", nb_])
         assert res4["count"] == n_test and abs(res4["score_sum"] - res["score_sum"]) < 1e-6 * n_test
+    # the recipe's own --softmax-batch (3072 for its 256-token batches, hgt_lm_wiki103_reproduce.sh:84): the reference's precondition
+    # B * T < softmax_batch is about the recipe's batch, not about how many of them this build scores per launch
+    res_sb = eval_lm.cli_main(base1 + knn_args + ["--softmax-batch", str(T + 1)])
+    assert res_sb["count"] == n_test and abs(res_sb["score_sum"] - res["score_sum"]) < 1e-6 * n_test
     # --graph-capture (this build): forward and softmax of the recipe's literal one-block batches replayed from HIP graphs, one
     # pair per batch shape (the 16-token blocks and the ragged 9-token one) -- the same scores to the bit, run after run
     plain = eval_lm.cli_main(base1 + knn_args + ["--batch-blocks", "0"])
