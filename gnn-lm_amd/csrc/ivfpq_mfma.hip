@@ -1004,20 +1004,14 @@ __global__ __launch_bounds__(GNNLM_RESCORE_NT) void ivfpq_refine_rescore_kernel(
         // [64][256] f32 = 64 pieces of 1 KiB: wave w brings pieces 4 w .. 4 w + 3 (global_load_lds_dwordx4: 16 B per lane, lane order;
         // M0 = the piece's LDS byte address).  From inline asm: the compiler's counters do not see them -- its own waits only ever
         // get more conservative by that -- and would otherwise guard every LDS read of the refinement with vmcnt(0)
-        constexpr int QUADS = 64 / (GNNLM_RESCORE_NT / 64) / 4;            // groups of four 1-KiB pieces per wave (16 waves: one)
-        static_assert(QUADS >= 1 && QUADS * 4 * (GNNLM_RESCORE_NT / 64) == 64, "the table's 64 pieces are dealt out four at a time");
-#pragma unroll
-        for (int qd = 0; qd < QUADS; ++qd) {
-            const int piece = 4 * (QUADS * __builtin_amdgcn_readfirstlane(wave) + qd);
-            const float* src = p.lut + q * p.ld_lut + piece * 256 + 4 * lane;
-            const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)rtab + (unsigned)piece * 1024u;
-            unsigned keep_;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                         "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
-                         "s_mov_b32 m0, %0"
-                         : "=&s"(keep_) : "v"(src), "s"(dst) : "memory");
-        }
+        const float* src = p.lut + q * p.ld_lut + (4 * wave) * 256 + 4 * lane;
+        const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)rtab + (unsigned)(4 * __builtin_amdgcn_readfirstlane(wave)) * 1024u;
+        unsigned keep_;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep_) : "v"(src), "s"(dst) : "memory");
     }
     gnnlm_ivfpq_refine_t r;
     r.surv = const_cast<uint32_t*>(p.surv);  r.surv_cnt = p.surv_cnt;  r.out_cnt = p.out_cnt;  r.cap = p.cap;
