@@ -1114,10 +1114,12 @@ def main():
         from gnnlm_amd.synthetic import synthetic_ivfpq_index
         idx = synthetic_ivfpq_index(args.n_store, eng.hgt.hidden_dim, 4096, 64, dev, nprobe=32)
         idx.attach_vals(eng.store.vals)                           # index key ids = store rows: payload = id << 24 | label
-    n_lanes = max(1, args.lanes) if (idx is not None and fetcher is None and args.streams == 1) else 1
     # multi-layer model: the engine fetches inside the step, AFTER merging equal context groups -- one request per distinct centre
     # row of the batch (hgt.py; the one-layer step prefetches the next batch's centre rows on a side stream instead, below)
     fetch_in_step = fetcher is not None and args.layers > 1
+    # batches in flight: also with a sharded store whose rows are prefetched on the fetch stream (the collectives stay on that one stream,
+    # in program order on every rank; the lanes only carry the math and the search) -- so that N = 1 and N > 1 time the same step
+    n_lanes = max(1, args.lanes) if (idx is not None and args.streams == 1 and not fetch_in_step) else 1
     if fetch_in_step and isinstance(fetcher, ShardedFetcher):
         eng.fetcher, eng.fetch_vals = fetcher, bool(args.shard_vals)
     merged_counts = []
@@ -1151,6 +1153,21 @@ def main():
             ev.record(fetch_stream)
         pending[bi] = (codes, valid, index, kv, ev)
 
+    def take_fetched(bi):
+        """The rows batch bi asked for (sharded store, prefetched on the fetch stream) -> the batch, ordered before the current stream."""
+        b = batches[bi % len(batches)]
+        if bi not in pending:
+            issue_fetch(bi)
+        codes, valid, index, kv, ev = pending.pop(bi)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for t in (codes, valid, index, kv):
+            if t is not None:
+                t.record_stream(cur)
+        b.fetched_codes, b.fetched_valid, b.fetched_index, b.knn_vals = codes, valid, index, kv
+        b.fetched_centres_only = centres_only
+        return b
+
     def score_one(bi, a, prefetch_next):
         b = batches[bi % len(batches)]
         if fetch_in_step:
@@ -1158,16 +1175,7 @@ def main():
             if not isinstance(fetcher, ShardedFetcher) and args.shard_vals:
                 b.knn_vals = fetcher.fetch_knn_vals(b.knn_ids)
         elif fetcher is not None:
-            if bi not in pending:
-                issue_fetch(bi)
-            codes, valid, index, kv, ev = pending.pop(bi)
-            cur = torch.cuda.current_stream()
-            cur.wait_event(ev)
-            for t in (codes, valid, index, kv):
-                if t is not None:
-                    t.record_stream(cur)
-            b.fetched_codes, b.fetched_valid, b.fetched_index, b.knn_vals = codes, valid, index, kv
-            b.fetched_centres_only = centres_only
+            b = take_fetched(bi)
         out = eng.score(b, args.lmbda, args.temperature, knn_index=idx, k=args.k)
         ops.masked_sum_f64(out["logp"], None, a)                  # score_sum (eval_lm.py:273)
         if fetch_in_step and len(merged_counts) < 64:
@@ -1199,7 +1207,13 @@ def main():
             j = i % n_lanes
             finish_lane(j)
             with torch.cuda.stream(lane_streams[j]):
-                lane_pending[j] = eng.score_begin(batches[i % len(batches)], args.lmbda, args.temperature, knn_index=idx, k=args.k)
+                if fetcher is not None:
+                    b = take_fetched(i)
+                else:
+                    b = batches[i % len(batches)]
+                lane_pending[j] = eng.score_begin(b, args.lmbda, args.temperature, knn_index=idx, k=args.k)
+            if fetcher is not None and not last:
+                issue_fetch(i + 1)                                    # the next batch's rows: requested now, on the fetch stream
             return
         main = torch.cuda.current_stream()
         for s_i in range(args.streams):

@@ -65,6 +65,14 @@ def test_bench_search_inside_the_step():
         assert ks["pairs_per_query"] > 0 and r["roofline"]["bound"] in ("hbm", "mfma")
         assert any(k_["kernel"].startswith("ivfpq_scan8") for k_ in r["kernels"])
     assert out["1"]["config"]["synthetic_ppl"] == out["3"]["config"]["synthetic_ppl"]
+    # the same steps with the range-sharded store's exchange forced through RCCL (one rank): rows prefetched on the fetch stream, two
+    # batches in flight on their lanes -- the same scores
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *common, "--lanes", "2", "--force-exchange"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert r["config"]["knn_search"]["lanes"] == 2 and r["config"]["store"].startswith("range-sharded") and r["config"]["collective_backend"] == "nccl"
+    assert r["config"]["synthetic_ppl"] == out["1"]["config"]["synthetic_ppl"]
 
 
 def test_bench_modes_agree():
@@ -114,7 +122,7 @@ def test_bench_two_ranks_search_inside_the_step():
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     c = r["config"]
     assert r["n_gpus"] == 2 and r["value"] > 0 and r["value_includes_search"] is True and r["scaling"] == "weak"
-    assert c["knn_search"]["where"].startswith("on the device") and c["knn_search"]["lanes"] == 1 and c["knn_search"]["parity"]["ok"] is True
+    assert c["knn_search"]["where"].startswith("on the device") and c["knn_search"]["lanes"] == 2 and c["knn_search"]["parity"]["ok"] is True   # (two batches in flight on every rank, as at N = 1; the exchange stays on its own stream)
     assert c["store"].startswith("range-sharded") and c["collective_backend"] == "gloo" and c["rccl_ranks"] == 0
 
 
