@@ -508,7 +508,7 @@ def main(args, tables=None, model=None):
             toks = torch.cat([h[0]["tokens"].reshape(-1) for h in hypos])
             n_new = min(keys.shape[0], save["size"] - save["idx"])
             if n_new < keys.shape[0]:
-                logger.warning("exceed offset at sample " + str(i))          # :227-230
+                logger.warning("exceed offset at sample " + str(int(sample["id"][0])))          # :227-230
             sl = slice(save["idx"], save["idx"] + n_new)
             save["keys"][sl] = keys[:n_new].to(torch.float16 if save["keys"].dtype == np.float16 else torch.float32).cpu().numpy()
             save["vals"][sl, 0] = toks[:n_new].cpu().numpy().astype(save["vals"].dtype)

@@ -44,3 +44,29 @@ def test_plain_multi_gpu_launch_spawns_torch_distributed_run(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_roofline_helpers_are_consistent():
+    """The filter's roofline line (`bench.filter_roofline`): achieved = table-byte look-ups x 32 int8 ops / time, priced against the dense
+    int8 peak; the PMC traffic of a profile id is the launch-weighted mean over the kernels launched under it (`bench.PMC_FAMILIES`:
+    the GEMM id covers the log-sum-exp A-stationary kernel, the filter id only the `<false>` instantiation) and is dropped when the
+    profile was measured on other kernel sources."""
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    r = bench.filter_roofline(total_ms=28.0, launches=1, pairs=32768 * 806461.0)
+    assert r["bound"] == "mfma" and r["unit"].startswith("TOP/s") and abs(r["achieved"] - 32768 * 806461 * 64 * 32 / 0.028 / 1e12) < 0.1
+    assert abs(r["frac"] - r["achieved"] / 5000.0) < 1e-3 and 0.3 < r["frac"] < 0.5
+    fams = bench.PMC_FAMILIES
+    assert any("gemm_lse_astationary".startswith(f) for f in fams["gemm_nt_f32_kernel"])
+    assert "ivfpq_scan8_kernel<false>" in fams["ivfpq_scan8_kernel"] and "ivfpq_scan8_kernel<true>" not in fams["ivfpq_scan8_kernel"]
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        t = json.load(f)
+    stamped = t["_meta"]["kernel_source_hash"] == bench.kernel_source_hash()
+    val, src = bench.pmc_traffic("ivfpq_scan8_kernel")
+    if stamped:
+        k = t["ivfpq_scan8_kernel<false>"]
+        assert val == round(k["hbm_bytes_per_launch"]) and src == t["_meta"]["profile"]
+    else:
+        assert val is None and "other kernel sources" in src
