@@ -36,8 +36,8 @@ SPLIT_PRODUCTS = {"f32": 1, "bf16x3": 3, "bf16x6": 6}            # bf16 MFMA pro
 KERNEL_BOUND = {"gemm_nt_f32_kernel": "mfma", "causal_attn_kernel": "mfma", "ivfpq_scan8_kernel": "mfma", "ivfpq_sums_kernel": "mfma"}     # everything else on this path: hbm
 # rocprof kernel names (profiles/pmc_traffic.json keys) behind a profile id of the library (csrc/common.h KernelId)
 PMC_FAMILIES = {"gemm_nt_f32_kernel": ["gemm_nt_f32", "gemm_lse_astationary"],
-                "ivfpq_scan8_kernel": ["ivfpq_scan8_kernel<false>", "search:ivfpq_scan8_kernel<false>"],
-                "ivfpq_sums_kernel": ["ivfpq_scan8_kernel<true>", "search:ivfpq_scan8_kernel<true>"]}
+                "ivfpq_scan8_kernel": ["ivfpq_scan8_kernel<false>"],      # (the "search:" rows of the file are tools/profile_search.sh's 8192-query launches)
+                "ivfpq_sums_kernel": ["ivfpq_scan8_kernel<true>"]}
 
 
 def parse():
